@@ -1,0 +1,93 @@
+"""Pin the oracle (oracle/speex_oracle.c) to the reference: every golden vector produced by
+the reference itself (native C + shipped WASM, tests/golden/make_golden.py) must be reproduced
+BIT-FOR-BIT by the restatement -- lengths, counters, table bits and output bytes."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from golden_util import drive, make_input, sha1
+
+
+def test_lcg_generator_matches_scalar_definition():
+    s, ref = 12345, []
+    for _ in range(1000):
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        v = s >> 16
+        ref.append(v - 65536 if v >= 32768 else v)
+    assert orc.lcg_pcm(1000, 12345).tolist() == ref
+
+
+def test_golden_inputs_regenerate(golden):
+    for c in golden["cases"]:
+        if c["frames"] <= 100000:
+            assert sha1(make_input(c)) == c["input_sha1"], c["name"]
+
+
+def test_oracle_reproduces_every_golden_case(golden):
+    for c in golden["cases"]:
+        x = make_input(c)
+        assert sha1(x) == c["input_sha1"], c["name"]
+        o = orc.Oracle(c["channels"], c["in_rate"], c["out_rate"], c["quality"])
+        assert (o.num, o.den, o.taps, o.oversample, o.kind, o.table_len) == (
+            c["num"], c["den"], c["taps"], c["oversample"], c["kind"], c["table_len"]), c["name"]
+        assert sha1(o.table()) == c["table_sha1"], c["name"] + ": filter table bits differ"
+        out, calls = drive(o, c, x)
+        assert out.shape[0] == c["out_frames"], c["name"]
+        assert calls[: len(c["calls"])] == c["calls"], c["name"] + ": per-call counters differ"
+        assert sha1(out) == c["out_sha1"], c["name"] + ": output bytes differ"
+        if "out_full" in c:
+            assert out.reshape(-1).tolist() == c["out_full"], c["name"]
+        assert out[:8].reshape(-1).tolist() == c["head"] and out[-8:].reshape(-1).tolist() == c["tail"]
+
+
+def test_oracle_bookkeeping_matches_planner_goldens(golden):
+    for p in golden["planner"]:
+        o = orc.Oracle(1, p["in_rate"], p["out_rate"], p["quality"])
+        for (f, cap, used, n_out, pos, ph) in p["calls"]:
+            out, u = o.process(np.zeros((f, 1), np.int16), cap)
+            assert (u, out.shape[0]) + o.position() == (used, n_out, pos, ph), (p["in_rate"], p["out_rate"])
+
+
+def test_oracle_error_paths():
+    for args in [(0, 44100, 48000, 7), (2, 0, 48000, 7), (2, 44100, 0, 7), (2, 44100, 48000, 11),
+                 (2, 44100, 48000, -1)]:
+        with pytest.raises(ValueError, match="Invalid argument."):
+            orc.Oracle(*args)
+    orc.Oracle(1, 8000, 8000, 0)  # quality 0 is accepted (reference resample.c:804)
+
+
+@pytest.mark.skipif(not orc.have_reference(), reason="oracle/_ref not built")
+def test_oracle_equals_reference_build_on_random_configs():
+    rng = np.random.RandomState(1)
+    rates = [8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 96000]
+    for trial in range(40):
+        ch = int(rng.randint(1, 5))
+        i, o = int(rng.choice(rates)), int(rng.choice(rates))
+        q = int(rng.randint(0, 11))
+        a, r = orc.Oracle(ch, i, o, q), orc.Reference(ch, i, o, q)
+        assert np.array_equal(a.table().view(np.uint32), r.table().view(np.uint32))
+        for call in range(4):
+            f = int(rng.choice([0, 1, 100, 777, 3000]))
+            cap = int(rng.choice([0, 10, 1000, 100000]))
+            x = orc.lcg_pcm(f * ch, trial * 10 + call).reshape(f, ch)
+            oa, ua = a.process(x, cap)
+            orr, ur = r.process(x, cap)
+            assert ua == ur and np.array_equal(oa, orr) and a.position() == r.position()
+            for c in range(ch):
+                assert np.array_equal(a.history(c), r.history(c))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/resources"), reason="reference fixtures absent")
+def test_oracle_on_the_reference_fixture_files(golden):
+    """The reference's own resources/*.pcm (not copied into this repo): digests from SURVEY section 4."""
+    for r in golden["resources"]:
+        raw = np.fromfile(os.path.join("/root/reference/resources", r["file"]), dtype=np.uint8)
+        raw = raw[: raw.size - raw.size % (2 * r["channels"])]
+        x = raw.view(np.int16).reshape(-1, r["channels"])
+        spec = dict(channels=r["channels"], in_rate=r["in_rate"], out_rate=r["out_rate"], chunks="whole")
+        out, _ = drive(orc.Oracle(r["channels"], r["in_rate"], r["out_rate"], r["quality"]), spec, x)
+        assert out.shape[0] == r["out_frames"] and sha1(out) == r["sha1"], r["file"]
+        # the reference test's only assertion (src/test.ts:40): durations agree within 10 ms
+        assert abs(x.shape[0] / r["in_rate"] - out.shape[0] / r["out_rate"]) < 0.01
