@@ -1,0 +1,164 @@
+// c_api.cpp -- the extern "C" boundary declared in include/speexhip_resampler.h.
+#include <cstring>
+#include <new>
+
+#include "../../include/speexhip_resampler.h"
+#include "engine.h"
+
+using speexhip::Batch;
+
+struct SpeexHipResamplerState_ {
+  Batch *batch;
+};
+struct SpeexHipBatch_ {
+  Batch *batch;
+};
+
+extern "C" {
+
+SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channels, uint32_t in_rate,
+                                                uint32_t out_rate, int quality, int *err) {
+  Batch *b = Batch::create(1, nb_channels, in_rate, out_rate, quality, err);
+  if (b == nullptr) return nullptr;
+  SpeexHipResamplerState *st = new (std::nothrow) SpeexHipResamplerState_{b};
+  if (st == nullptr) {
+    delete b;
+    if (err) *err = SPEEXHIP_ERR_ALLOC_FAILED;
+  }
+  return st;
+}
+
+void speexhip_resampler_destroy(SpeexHipResamplerState *st) {
+  if (st == nullptr) return;
+  delete st->batch;
+  delete st;
+}
+
+int speexhip_resampler_process_interleaved_int(SpeexHipResamplerState *st, const int16_t *in,
+                                               uint32_t *in_len, int16_t *out, uint32_t *out_len) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
+    return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->process_host(in, in_len, out, out_len);
+}
+
+int speexhip_resampler_process_interleaved_int_device(SpeexHipResamplerState *st, const int16_t *d_in,
+                                                      uint32_t *in_len, int16_t *d_out,
+                                                      uint32_t *out_len, void *hip_stream) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->process_device(d_in, 0, in_len, d_out, 0, out_len,
+                                   static_cast<hipStream_t>(hip_stream));
+}
+
+void speexhip_resampler_get_rate(SpeexHipResamplerState *st, uint32_t *in_rate, uint32_t *out_rate) {
+  *in_rate = st->batch->filter().in_rate;
+  *out_rate = st->batch->filter().out_rate;
+}
+
+const char *speexhip_resampler_strerror(int err) {
+  switch (err) {  // reference resample.c:1222-1239
+    case SPEEXHIP_ERR_SUCCESS: return "Success.";
+    case SPEEXHIP_ERR_ALLOC_FAILED: return "Memory allocation failed.";
+    case SPEEXHIP_ERR_BAD_STATE: return "Bad resampler state.";
+    case SPEEXHIP_ERR_INVALID_ARG: return "Invalid argument.";
+    case SPEEXHIP_ERR_PTR_OVERLAP: return "Input and output buffers overlap.";
+    case SPEEXHIP_ERR_DEVICE: return speexhip::last_device_error();
+    default: return "Unknown error. Bad error code or strange version mismatch.";
+  }
+}
+
+int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode) {
+  return st ? st->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG;
+}
+
+int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info) {
+  if (st == nullptr || info == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  st->batch->info(0, info);
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int speexhip_resampler_get_history(SpeexHipResamplerState *st, int16_t *dst) {
+  if (st == nullptr || dst == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->history(0, dst);
+}
+
+SpeexHipBatch *speexhip_batch_init(uint32_t n_streams, uint32_t nb_channels, uint32_t in_rate,
+                                   uint32_t out_rate, int quality, int *err) {
+  Batch *b = Batch::create(n_streams, nb_channels, in_rate, out_rate, quality, err);
+  if (b == nullptr) return nullptr;
+  SpeexHipBatch *h = new (std::nothrow) SpeexHipBatch_{b};
+  if (h == nullptr) {
+    delete b;
+    if (err) *err = SPEEXHIP_ERR_ALLOC_FAILED;
+  }
+  return h;
+}
+
+void speexhip_batch_destroy(SpeexHipBatch *b) {
+  if (b == nullptr) return;
+  delete b->batch;
+  delete b;
+}
+
+int speexhip_batch_set_mode(SpeexHipBatch *b, int mode) {
+  return b ? b->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG;
+}
+
+int speexhip_batch_get_info(SpeexHipBatch *b, uint32_t stream, SpeexHipInfo *info) {
+  if (b == nullptr || info == nullptr || stream >= b->batch->n_streams()) return SPEEXHIP_ERR_INVALID_ARG;
+  b->batch->info(stream, info);
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int speexhip_batch_process_interleaved_int_device(SpeexHipBatch *b, const int16_t *d_in,
+                                                  uint64_t in_stream_stride, uint32_t *in_len,
+                                                  int16_t *d_out, uint64_t out_stream_stride,
+                                                  uint32_t *out_len, void *hip_stream) {
+  if (b == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return b->batch->process_device(d_in, in_stream_stride, in_len, d_out, out_stream_stride, out_len,
+                                  static_cast<hipStream_t>(hip_stream));
+}
+
+int speexhip_design_filter(uint32_t in_rate, uint32_t out_rate, int quality, SpeexHipInfo *info,
+                           float *table, uint32_t table_capacity) {
+  speexhip::FilterSpec f;
+  const int rc = speexhip::design_filter(in_rate, out_rate, quality, &f, table != nullptr);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  if (info != nullptr) {
+    std::memset(info, 0, sizeof(*info));
+    info->in_rate = f.in_rate;
+    info->out_rate = f.out_rate;
+    info->num_rate = f.num;
+    info->den_rate = f.den;
+    info->quality = f.quality;
+    info->filt_len = f.taps;
+    info->oversample = f.oversample;
+    info->sinc_table_length = f.table_len;
+    info->kernel = f.kind;
+    info->device = -1;
+  }
+  if (table != nullptr) {
+    const uint32_t n = f.table_len < table_capacity ? f.table_len : table_capacity;
+    std::memcpy(table, f.table.data(), sizeof(float) * n);
+  }
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int speexhip_plan_call(uint32_t num_rate, uint32_t den_rate, uint32_t in_len, uint32_t out_cap,
+                       int32_t *last_sample, uint32_t *samp_frac_num, uint32_t *consumed,
+                       uint32_t *produced) {
+  if (num_rate == 0 || den_rate == 0 || last_sample == nullptr || samp_frac_num == nullptr)
+    return SPEEXHIP_ERR_INVALID_ARG;
+  speexhip::StreamPos p;
+  p.last = *last_sample;
+  p.frac = *samp_frac_num;
+  const speexhip::CallPlan plan = speexhip::plan_call(num_rate, den_rate, in_len, out_cap, p);
+  *last_sample = plan.end.last;
+  *samp_frac_num = plan.end.frac;
+  if (consumed) *consumed = plan.consumed;
+  if (produced) *produced = plan.produced;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+const char *speexhip_version(void) { return "speexhip 0.1.0 gfx950"; }
+
+}  // extern "C"

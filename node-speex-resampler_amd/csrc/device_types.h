@@ -1,0 +1,54 @@
+// device_types.h -- plain structs shared by the host engine and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace speexhip {
+
+// One stream's share of one processing call.  V = history ++ input is the virtual frame
+// sequence the FIR windows index (history = the last taps-1 consumed frames, zeros at start:
+// reference resample.c:721-725, 898-899).
+struct StreamDesc {
+  const int16_t *in;    // interleaved s16, in_frames frames (device); NULL = silence
+  const int16_t *hist;  // (taps-1) frames, interleaved (device)
+  int16_t *out;         // interleaved s16, room for n_out frames (device)
+  int16_t *hist_next;   // where this call leaves the next call's history
+  uint32_t in_frames;
+  uint32_t n_out;       // frames to produce (host planner)
+  uint32_t consumed;    // input frames entering the history
+  int32_t last0;        // window start of output 0, in V-frames minus (taps-1) offset: see pos()
+  uint32_t frac0;       // phase numerator of output 0
+  uint32_t k_shift;     // phase_index_of(frac0): canonical phase index of output 0
+  int32_t base_shift;   // last0 - (k_shift*num) div den  (tiled kernel's period origin)
+  uint32_t tile_begin;  // first tile of this stream in the launch's flat tile list
+};
+
+static const int kMaxPackedStreams = 8;
+struct DescPack {  // small batches travel in the kernel-argument segment (no H2D copy)
+  StreamDesc d[kMaxPackedStreams];
+};
+
+struct ExactParams {
+  const float *table;   // reference-layout sinc table (device)
+  uint32_t table_len;
+  uint32_t num, den;
+  uint32_t taps, oversample;
+  uint32_t channels;
+  uint32_t outs_per_block;  // output frames per workgroup (== blockDim.x)
+  uint32_t span_cap;        // frames of LDS sample window per workgroup
+};
+
+struct TiledParams {
+  const float *rows;      // phase rows, layout [s/4][i][g] of float4 (device)
+  uint32_t table_f4;      // float4 count of the rows
+  uint32_t l4;            // row length / 4
+  uint32_t groups;        // phase groups (R phases each)
+  uint32_t cgroups;       // channel groups (CT channels each)
+  uint32_t num, den, taps, channels;
+  uint32_t periods;       // output periods (den outputs each) per workgroup
+  uint32_t mgroups;       // periods / M
+  uint32_t ksplit;        // lanes sharing one output's tap range (1, 2 or 4)
+  uint32_t s4_per_slice;  // float4 steps per tap slice
+  uint32_t tail_frames;   // input frames a period needs beyond its start
+};
+
+}  // namespace speexhip

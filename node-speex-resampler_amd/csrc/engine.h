@@ -1,0 +1,74 @@
+// engine.h -- host engine: owns device state for a batch of independent streams that share
+// one filter, plans each call on the host and launches the HIP kernels (product code).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/speexhip_resampler.h"
+#include "device_types.h"
+#include "filter_design.h"
+#include "kernels.h"
+#include "stream_plan.h"
+
+namespace speexhip {
+
+const char *last_device_error();  // text of the most recent HIP failure on this thread
+
+class Batch {
+ public:
+  // Returns nullptr and sets *err on failure.  Uses the calling thread's current HIP device.
+  static Batch *create(uint32_t n_streams, uint32_t channels, uint32_t in_rate, uint32_t out_rate,
+                       int quality, int *err);
+  ~Batch();
+
+  // Device-resident call for all streams; asynchronous on `stream`.
+  int process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_len, int16_t *d_out,
+                     uint64_t out_stride, uint32_t *out_len, hipStream_t stream);
+  // Host-buffer call for a single-stream batch; synchronous (H2D, kernels, D2H).
+  int process_host(const int16_t *in, uint32_t *in_len, int16_t *out, uint32_t *out_len);
+
+  int set_mode(int mode);
+  void info(uint32_t stream, SpeexHipInfo *out) const;
+  int history(uint32_t stream, int16_t *dst);
+  const FilterSpec &filter() const { return filter_; }
+  uint32_t n_streams() const { return n_streams_; }
+
+ private:
+  Batch() = default;
+  int setup();
+  int ensure_stage(size_t in_elems, size_t out_elems);
+
+  FilterSpec filter_;
+  uint32_t n_streams_ = 0, channels_ = 0;
+  int device_ = 0;
+  int mode_ = SPEEXHIP_MODE_FAST;
+  std::vector<StreamPos> pos_;
+
+  float *d_table_ = nullptr;
+  int16_t *d_hist_[2] = {nullptr, nullptr};
+  size_t hist_elems_ = 0;  // per stream: (taps-1)*channels
+  int hist_cur_ = 0;
+
+  ExactGeometry exact_geo_;
+  TiledPlan tiled_;        // fast path (kernels_tiled.hip); tiled_.usable == false -> exact
+  float *d_phase_rows_ = nullptr;
+
+  // descriptor transport for batches larger than kMaxPackedStreams
+  static const int kRing = 32;
+  StreamDesc *h_ring_ = nullptr;  // pinned
+  StreamDesc *d_ring_ = nullptr;
+  hipEvent_t ring_done_[kRing] = {};
+  bool ring_busy_[kRing] = {};
+  int ring_next_ = 0;
+
+  // host-buffer path (single stream)
+  hipStream_t own_stream_ = nullptr;
+  int16_t *d_stage_in_ = nullptr, *d_stage_out_ = nullptr;
+  int16_t *h_pin_in_ = nullptr, *h_pin_out_ = nullptr;
+  size_t stage_in_cap_ = 0, stage_out_cap_ = 0;
+};
+
+}  // namespace speexhip

@@ -1,0 +1,48 @@
+// kernels.h -- host-callable launchers of the HIP kernels (product code).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "device_types.h"
+#include "filter_design.h"
+
+namespace speexhip {
+
+// ---- bit-exact kernels (kernels_exact.hip) -------------------------------------------------
+struct ExactGeometry {
+  int ct = 1;                  // channels per lane (2 when the channel count is even)
+  uint32_t channel_groups = 1;
+  uint32_t outs_per_block = 256;
+  uint32_t span_cap = 0;
+  size_t lds_bytes = 0;
+  bool staged = true;          // false: filter/window too large for LDS, read through L2
+};
+ExactGeometry exact_geometry(const FilterSpec &f, uint32_t channels, size_t lds_budget);
+hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float *d_table,
+                        uint32_t channels, const StreamDesc *d_descs, const DescPack *pack,
+                        uint32_t n_streams, uint32_t max_n_out, hipStream_t stream);
+
+// ---- fast tiled kernel (kernels_tiled.hip) -------------------------------------------------
+struct TiledPlan {          // per filter, fixed at init
+  bool usable = false;      // false: this configuration runs the exact kernel in FAST mode too
+  int r = 1, m = 1, ct = 1; // register tile: phases x periods x channels per lane
+  uint32_t groups = 0, cgroups = 0;
+  uint32_t row_len = 0, l4 = 0, table_f4 = 0, tail_frames = 0;
+  size_t table_bytes = 0, lds_budget = 0;
+};
+struct TiledLaunch {        // per call
+  uint32_t periods = 0, mgroups = 0, ksplit = 1, s4_per_slice = 0, threads = 0, blocks = 0;
+  size_t lds_bytes = 0;
+};
+TiledPlan plan_tiled(const FilterSpec &f, uint32_t channels, size_t lds_budget);
+void build_phase_rows(const FilterSpec &f, const TiledPlan &t, std::vector<float> *rows);
+TiledLaunch tiled_geometry(const FilterSpec &f, const TiledPlan &t, uint32_t channels,
+                           uint32_t n_streams, uint32_t max_periods, uint32_t target_workgroups);
+hipError_t launch_tiled(const FilterSpec &f, const TiledPlan &t, const float *d_rows, uint32_t channels,
+                        const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                        uint32_t n_streams, uint32_t max_n_out, hipStream_t stream);
+
+}  // namespace speexhip

@@ -1,0 +1,253 @@
+"""ctypes binding of libspeexhip.so (include/speexhip_resampler.h) plus a Python mirror of the
+reference's host class (``SpeexResampler.processChunk``, reference src/index.ts:21-117) so that
+the parity tests and bench.py can drive the HIP path without Node.
+
+There is NO fallback: if the library is missing or no MI355X is usable, calls raise.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libspeexhip.so")
+
+MODE_FAST, MODE_EXACT = 0, 1
+KERNEL_NAMES = ("direct_single", "direct_double", "interpolate_single", "interpolate_double")
+ERR_DEVICE = 6
+
+EXPORTS = [
+    "speexhip_resampler_init", "speexhip_resampler_destroy",
+    "speexhip_resampler_process_interleaved_int", "speexhip_resampler_get_rate",
+    "speexhip_resampler_strerror", "speexhip_resampler_process_interleaved_int_device",
+    "speexhip_resampler_set_mode", "speexhip_resampler_get_info", "speexhip_resampler_get_history",
+    "speexhip_batch_init", "speexhip_batch_destroy", "speexhip_batch_set_mode",
+    "speexhip_batch_get_info", "speexhip_batch_process_interleaved_int_device",
+    "speexhip_design_filter", "speexhip_plan_call", "speexhip_version",
+]
+
+
+class Info(C.Structure):
+    _fields_ = [("in_rate", C.c_uint32), ("out_rate", C.c_uint32), ("num_rate", C.c_uint32),
+                ("den_rate", C.c_uint32), ("nb_channels", C.c_uint32), ("quality", C.c_int32),
+                ("filt_len", C.c_uint32), ("oversample", C.c_uint32),
+                ("sinc_table_length", C.c_uint32), ("kernel", C.c_int32), ("mode", C.c_int32),
+                ("fast_path", C.c_int32), ("last_sample", C.c_int32), ("samp_frac_num", C.c_uint32),
+                ("device", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Load libspeexhip.so or raise (the product path never degrades to a CPU implementation)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libspeexhip.so not built: run `python __graft_entry__.py` or "
+                               "`make -C node-speex-resampler_amd` (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        u32, i32, p = C.c_uint32, C.c_int, C.c_void_p
+        pu32, pi16 = C.POINTER(C.c_uint32), C.POINTER(C.c_int16)
+        L.speexhip_resampler_init.restype = p
+        L.speexhip_resampler_init.argtypes = [u32, u32, u32, i32, C.POINTER(C.c_int)]
+        L.speexhip_resampler_destroy.argtypes = [p]
+        L.speexhip_resampler_process_interleaved_int.restype = i32
+        L.speexhip_resampler_process_interleaved_int.argtypes = [p, pi16, pu32, pi16, pu32]
+        L.speexhip_resampler_process_interleaved_int_device.restype = i32
+        L.speexhip_resampler_process_interleaved_int_device.argtypes = [p, p, pu32, p, pu32, p]
+        L.speexhip_resampler_get_rate.argtypes = [p, pu32, pu32]
+        L.speexhip_resampler_strerror.restype = C.c_char_p
+        L.speexhip_resampler_strerror.argtypes = [i32]
+        L.speexhip_resampler_set_mode.restype = i32
+        L.speexhip_resampler_set_mode.argtypes = [p, i32]
+        L.speexhip_resampler_get_info.restype = i32
+        L.speexhip_resampler_get_info.argtypes = [p, C.POINTER(Info)]
+        L.speexhip_resampler_get_history.restype = i32
+        L.speexhip_resampler_get_history.argtypes = [p, pi16]
+        L.speexhip_batch_init.restype = p
+        L.speexhip_batch_init.argtypes = [u32, u32, u32, u32, i32, C.POINTER(C.c_int)]
+        L.speexhip_batch_destroy.argtypes = [p]
+        L.speexhip_batch_set_mode.restype = i32
+        L.speexhip_batch_set_mode.argtypes = [p, i32]
+        L.speexhip_batch_get_info.restype = i32
+        L.speexhip_batch_get_info.argtypes = [p, u32, C.POINTER(Info)]
+        L.speexhip_batch_process_interleaved_int_device.restype = i32
+        L.speexhip_batch_process_interleaved_int_device.argtypes = [p, p, C.c_uint64, pu32, p,
+                                                                    C.c_uint64, pu32, p]
+        L.speexhip_design_filter.restype = i32
+        L.speexhip_design_filter.argtypes = [u32, u32, i32, C.POINTER(Info), C.POINTER(C.c_float), u32]
+        L.speexhip_plan_call.restype = i32
+        L.speexhip_plan_call.argtypes = [u32, u32, u32, u32, C.POINTER(C.c_int32), pu32, pu32, pu32]
+        L.speexhip_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def strerror(code):
+    return lib().speexhip_resampler_strerror(code).decode()
+
+
+def design_filter(in_rate, out_rate, quality, want_table=True):
+    """Host-only filter design; returns (info dict, table float32 array or None)."""
+    info = Info()
+    rc = lib().speexhip_design_filter(in_rate, out_rate, quality, C.byref(info), None, 0)
+    if rc != 0:
+        raise ValueError(strerror(rc))
+    table = None
+    if want_table:
+        table = np.zeros(info.sinc_table_length, np.float32)
+        rc = lib().speexhip_design_filter(in_rate, out_rate, quality, C.byref(info),
+                                          table.ctypes.data_as(C.POINTER(C.c_float)), table.size)
+        assert rc == 0
+    return info.as_dict(), table
+
+
+def plan_call(num, den, in_len, out_cap, last, frac):
+    """Host-only stream bookkeeping; returns (consumed, produced, last', frac')."""
+    l, f, c, p = C.c_int32(last), C.c_uint32(frac), C.c_uint32(), C.c_uint32()
+    rc = lib().speexhip_plan_call(num, den, in_len, out_cap, C.byref(l), C.byref(f), C.byref(c),
+                                  C.byref(p))
+    if rc != 0:
+        raise ValueError(strerror(rc))
+    return c.value, p.value, l.value, f.value
+
+
+class Resampler:
+    """Thin object over the C ABI state: host-buffer ``process`` and device-pointer
+    ``process_device`` (same signature as oracle.Oracle.process for the shared test driver)."""
+
+    def __init__(self, channels, in_rate, out_rate, quality=7, mode=None):
+        err = C.c_int(0)
+        self._h = lib().speexhip_resampler_init(channels, in_rate, out_rate, quality, C.byref(err))
+        if not self._h:
+            raise (RuntimeError if err.value == ERR_DEVICE else ValueError)(strerror(err.value))
+        self.channels = channels
+        if mode is not None:
+            self.set_mode(mode)
+        i = self.info()
+        self.num, self.den, self.taps = i["num_rate"], i["den_rate"], i["filt_len"]
+        self.oversample, self.kind = i["oversample"], KERNEL_NAMES[i["kernel"]]
+        self.table_len = i["sinc_table_length"]
+
+    def set_mode(self, mode):
+        rc = lib().speexhip_resampler_set_mode(self._h, mode)
+        if rc:
+            raise ValueError(strerror(rc))
+
+    def info(self):
+        i = Info()
+        lib().speexhip_resampler_get_info(self._h, C.byref(i))
+        return i.as_dict()
+
+    def position(self):
+        i = self.info()
+        return i["last_sample"], i["samp_frac_num"]
+
+    def history(self):
+        buf = np.zeros(((self.taps - 1), self.channels), np.int16)
+        rc = lib().speexhip_resampler_get_history(self._h, buf.ctypes.data_as(C.POINTER(C.c_int16)))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return buf
+
+    def process(self, frames, out_capacity):
+        frames = np.ascontiguousarray(frames, dtype=np.int16)
+        if frames.ndim == 1:
+            frames = frames.reshape(-1, self.channels)
+        out = np.zeros((max(int(out_capacity), 1), self.channels), np.int16)
+        il, ol = C.c_uint32(frames.shape[0]), C.c_uint32(int(out_capacity))
+        rc = lib().speexhip_resampler_process_interleaved_int(
+            self._h, frames.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(il),
+            out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(ol))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return out[: ol.value].copy(), il.value
+
+    def process_device(self, d_in_ptr, in_frames, d_out_ptr, out_capacity, stream_ptr=0):
+        il, ol = C.c_uint32(in_frames), C.c_uint32(out_capacity)
+        rc = lib().speexhip_resampler_process_interleaved_int_device(
+            self._h, C.c_void_p(d_in_ptr), C.byref(il), C.c_void_p(d_out_ptr), C.byref(ol),
+            C.c_void_p(stream_ptr))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return il.value, ol.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().speexhip_resampler_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class Batch:
+    """n_streams independent streams with one shared filter; device pointers, one launch/call."""
+
+    def __init__(self, n_streams, channels, in_rate, out_rate, quality=7, mode=None):
+        err = C.c_int(0)
+        self._h = lib().speexhip_batch_init(n_streams, channels, in_rate, out_rate, quality,
+                                            C.byref(err))
+        if not self._h:
+            raise (RuntimeError if err.value == ERR_DEVICE else ValueError)(strerror(err.value))
+        self.n_streams, self.channels = n_streams, channels
+        if mode is not None:
+            rc = lib().speexhip_batch_set_mode(self._h, mode)
+            if rc:
+                raise ValueError(strerror(rc))
+
+    def info(self, stream=0):
+        i = Info()
+        lib().speexhip_batch_get_info(self._h, stream, C.byref(i))
+        return i.as_dict()
+
+    def process_device(self, d_in_ptr, in_stride, in_frames, d_out_ptr, out_stride, out_capacity,
+                       stream_ptr=0):
+        """in_frames / out_capacity: int (same for all streams) or sequences of n_streams."""
+        n = self.n_streams
+        il = (C.c_uint32 * n)(*([in_frames] * n if np.isscalar(in_frames) else in_frames))
+        ol = (C.c_uint32 * n)(*([out_capacity] * n if np.isscalar(out_capacity) else out_capacity))
+        rc = lib().speexhip_batch_process_interleaved_int_device(
+            self._h, C.c_void_p(d_in_ptr), in_stride, il, C.c_void_p(d_out_ptr), out_stride, ol,
+            C.c_void_p(stream_ptr))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return list(il), list(ol)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().speexhip_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class SpeexResampler:
+    """Python mirror of the reference's TypeScript class (src/index.ts:21-117), over the HIP
+    library: same constructor arguments, lazy init, messages, length check and -- crucially --
+    the grow-only output-capacity rule (src/index.ts:80-87,95) that decides how many frames
+    each processChunk call may emit (and silently drops the rest)."""
+
+    def __init__(self, channels, inRate, outRate, quality=7):
+        self.channels, self.inRate, self.outRate, self.quality = channels, inRate, outRate, quality
+        self._res = None
+        self._outBufferSize = -1
+
+    def processChunk(self, chunk):
+        chunk = bytes(chunk) if not isinstance(chunk, (bytes, bytearray, memoryview)) else chunk
+        n = len(chunk)
+        if self.channels == 0 or n % (self.channels * 2) != 0:  # JS: x % 0 is NaN !== 0
+            raise ValueError("Chunk length should be a multiple of channels * 2 bytes")
+        if self._res is None:
+            self._res = Resampler(self.channels, self.inRate, self.outRate, self.quality)
+        target = math.ceil(n * self.outRate / self.inRate)
+        if self._outBufferSize < target:
+            self._outBufferSize = target
+        capacity = int(self._outBufferSize / self.channels / 2)
+        frames = np.frombuffer(chunk, dtype=np.int16).reshape(-1, self.channels)
+        out, _ = self._res.process(frames, capacity)
+        return out.tobytes()

@@ -1,0 +1,164 @@
+"""CPU tests of the PRODUCT's host side (no GPU, no compute calls): the C-ABI library loads and
+exports every symbol include/*.h declares; its filter design reproduces the reference's table
+bits; its closed-form stream planner reproduces the reference's per-call counters."""
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import speexhip
+from golden_util import ROOT
+
+
+def sha1(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = speexhip.lib()
+    header = open(os.path.join(ROOT, "include", "speexhip_resampler.h")).read()
+    declared = set(re.findall(r"\b(speexhip_\w+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(speexhip.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), "missing export " + name
+    out = subprocess.run(["nm", "-D", "--defined-only", speexhip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (\w+)", out))
+    assert declared <= exported
+    assert b"gfx950" in lib.speexhip_version()
+
+
+def test_strerror_matches_reference_strings():
+    # reference resample.c:1222-1239 (5 = OVERFLOW has no case there -> "Unknown error...")
+    assert speexhip.strerror(0) == "Success."
+    assert speexhip.strerror(1) == "Memory allocation failed."
+    assert speexhip.strerror(2) == "Bad resampler state."
+    assert speexhip.strerror(3) == "Invalid argument."
+    assert speexhip.strerror(4) == "Input and output buffers overlap."
+    assert speexhip.strerror(5) == "Unknown error. Bad error code or strange version mismatch."
+    assert speexhip.strerror(99) == "Unknown error. Bad error code or strange version mismatch."
+
+
+def test_filter_design_bits_match_reference_goldens(golden):
+    seen = set()
+    for c in golden["cases"]:
+        key = (c["in_rate"], c["out_rate"], c["quality"])
+        if key in seen:
+            continue
+        seen.add(key)
+        info, table = speexhip.design_filter(*key)
+        assert (info["num_rate"], info["den_rate"], info["filt_len"], info["oversample"],
+                speexhip.KERNEL_NAMES[info["kernel"]], info["sinc_table_length"]) == (
+            c["num"], c["den"], c["taps"], c["oversample"], c["kind"], c["table_len"]), c["name"]
+        assert sha1(table) == c["table_sha1"], c["name"] + ": product table differs from the reference"
+    assert len(seen) >= 12
+
+
+def test_filter_design_equals_oracle_on_a_rate_grid():
+    import oracle as orc
+    rates = [8000, 11025, 12000, 16000, 22050, 32000, 44100, 48000, 88200, 96000, 192000]
+    for i in rates:
+        for o in rates:
+            for q in (0, 3, 5, 8, 9, 10):
+                info, table = speexhip.design_filter(i, o, q)
+                ref = orc.Oracle(1, i, o, q)
+                assert (info["filt_len"], info["oversample"], speexhip.KERNEL_NAMES[info["kernel"]]) == (
+                    ref.taps, ref.oversample, ref.kind)
+                assert np.array_equal(table.view(np.uint32), ref.table().view(np.uint32)), (i, o, q)
+
+
+def test_design_filter_rejects_bad_arguments():
+    for args in [(0, 48000, 7), (44100, 0, 7), (44100, 48000, 11), (44100, 48000, -1)]:
+        with pytest.raises(ValueError, match="Invalid argument."):
+            speexhip.design_filter(*args)
+
+
+def test_planner_matches_reference_counters(golden):
+    for p in golden["planner"]:
+        info, _ = speexhip.design_filter(p["in_rate"], p["out_rate"], p["quality"], want_table=False)
+        last, frac = 0, 0
+        for (f, cap, used, n_out, pos, ph) in p["calls"]:
+            c, n, last, frac = speexhip.plan_call(info["num_rate"], info["den_rate"], f, cap, last, frac)
+            assert (c, n, last, frac) == (used, n_out, pos, ph), (p["in_rate"], p["out_rate"], f, cap)
+
+
+def test_planner_matches_every_golden_call_sequence(golden):
+    for c in golden["cases"]:
+        last, frac = 0, 0
+        for (f, cap, used, n_out, pos, ph) in c["calls"]:
+            got = speexhip.plan_call(c["num"], c["den"], f, cap, last, frac)
+            assert got == (used, n_out, pos, ph), c["name"]
+            last, frac = pos, ph
+
+
+def test_planner_equals_oracle_on_random_calls():
+    import oracle as orc
+    rng = np.random.RandomState(7)
+    for (i, o) in [(44100, 48000), (48000, 44100), (192000, 8000), (8000, 192000), (44101, 48000),
+                   (48000, 16000), (22050, 22050), (11025, 48000)]:
+        ref = orc.Oracle(1, i, o, 2)
+        last, frac = 0, 0
+        for _ in range(300):
+            f = int(rng.randint(0, 3000))
+            cap = int(rng.choice([0, 1, 7, 100, 1024, 5000, 1 << 20]))
+            out, used = ref.process(np.zeros((f, 1), np.int16), cap)
+            c, n, last, frac = speexhip.plan_call(ref.num, ref.den, f, cap, last, frac)
+            assert (c, n, last, frac) == (used, out.shape[0]) + ref.position()
+
+
+def test_init_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="HIP device error"):
+        speexhip.Resampler(2, 44100, 48000, 7)
+    # argument errors still win over the device check (reference order, resample.c:804-809)
+    with pytest.raises(ValueError, match="Invalid argument."):
+        speexhip.Resampler(2, 44100, 48000, 11)
+
+
+def test_python_mirror_keeps_the_wrapper_contract_without_touching_the_gpu():
+    r = speexhip.SpeexResampler(2, 44100, 48000)
+    assert (r.channels, r.inRate, r.outRate, r.quality) == (2, 44100, 48000, 7)
+    with pytest.raises(ValueError, match="Chunk length should be a multiple of channels \\* 2 bytes"):
+        r.processChunk(b"\0" * 7)
+    with pytest.raises(ValueError, match="Chunk length should be a multiple"):
+        speexhip.SpeexResampler(0, 44100, 48000).processChunk(b"\0" * 8)
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_node_addon_loads_and_mirrors_reference_errors():
+    addon = os.path.join(ROOT, "node-speex-resampler_amd", "speex_hip_napi.node")
+    if not os.path.exists(addon):
+        pytest.skip("addon not built")
+    js = r"""
+const R = require(process.argv[1]);
+const out = {};
+const grab = (k, f) => { try { f(); out[k] = 'no throw'; } catch (e) { out[k] = e.message; } };
+grab('early', () => new R.default(2, 44100, 48000).processChunk(Buffer.alloc(8)));
+R.default.initPromise.then(() => {
+  grab('len', () => new R.default(2, 44100, 48000).processChunk(Buffer.alloc(7)));
+  grab('ch0', () => new R.default(0, 44100, 48000).processChunk(Buffer.alloc(8)));
+  grab('q11', () => new R.default(2, 44100, 48000, 11).processChunk(Buffer.alloc(8)));
+  grab('rate0', () => new R.default(2, 0, 48000).processChunk(Buffer.alloc(8)));
+  const r = new R.default(2, 44100, 48000);
+  out.fields = [r.channels, r.inRate, r.outRate, r.quality];
+  out.exports = [typeof R.default, typeof R.SpeexResamplerTransform, typeof R.default.initPromise.then];
+  console.log(JSON.stringify(out));
+});
+"""
+    res = subprocess.run(["node", "-e", js, os.path.join(ROOT, "node-speex-resampler_amd", "index.js")],
+                         capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0, res.stderr
+    import json
+    out = json.loads(res.stdout)
+    assert out["early"] == "You need to wait for SpeexResampler.initPromise before calling this method"
+    assert out["len"] == "Chunk length should be a multiple of channels * 2 bytes"
+    assert out["ch0"] == "Chunk length should be a multiple of channels * 2 bytes"
+    assert out["q11"] == "Invalid argument." and out["rate0"] == "Invalid argument."
+    assert out["fields"] == [2, 44100, 48000, 7]
+    assert out["exports"] == ["function", "function", "function"]
