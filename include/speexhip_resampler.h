@@ -114,8 +114,8 @@ typedef struct SpeexHipInfo {
   uint32_t sinc_table_length;    /* floats, resample.c:652,657 */
   int32_t kernel;                /* SPEEXHIP_KERNEL_* */
   int32_t mode;                  /* SPEEXHIP_MODE_* */
-  int32_t fast_path;             /* 1 when FAST mode runs the tiled phase-table kernel, 0 when
-                                    it falls back to the exact kernel for this configuration */
+  int32_t fast_path;             /* what FAST mode runs for this configuration: 2 = period-lane
+                                    kernel, 1 = tiled kernel, 0 = falls back to the exact kernel */
   int32_t last_sample;           /* stream position, resample.c:135 */
   uint32_t samp_frac_num;        /* stream phase, resample.c:136 */
   int32_t device;                /* HIP device ordinal the state lives on */

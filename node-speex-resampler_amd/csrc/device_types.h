@@ -48,7 +48,23 @@ struct TiledParams {
   uint32_t mgroups;       // periods / M
   uint32_t ksplit;        // lanes sharing one output's tap range (1, 2 or 4)
   uint32_t s4_per_slice;  // float4 steps per tap slice
+  uint32_t slice_f4;      // float4 per tap slice in the global rows (s4_per_slice * R * groups)
+  uint32_t slice_pad_f4;  // float4 of LDS padding between slices (bank-conflict-free slices)
   uint32_t tail_frames;   // input frames a period needs beyond its start
+  uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP): bit0 rows, bit1 window, bit2 FIR loop,
+                          // bit3 stores -- phases to leave out when timing; 0 in normal operation
+};
+
+struct PeriodParams {
+  const float *rows;      // effective taps, layout [group][s/4][s%4][i] (device, read by scalar loads)
+  uint32_t l4;            // row length / 4
+  uint32_t groups;        // phase groups (R phases each)
+  uint32_t num, den, taps, channels;
+  uint32_t cgroups;       // channel groups per frame (CT channels each)
+  uint32_t lane_periods;  // output periods per workgroup tile (= lanes / cgroups)
+  uint32_t wave_groups;   // waves per workgroup; wave w of split z takes groups z*wave_groups+w, ...
+  uint32_t tail_frames;   // input frames a period needs beyond its start
+  uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP), 0 in normal operation
 };
 
 }  // namespace speexhip

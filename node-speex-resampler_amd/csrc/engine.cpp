@@ -85,6 +85,15 @@ int Batch::setup() {
     HIP_TRY(hipMalloc(&d_phase_rows_, rows.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(d_phase_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  period_ = plan_period(filter_, channels_, kLdsBudget);
+  if (period_.usable) {
+    std::vector<float> rows;
+    build_period_rows(filter_, period_, &rows);
+    HIP_TRY(hipMalloc(&d_period_rows_, rows.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_period_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  const char *fk = std::getenv("SPEEXHIP_FAST_KERNEL");
+  prefer_tiled_ = fk != nullptr && std::strcmp(fk, "tiled") == 0;
   if (n_streams_ > static_cast<uint32_t>(kMaxPackedStreams)) {
     const size_t ring_bytes = sizeof(StreamDesc) * n_streams_ * kRing;
     HIP_TRY(hipHostMalloc(&h_ring_, ring_bytes, hipHostMallocDefault));
@@ -101,6 +110,7 @@ Batch::~Batch() {
   (void)hipFree(d_hist_[0]);
   (void)hipFree(d_hist_[1]);
   (void)hipFree(d_phase_rows_);
+  (void)hipFree(d_period_rows_);
   (void)hipFree(d_ring_);
   if (h_ring_) (void)hipHostFree(h_ring_);
   for (int i = 0; i < kRing; i++)
@@ -131,7 +141,7 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
   o->sinc_table_length = filter_.table_len;
   o->kernel = filter_.kind;
   o->mode = mode_;
-  o->fast_path = tiled_.usable ? 1 : 0;
+  o->fast_path = (period_.usable && !(prefer_tiled_ && tiled_.usable)) ? 2 : (tiled_.usable ? 1 : 0);
   if (s < n_streams_) {
     o->last_sample = pos_[s].last;
     o->samp_frac_num = pos_[s].frac;
@@ -198,7 +208,10 @@ int Batch::process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_
       d_descs = dst;
     }
     hipError_t e;
-    if (mode_ == SPEEXHIP_MODE_FAST && tiled_.usable)
+    if (mode_ == SPEEXHIP_MODE_FAST && period_.usable && !(prefer_tiled_ && tiled_.usable))
+      e = launch_period(filter_, period_, d_period_rows_, channels_, descs, d_descs,
+                        packed ? &pack : nullptr, n_streams_, stream);
+    else if (mode_ == SPEEXHIP_MODE_FAST && tiled_.usable)
       e = launch_tiled(filter_, tiled_, d_phase_rows_, channels_, descs, d_descs,
                        packed ? &pack : nullptr, n_streams_, max_out, stream);
     else

@@ -55,6 +55,9 @@ class Batch {
   ExactGeometry exact_geo_;
   TiledPlan tiled_;        // fast path (kernels_tiled.hip); tiled_.usable == false -> exact
   float *d_phase_rows_ = nullptr;
+  PeriodPlan period_;      // primary fast path (kernels_period.hip)
+  float *d_period_rows_ = nullptr;
+  bool prefer_tiled_ = false;  // env SPEEXHIP_FAST_KERNEL=tiled
 
   // descriptor transport for batches larger than kMaxPackedStreams
   static const int kRing = 32;

@@ -35,6 +35,7 @@ struct TiledPlan {          // per filter, fixed at init
 };
 struct TiledLaunch {        // per call
   uint32_t periods = 0, mgroups = 0, ksplit = 1, s4_per_slice = 0, threads = 0, blocks = 0;
+  uint32_t slice_f4 = 0, slice_pad_f4 = 0;
   size_t lds_bytes = 0;
 };
 TiledPlan plan_tiled(const FilterSpec &f, uint32_t channels, size_t lds_budget);
@@ -44,5 +45,18 @@ TiledLaunch tiled_geometry(const FilterSpec &f, const TiledPlan &t, uint32_t cha
 hipError_t launch_tiled(const FilterSpec &f, const TiledPlan &t, const float *d_rows, uint32_t channels,
                         const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
                         uint32_t n_streams, uint32_t max_n_out, hipStream_t stream);
+
+// ---- primary fast kernel: period-lane mapping, taps in SGPRs (kernels_period.hip) ----------
+struct PeriodPlan {         // per filter, fixed at init
+  bool usable = false;
+  uint32_t r = 10, ct = 1, cgroups = 0, groups = 0;
+  uint32_t row_len = 0, l4 = 0, tail_frames = 0, lane_periods = 0;
+  size_t rows_floats = 0, window_bytes = 0;
+};
+PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget);
+void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<float> *rows);
+hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
+                         const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                         uint32_t n_streams, hipStream_t stream);
 
 }  // namespace speexhip

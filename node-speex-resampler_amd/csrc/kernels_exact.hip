@@ -227,17 +227,21 @@ hipError_t launch_k(const ExactParams &p, const StreamDesc *d_descs, const DescP
   DescPack empty;
   if (pack != nullptr) {
     auto kern = resample_exact<KIND, CT, STAGED, true>;
-    if (lds_bytes > 64 * 1024)
+    static bool lds_opt_in = false;  // once per kernel: allow the full 160 KiB of dynamic LDS
+    if (!lds_opt_in) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds_bytes));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      lds_opt_in = true;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, nullptr, *pack);
   } else {
     auto kern = resample_exact<KIND, CT, STAGED, false>;
-    if (lds_bytes > 64 * 1024)
+    static bool lds_opt_in = false;  // once per kernel: allow the full 160 KiB of dynamic LDS
+    if (!lds_opt_in) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds_bytes));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      lds_opt_in = true;
+    }
     memset(&empty, 0, sizeof(empty));
     hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, d_descs, empty);
   }

@@ -26,9 +26,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include "device_helpers.h"
 #include "device_types.h"
 #include "filter_design.h"
 #include "kernels.h"
@@ -36,49 +38,46 @@
 namespace speexhip {
 namespace {
 
-__device__ __forceinline__ float tiled_virtual_sample(const StreamDesc &d, uint32_t hist_frames,
-                                                      uint32_t channels, int64_t v, uint32_t c) {
-  if (v < 0) return 0.f;
-  if (v < static_cast<int64_t>(hist_frames)) return static_cast<float>(d.hist[v * channels + c]);
-  v -= hist_frames;
-  if (d.in == nullptr || v >= static_cast<int64_t>(d.in_frames)) return 0.f;
-  return static_cast<float>(d.in[v * channels + c]);
-}
-
-// round-half-up + saturate, identical in value to floor(.5 + (double)v) of arch.h:208-209:
-// v - floorf(v) is exact in fp32, so no double arithmetic is needed.
-__device__ __forceinline__ int16_t round_pcm(float v) {
-  if (v < -32767.5f) return -32768;
-  if (v > 32766.5f) return 32767;
-  const float fl = floorf(v);
-  return static_cast<int16_t>(static_cast<int>(fl) + ((v - fl) >= 0.5f ? 1 : 0));
-}
-
-__device__ void tiled_next_history(const TiledParams &p, const StreamDesc &d) {
-  const uint32_t hist_frames = p.taps - 1;
-  const uint32_t total = hist_frames * p.channels;
-  for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
-    const uint32_t h = i / p.channels, c = i - h * p.channels;
-    const int64_t v = static_cast<int64_t>(d.consumed) + h;
-    int16_t s;
-    if (v < static_cast<int64_t>(hist_frames)) {
-      s = d.hist[v * p.channels + c];
-    } else {
-      const int64_t f = v - hist_frames;
-      s = (d.in != nullptr && f < static_cast<int64_t>(d.in_frames)) ? d.in[f * p.channels + c]
-                                                                      : static_cast<int16_t>(0);
+// Copy of the n float4 of tap rows global -> LDS with UNR independent loads in flight per lane
+// (indices clamped instead of branched around, values pinned, so hipcc keeps all loads
+// outstanding).  Every `slice` float4 the destination skips `pad` float4: the tap slices of the
+// KS lanes of a quad then start on different 16-byte bank slots (conflict-free ds_read_b128).
+template <int UNR>
+__device__ __forceinline__ void stage_rows(float4 *dst, const float4 *src, uint32_t n, uint32_t slice,
+                                           uint32_t pad) {
+  for (uint32_t base = 0; base < n; base += blockDim.x * UNR) {
+    float4 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const uint32_t i = base + u * blockDim.x + threadIdx.x;
+      v[u] = src[min(i, n - 1)];
     }
-    d.hist_next[i] = s;
+#pragma unroll
+    for (int u = 0; u < UNR; u++)
+      asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const uint32_t i = base + u * blockDim.x + threadIdx.x;
+      if (i < n) dst[i + (i / slice) * pad] = v[u];
+    }
   }
 }
 
+// lane <-> lane^1 and lane <-> lane^2 exchanges inside a quad (DPP quad_perm, no LDS)
+__device__ __forceinline__ float quad_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
 template <int R, int M, int CT, bool PACKED>
-__global__ __launch_bounds__(512) void resample_tiled(TiledParams p, const StreamDesc *streams,
+__global__ __launch_bounds__(768) void resample_tiled(TiledParams p, const StreamDesc *streams,
                                                       DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
-    tiled_next_history(p, d);
+    roll_history(p.taps, p.channels, d);
     return;
   }
   if (d.n_out == 0) return;
@@ -89,25 +88,22 @@ __global__ __launch_bounds__(512) void resample_tiled(TiledParams p, const Strea
   const uint32_t m_cnt = min(p.periods, m_total - m_lo);
 
   float4 *T = reinterpret_cast<float4 *>(lds);
-  float *xs = lds + static_cast<size_t>(p.table_f4) * 4;
+  float *xs = lds + static_cast<size_t>(p.table_f4 + (p.ksplit - 1) * p.slice_pad_f4) * 4;
 
-  // ---- stage the tap rows (L2-resident after the first workgroup) --------------------------
-  {
-    const float4 *src = reinterpret_cast<const float4 *>(p.rows);
-    for (uint32_t i = threadIdx.x; i < p.table_f4; i += blockDim.x) T[i] = src[i];
-  }
   // ---- stage the input window: interleaved s16 in HBM -> float in LDS ----------------------
-  const int64_t f_lo = static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * p.num;
+  // Window origin in input-relative elements, rounded down to the input's 16-byte grid.
+  const int64_t hist_elems = static_cast<int64_t>(p.taps - 1) * p.channels;
+  const int64_t in_elems = static_cast<int64_t>(d.in_frames) * p.channels;
+  const int64_t q_lo = (static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * p.num) *
+                           p.channels - hist_elems;
+  const int64_t q_base = (q_lo >= 0 ? q_lo / 8 : -((-q_lo + 7) / 8)) * 8;
+  const uint32_t xshift = static_cast<uint32_t>(q_lo - q_base);
   const uint32_t span = (m_cnt - 1) * p.num + p.tail_frames;
-  {
-    const uint32_t C = p.channels;
-    const uint32_t hist_frames = p.taps - 1;
-    const uint32_t total = span * C;
-    for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
-      const uint32_t f = i / C, c = i - f * C;
-      xs[i] = tiled_virtual_sample(d, hist_frames, C, f_lo + f, c);
-    }
-  }
+  if (!(p.skip & 2u))
+    stage_window<4>(xs, d, q_base, (xshift + span * p.channels + 7) / 8, hist_elems, in_elems);
+  // ---- stage the tap rows (L2-resident after the first workgroups) -------------------------
+  if (!(p.skip & 1u))
+    stage_rows<8>(T, reinterpret_cast<const float4 *>(p.rows), p.table_f4, p.slice_f4, p.slice_pad_f4);
   __syncthreads();
 
   // ---- lane coordinates -------------------------------------------------------------------
@@ -127,7 +123,7 @@ __global__ __launch_bounds__(512) void resample_tiled(TiledParams p, const Strea
   for (int mi = 0; mi < M; mi++) {
     uint32_t m = mg * M + mi;
     if (m >= m_cnt) m = m_cnt - 1;  // idle periods recompute the last one, never stored
-    xoff[mi] = (m * p.num + delta_g) * p.channels + cgc * CT;
+    xoff[mi] = xshift + (m * p.num + delta_g) * p.channels + cgc * CT;
   }
 
   float acc[R][M][CT];
@@ -139,12 +135,13 @@ __global__ __launch_bounds__(512) void resample_tiled(TiledParams p, const Strea
       for (int ct = 0; ct < CT; ct++) acc[i][mi][ct] = 0.f;
 
   const uint32_t s4_begin = ks * p.s4_per_slice;
-  const uint32_t s4_end = min(s4_begin + p.s4_per_slice, p.l4);
+  const uint32_t s4_end = (p.skip & 4u) ? s4_begin : min(s4_begin + p.s4_per_slice, p.l4);
   const uint32_t C = p.channels;
-  for (uint32_t s4 = s4_begin; s4 < s4_end; s4++) {
+  const float4 *tp = T + ks * (p.slice_f4 + p.slice_pad_f4) + g;  // this lane's slice, its group
+  for (uint32_t s4 = s4_begin; s4 < s4_end; s4++, tp += R * p.groups) {
     float4 tap[R];
 #pragma unroll
-    for (int i = 0; i < R; i++) tap[i] = T[(s4 * R + i) * p.groups + g];
+    for (int i = 0; i < R; i++) tap[i] = tp[i * p.groups];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       float x[M][CT];
@@ -170,39 +167,69 @@ __global__ __launch_bounds__(512) void resample_tiled(TiledParams p, const Strea
     }
   }
 
-  // ---- wave-level reduction over the tap slices (adjacent lanes) ---------------------------
-  for (uint32_t step = 1; step < p.ksplit; step <<= 1) {
+  // ---- wave-level reduction over the tap slices (adjacent lanes, DPP butterfly) ------------
+  if (p.ksplit >= 2) {
 #pragma unroll
     for (int i = 0; i < R; i++)
 #pragma unroll
       for (int mi = 0; mi < M; mi++)
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) acc[i][mi][ct] += __shfl_xor(acc[i][mi][ct], step);
+        for (int ct = 0; ct < CT; ct++) acc[i][mi][ct] += quad_xor1(acc[i][mi][ct]);
+  }
+  if (p.ksplit >= 4) {
+#pragma unroll
+    for (int i = 0; i < R; i++)
+#pragma unroll
+      for (int mi = 0; mi < M; mi++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) acc[i][mi][ct] += quad_xor2(acc[i][mi][ct]);
   }
 
-  // ---- round, interleave, store: slice ks writes rows i == ks (mod KS) ----------------------
-  if (!lane_live) return;
+  // ---- round + interleave into an LDS image of the tile's output, then coalesced stores ----
+  // The tile's valid frames [Kb, Ke) are one contiguous run of the stream's output.  The LDS
+  // image reuses the input window; its origin is chosen so that LDS element index == global
+  // element index (mod 8), which makes every interior 16-byte chunk aligned on both sides.
+  if (p.skip & 8u) return;
+  __syncthreads();  // every lane is done reading the window
+  int16_t *ytile = reinterpret_cast<int16_t *>(xs);
+  const uint64_t K_lo = static_cast<uint64_t>(m_lo) * p.den;
+  const uint64_t Kb = max(K_lo, static_cast<uint64_t>(d.k_shift));
+  const uint64_t Ke = min(K_lo + static_cast<uint64_t>(m_cnt) * p.den, static_cast<uint64_t>(K_end));
+  int16_t *gout = d.out + (Kb - d.k_shift) * C;  // first element this tile writes
+  const uint32_t lead = static_cast<uint32_t>((reinterpret_cast<uintptr_t>(gout) >> 1) & 7u);
+  const uint32_t n_elems = static_cast<uint32_t>(Ke - Kb) * C;
+  if (lane_live) {
 #pragma unroll
-  for (int i = 0; i < R; i++) {
-    if ((static_cast<uint32_t>(i) % p.ksplit) != ks) continue;
-    const uint32_t r = g * R + i;
-    if (r >= p.den) continue;
+    for (int i = 0; i < R; i++) {
+      if ((static_cast<uint32_t>(i) & (p.ksplit - 1)) != ks) continue;  // slice ks owns rows i == ks (mod KS)
+      const uint32_t r = g * R + i;
+      if (r >= p.den) continue;
 #pragma unroll
-    for (int mi = 0; mi < M; mi++) {
-      const uint32_t m = mg * M + mi;
-      if (m >= m_cnt) continue;
-      const uint64_t K = static_cast<uint64_t>(m_lo + m) * p.den + r;
-      if (K < d.k_shift || K >= K_end) continue;
-      int16_t *o = d.out + (K - d.k_shift) * C + cg * CT;
-      if (CT == 2 && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
-        const uint32_t packed =
-            static_cast<uint16_t>(round_pcm(acc[i][mi][0])) |
-            (static_cast<uint32_t>(static_cast<uint16_t>(round_pcm(acc[i][mi][CT - 1]))) << 16);
-        *reinterpret_cast<uint32_t *>(o) = packed;
-      } else {
+      for (int mi = 0; mi < M; mi++) {
+        const uint32_t m = mg * M + mi;
+        const uint64_t K = K_lo + static_cast<uint64_t>(m) * p.den + r;
+        if (m >= m_cnt || K < Kb || K >= Ke) continue;
+        const uint32_t li = lead + static_cast<uint32_t>(K - Kb) * C + cg * CT;
+        if (CT == 2 && (li & 1u) == 0) {
+          const uint32_t packed =
+              static_cast<uint16_t>(round_pcm(acc[i][mi][0])) |
+              (static_cast<uint32_t>(static_cast<uint16_t>(round_pcm(acc[i][mi][CT - 1]))) << 16);
+          *reinterpret_cast<uint32_t *>(ytile + li) = packed;
+        } else {
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) o[ct] = round_pcm(acc[i][mi][ct]);
+          for (int ct = 0; ct < CT; ct++) ytile[li + ct] = round_pcm(acc[i][mi][ct]);
+        }
       }
+    }
+  }
+  __syncthreads();
+  const uint32_t chunks = (lead + n_elems + 7) / 8;
+  for (uint32_t j = threadIdx.x; j < chunks; j += blockDim.x) {
+    const uint32_t e0 = j * 8;  // LDS element index of this 16-byte chunk
+    if (e0 >= lead && e0 + 8 <= lead + n_elems) {
+      *reinterpret_cast<uint4 *>(gout + (e0 - lead)) = *reinterpret_cast<const uint4 *>(ytile + e0);
+    } else {
+      for (uint32_t e = max(e0, lead); e < min(e0 + 8, lead + n_elems); e++) gout[e - lead] = ytile[e];
     }
   }
 }
@@ -212,21 +239,33 @@ hipError_t launch_rmc(const TiledParams &p, const StreamDesc *d_descs, const Des
                       uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   if (pack != nullptr) {
     auto kern = resample_tiled<R, M, CT, true>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    static bool lds_opt_in = false;  // once per kernel: allow the full 160 KiB of dynamic LDS
+    if (!lds_opt_in) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      lds_opt_in = true;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, stream, p, nullptr, *pack);
   } else {
     DescPack empty;
     std::memset(&empty, 0, sizeof(empty));
     auto kern = resample_tiled<R, M, CT, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    static bool lds_opt_in = false;  // once per kernel: allow the full 160 KiB of dynamic LDS
+    if (!lds_opt_in) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      lds_opt_in = true;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, stream, p, d_descs, empty);
   }
   return hipGetLastError();
 }
 
 uint32_t round_up(uint32_t v, uint32_t q) { return (v + q - 1) / q * q; }
+
+// floats of LDS beyond span*channels: the window starts on the input's 16-byte grid (<= 7
+// elements early) and is staged in groups of 8
+const size_t kWindowSlack = 16;
 
 }  // namespace
 
@@ -262,7 +301,10 @@ TiledPlan plan_tiled(const FilterSpec &f, uint32_t channels, size_t lds_budget) 
   t.lds_budget = lds_budget;
   // a workgroup must hold the rows plus at least M periods of input
   const uint64_t min_span = static_cast<uint64_t>(t.m - 1) * f.num + t.tail_frames;
-  t.usable = t.table_bytes + min_span * channels * 4 <= lds_budget && t.groups * t.cgroups <= 512;
+  const size_t min_image = (static_cast<size_t>(t.m) * f.den * channels + 8) * 2;
+  t.usable = t.table_bytes + 3 * 15 * 16 + kWindowSlack * 4 +
+                     std::max<size_t>(min_span * channels * 4, min_image) <= lds_budget &&
+             t.groups * t.cgroups <= 768;
   return t;
 }
 
@@ -289,29 +331,38 @@ void build_phase_rows(const FilterSpec &f, const TiledPlan &t, std::vector<float
 TiledLaunch tiled_geometry(const FilterSpec &f, const TiledPlan &t, uint32_t channels,
                            uint32_t n_streams, uint32_t max_periods, uint32_t target_workgroups) {
   TiledLaunch L;
-  // periods per workgroup: enough workgroups to cover the chip, bounded by LDS and 512 lanes
-  const size_t sample_room = t.lds_budget - t.table_bytes;
-  uint64_t fit = 1;
-  if (sample_room / (channels * 4) > t.tail_frames)
-    fit = (sample_room / (channels * 4) - t.tail_frames) / f.num + 1;
+  const uint32_t kMaxLanes = 768;  // 12 waves: 3 per SIMD at <= 168 VGPRs
+  // The LDS behind the tap rows holds first the input window (float), then the tile's output
+  // image (int16): periods are bounded by both, by the lane budget and by the chip fill.
+  const size_t pad_room = 3 * 15 * 16;  // worst-case slice padding
+  const size_t room = t.lds_budget - t.table_bytes - pad_room - kWindowSlack * 4;
+  auto window_bytes = [&](uint64_t periods) {
+    return ((periods - 1) * f.num + t.tail_frames) * channels * size_t(4);
+  };
+  auto image_bytes = [&](uint64_t periods) { return (periods * f.den * channels + 8) * size_t(2); };
   uint32_t want = (max_periods * n_streams + target_workgroups - 1) / std::max(1u, target_workgroups);
   want = round_up(std::max(want, 1u), t.m);
-  uint32_t periods = static_cast<uint32_t>(std::min<uint64_t>(want, fit));
-  periods = std::max<uint32_t>(periods / t.m * t.m, t.m);
-  // lanes = ksplit * groups * mgroups * cgroups <= 512
   const uint32_t base_lanes = t.groups * t.cgroups;
-  uint32_t mgroups = periods / t.m;
-  while (mgroups > 1 && base_lanes * mgroups > 512) mgroups--;
-  periods = mgroups * t.m;
+  uint32_t periods = want;
+  while (periods > static_cast<uint32_t>(t.m) &&
+         (window_bytes(periods) > room || image_bytes(periods) > room ||
+          base_lanes * (periods / t.m) > kMaxLanes))
+    periods -= t.m;
+  const uint32_t mgroups = periods / t.m;
   uint32_t ksplit = 1;
-  while (ksplit < 4 && base_lanes * mgroups * ksplit * 2 <= 512 && t.l4 / (ksplit * 2) >= 4) ksplit *= 2;
+  while (ksplit < 4 && base_lanes * mgroups * ksplit * 2 <= kMaxLanes && t.l4 / (ksplit * 2) >= 4)
+    ksplit *= 2;
   L.periods = periods;
   L.mgroups = mgroups;
   L.ksplit = ksplit;
   L.s4_per_slice = (t.l4 + ksplit - 1) / ksplit;
+  L.slice_f4 = L.s4_per_slice * t.r * t.groups;
+  // slice starts 16/KS bank slots apart (mod 16): the KS lanes of a quad never share a slot
+  const uint32_t target = ksplit > 1 ? 16 / ksplit : 0;
+  L.slice_pad_f4 = ksplit > 1 ? (target + 16 - L.slice_f4 % 16) % 16 : 0;
   L.threads = round_up(base_lanes * mgroups * ksplit, 64);
-  const uint64_t span = static_cast<uint64_t>(periods - 1) * f.num + t.tail_frames;
-  L.lds_bytes = t.table_bytes + span * channels * 4;
+  L.lds_bytes = t.table_bytes + size_t(ksplit - 1) * L.slice_pad_f4 * 16 + kWindowSlack * 4 +
+                std::max(window_bytes(periods), image_bytes(periods));
   L.blocks = (max_periods + periods - 1) / periods;
   return L;
 }
@@ -342,7 +393,11 @@ hipError_t launch_tiled(const FilterSpec &f, const TiledPlan &t, const float *d_
   p.mgroups = L.mgroups;
   p.ksplit = L.ksplit;
   p.s4_per_slice = L.s4_per_slice;
+  p.slice_f4 = L.slice_f4;
+  p.slice_pad_f4 = L.slice_pad_f4;
   p.tail_frames = t.tail_frames;
+  static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
+  p.skip = skip_mask;
   dim3 grid((max_periods == 0 ? 0 : L.blocks) + 1, n_streams, 1);
 #define SPEEXHIP_TILED_CASE(RR, MM)                                                             \
   if (t.r == RR && t.m == MM)                                                                   \

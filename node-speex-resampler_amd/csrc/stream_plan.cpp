@@ -25,6 +25,33 @@ CallPlan plan_call(uint32_t num, uint32_t den, uint32_t in_frames, uint32_t out_
   int64_t last = pos.last;
   uint64_t frac = pos.frac;
   uint64_t in_left = in_frames, out_left = out_capacity;
+
+  // Fast-forward over whole 160-frame blocks in closed form.  While a block can never emit
+  // more than kBlockOut outputs and the call's capacity is not yet in reach, every block
+  // consumes exactly kBlockIn frames and ends with its position past the block, so the state
+  // after b blocks is the state after P(b) = #outputs starting before frame 160*b.
+  const uint64_t per_block_max = ceil_div(static_cast<uint64_t>(kBlockIn) * den, num) + 1;
+  if (per_block_max <= kBlockOut && in_left > 2 * kBlockIn && out_left > 2 * per_block_max) {
+    uint64_t lo = 0, hi = in_left / kBlockIn - 1;  // keep at least one block for the loop below
+    const uint64_t room = out_left - 2 * per_block_max;
+    while (lo < hi) {  // largest b with P(b) <= room
+      const uint64_t mid = (lo + hi + 1) / 2;
+      if (outputs_before(num, den, last, static_cast<uint32_t>(frac),
+                         static_cast<int64_t>(mid * kBlockIn)) <= room)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    if (lo > 0) {
+      const uint64_t made = outputs_before(num, den, last, static_cast<uint32_t>(frac),
+                                           static_cast<int64_t>(lo * kBlockIn));
+      const uint64_t t = frac + made * num;
+      last = last + static_cast<int64_t>(t / den) - static_cast<int64_t>(lo * kBlockIn);
+      frac = t % den;
+      in_left -= lo * kBlockIn;
+      out_left -= made;
+    }
+  }
   while (in_left && out_left) {
     const uint64_t blk_in = in_left < kBlockIn ? in_left : kBlockIn;
     const uint64_t blk_out = out_left < kBlockOut ? out_left : kBlockOut;

@@ -50,6 +50,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libspeexhip.so not built: run `python __graft_entry__.py` or "
                                "`make -C node-speex-resampler_amd` (no CPU fallback exists)")
+        # One HIP runtime per process: PyTorch-ROCm preloads its bundled libamdhip64.so.7 by path;
+        # if ours pulled in /opt/rocm's copy first there would be two runtimes and the second
+        # to initialise sees no device.  Loading torch first makes both share one copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         u32, i32, p = C.c_uint32, C.c_int, C.c_void_p
         pu32, pi16 = C.POINTER(C.c_uint32), C.POINTER(C.c_int16)
