@@ -56,7 +56,8 @@ struct TiledParams {
 };
 
 struct PeriodParams {
-  const float *rows;      // effective taps, layout [group][s/4][s%4][i] (device, read by scalar loads)
+  const float *rows;      // effective taps, layout [group][s][i] (device, read by scalar loads)
+  const uint32_t *delta;  // per group: (g*R*num) div den, first-input offset of the group
   uint32_t l4;            // row length / 4
   uint32_t groups;        // phase groups (R phases each)
   uint32_t num, den, taps, channels;

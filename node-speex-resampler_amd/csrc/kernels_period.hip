@@ -34,11 +34,158 @@
 namespace speexhip {
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// dword-aligned wide global stores (global memory needs only dword alignment for x2/x4)
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef __attribute__((address_space(1))) u32x4_a4 g_u32x4_a4;
+typedef __attribute__((address_space(1))) u32x2_a4 g_u32x2_a4;
+
+// acc += tap * x on both halves, the tap being element HI of a wave-uniform pair held in SGPRs.
+// Written as one instruction so that the odd element is selected in place with op_sel: left to
+// itself hipcc copies odd taps into even SGPRs first (one s_mov each), and the scalar ALU --
+// ONE per CU, shared by all 32 resident waves -- becomes the bottleneck of the loop.
+__device__ __forceinline__ void fma_tap(f32x2 &acc, const f32x2 &tap_pair, const f32x2 &x, bool hi) {
+  if (hi)  // constant after unrolling: the branch folds away
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+}
+
+// FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
+// followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
+template <int R, int CT, bool ONE_GROUP>
+__device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__restrict__ rows,
+                                         const StreamDesc &d, const float *xs, uint32_t xshift,
+                                         uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
+                                         uint32_t zsplit, uint32_t nsplit) {
+  // ONE_GROUP: the frame is exactly one channel group (mono, stereo): the sample stride is a
+  // compile-time constant and the LDS reads of an iteration share one address register.
+  const uint32_t C = ONE_GROUP ? static_cast<uint32_t>(CT) : p.channels;
+  const uint32_t cg = ONE_GROUP ? 0 : lane % p.cgroups;
+  const uint32_t pl = ONE_GROUP ? lane : lane / p.cgroups;  // period of this lane inside the tile
+  const bool lane_live = pl < m_cnt;
+  // float index of this lane's first sample of a group with delta_g = 0
+  const uint32_t xlane = xshift + min(pl, p.lane_periods - 1) * p.num * C + cg * CT;
+  const uint64_t K_lane = static_cast<uint64_t>(m_lo + pl) * p.den;
+
+  const uint32_t g_step = p.wave_groups * nsplit;
+  for (uint32_t g = zsplit * p.wave_groups + wave; g < p.groups; g += g_step) {
+    f32x2 acc[R];  // .x = first channel of the pair, .y = second (unused when CT == 1)
+#pragma unroll
+    for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
+    const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
+    const float *xp = xs + xlane + delta_g * C;
+    const uint32_t n_it = (p.skip & 4u) ? 0 : p.l4;
+    // Taps are wave-uniform: they travel HBM/L2 -> scalar cache -> SGPRs (s_load: the row pointer
+    // is a __restrict__ kernel argument, so the loads are provably invariant) and feed
+    // v_pk_fma_f32 directly.  The 4R taps of an iteration live in two banks (steps 0-1, steps
+    // 2-3) written in software-pipelined order: each bank is re-loaded while the other bank's
+    // 2R FMAs issue, so a scalar-load round trip overlaps FMAs of the same wave.
+    const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (4 * R);
+    // Bank A = steps 0-1 of an iteration, bank B = steps 2-3: each bank is its 2R taps (R SGPR
+    // pairs) plus its two sample reads.  Order per iteration, pinned with sched_barrier:
+    //   wait A | issue loads B | 2R FMAs A | wait B | issue loads A(next) | 2R FMAs B
+    // A wait is lgkmcnt(0) (scalar loads return out of order and share the counter with LDS),
+    // so a bank's loads must be issued right AFTER the other bank's wait; `touch_bank` is an
+    // empty asm that reads the bank and thereby makes hipcc put the wait exactly there.
+    f32x2 ta[R], tb[R], xa[2], xb[2];
+    auto load_bank = [&](f32x2 (&t)[R], f32x2 (&x)[2], const float *tp, const float *sp) {
+#pragma unroll
+      for (int j = 0; j < R; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (CT == 2) {
+          x[u] = *reinterpret_cast<const f32x2 *>(sp + u * C);
+        } else {
+          x[u].x = sp[u * C];
+          x[u].y = 0.f;
+        }
+      }
+    };
+    auto touch_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
+      asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
+                   "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]));
+    };
+    auto fma_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int i = 0; i < R; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
+    };
+    static_assert(R == 10, "touch_bank lists R = 10 tap pairs");
+    load_bank(ta, xa, trow, xp);
+    for (uint32_t it = 0; it < n_it; it++) {
+      touch_bank(ta, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      load_bank(tb, xb, trow + 2 * R, xp + 2 * C);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_bank(ta, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      touch_bank(tb, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      trow += 4 * R;
+      xp += 4 * C;
+      // next iteration's bank A: the rows carry one iteration of zero padding past the last
+      // group and the window one step group of slack, so the final prefetch stays in bounds
+      load_bank(ta, xa, trow, xp);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_bank(tb, xb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    touch_bank(ta, xa);  // retire the last prefetch
+    if ((p.skip & 8u) || !lane_live) continue;
+
+    // ---- direct stores: R consecutive frames per lane, 4 bytes each per channel pair.  With
+    //      two workgroups per CU they overlap the other workgroup's FMAs (an LDS transpose
+    //      for fully coalesced stores measured slower).
+    // rows i in [i_lo, i_hi) of this group are real phases that fall inside this call
+    const int64_t k0 = static_cast<int64_t>(K_lane) + static_cast<int64_t>(g) * R - d.k_shift;
+    const int64_t lo64 = k0 < 0 ? -k0 : 0;
+    const int64_t hi64 = min(static_cast<int64_t>(R), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * R,
+                                                         static_cast<int64_t>(d.n_out) - k0));
+    const int i_lo = static_cast<int>(min(lo64, static_cast<int64_t>(R)));
+    const int i_hi = static_cast<int>(max(hi64, static_cast<int64_t>(0)));
+    g_i16 *o = as_global(d.out) + k0 * static_cast<int64_t>(C) + cg * CT;
+    const bool aligned = CT == 2 && ((reinterpret_cast<uintptr_t>(d.out) | (C * 2u)) & 3u) == 0;
+    if (ONE_GROUP && CT == 2 && aligned && i_lo == 0 && i_hi == R) {
+      // the lane's R frames are R consecutive dwords: 16 + 16 + 8 bytes instead of R narrow
+      // stores (each store instruction costs one line request per lane whatever its width)
+      uint32_t v[R];
+#pragma unroll
+      for (int i = 0; i < R; i++) v[i] = round_pack_pcm(acc[i].x, acc[i].y);
+      g_u32x4_a4 *o4 = (g_u32x4_a4 *)o;
+      o4[0] = u32x4_a4{v[0], v[1], v[2], v[3]};
+      o4[1] = u32x4_a4{v[4], v[5], v[6], v[7]};
+      *(g_u32x2_a4 *)(o + 16) = u32x2_a4{v[8], v[9]};
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++, o += C) {
+      if (i < i_lo || i >= i_hi) continue;
+      if (CT == 2) {
+        const uint32_t v = round_pack_pcm(acc[i].x, acc[i].y);
+        if (aligned) {
+          *(g_u32 *)o = v;
+        } else {
+          o[0] = static_cast<int16_t>(v & 0xffffu);
+          o[1] = static_cast<int16_t>(v >> 16);
+        }
+      } else {
+        o[0] = static_cast<int16_t>(round_pack_pcm(acc[i].x, 0.f) & 0xffffu);
+      }
+    }
+  }
+}
+
 // <= 80 SGPRs: the hardware admits 8 waves per SIMD (two 16-wave workgroups per CU) only then
 // (MI355X_MICROARCH.md, residency); the compiler alone settles at ~106.
-template <int R, int CT, int STEPS, bool PACKED>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period(PeriodParams p, const float *__restrict__ rows,
-                                                        const StreamDesc *streams, DescPack pack) {
+//
+// One-shot form: workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one
+// of gridDim.z shares of its phase groups.  Used when a launch has too few tiles to loop over.
+template <int R, int CT, bool ONE_GROUP, bool PACKED>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
+    PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
@@ -51,163 +198,128 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   const uint32_t m_lo = blockIdx.x * p.lane_periods;
   if (m_lo >= m_total) return;
   const uint32_t m_cnt = min(p.lane_periods, m_total - m_lo);
-  const uint32_t C = p.channels;
 
-  // ---- stage the input window: interleaved s16 in HBM -> float in LDS ----------------------
-  const int64_t hist_elems = static_cast<int64_t>(p.taps - 1) * C;
-  const int64_t in_elems = static_cast<int64_t>(d.in_frames) * C;
-  const int64_t q_lo =
-      (static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * p.num) * C - hist_elems;
-  const int64_t q_base = (q_lo >= 0 ? q_lo / 8 : -((-q_lo + 7) / 8)) * 8;
-  const uint32_t xshift = static_cast<uint32_t>(q_lo - q_base);
-  const uint32_t span = (m_cnt - 1) * p.num + p.tail_frames;
-  if (!(p.skip & 2u)) stage_window<4>(xs, d, q_base, (xshift + span * C + 7) / 8, hist_elems, in_elems);
+  const WindowGeom wg = window_geom(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt);
+  if (!(p.skip & 2u)) {
+    u32x4 w[3];
+    window_fetch<3>(wg, w);
+    window_commit<3>(xs, d, wg, w);
+  }
   __syncthreads();
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  fir_tile<R, CT, ONE_GROUP>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z,
+                             gridDim.z);
+}
 
-  // ---- wave / lane coordinates ---------------------------------------------------------------
+// Persistent form: gridDim.x workgroups (two per CU) walk the launch's flat tile list
+// T = stream * tiles_per_stream + tile.  While the FIR of tile T runs, the 16-byte loads of the
+// next tile's input window are already in flight (registers), so HBM latency, the int16->float
+// conversion and the stores of one workgroup hide behind the other's FMAs and the workgroups
+// never fall into lock-step the way back-to-back launches of the one-shot form do.
+template <int R, int CT, bool ONE_GROUP, bool PACKED>
+__device__ __forceinline__ void persistent_body(const PeriodParams &p, const float *__restrict__ rows,
+                                                const StreamDesc *streams, const DescPack &pack,
+                                                uint32_t n_streams, uint32_t tiles_per_stream, float *xs) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t cg = lane % p.cgroups;
-  const uint32_t pl = lane / p.cgroups;  // period of this lane inside the tile
-  const bool lane_live = pl < m_cnt;
-  // float index of this lane's first sample of a group with delta_g = 0
-  const uint32_t xlane = xshift + min(pl, p.lane_periods - 1) * p.num * C + cg * CT;
-  const uint64_t K_lane = static_cast<uint64_t>(m_lo + pl) * p.den;
+  for (uint32_t s = blockIdx.x; s < n_streams; s += gridDim.x)  // history rolls ride along
+    roll_history(p.taps, p.channels, PACKED ? pack.d[s] : streams[s]);
 
-  const uint32_t g_first = blockIdx.z * p.wave_groups + wave;
-  const uint32_t g_step = p.wave_groups * gridDim.z;
-  // One round (every wave owns at most one group): outputs are transposed through LDS, which
-  // may then reuse the window.  Several rounds (more groups than waves): direct stores.
-  const bool via_lds = CT == 2 && p.groups <= g_step && !(p.skip & 16u);
-  const uint32_t r_lo = blockIdx.z * p.wave_groups * R;                    // first phase of this workgroup
-  const uint32_t r_hi = min(p.den, (blockIdx.z + 1) * p.wave_groups * R);  // one past its last
-  const uint32_t run = r_hi > r_lo ? r_hi - r_lo : 0;                      // phases per period here
-  for (uint32_t g = g_first; g < p.groups || via_lds; g += g_step) {
-    const bool has_group = g < p.groups;
-    float acc[R][CT];
-#pragma unroll
-    for (int i = 0; i < R; i++)
-#pragma unroll
-      for (int ct = 0; ct < CT; ct++) acc[i][ct] = 0.f;
-    if (has_group) {
-      const uint32_t delta_g = static_cast<uint32_t>((static_cast<uint64_t>(g) * R * p.num) / p.den);
-      // `rows` is a __restrict__ kernel argument: provably invariant, so these wave-uniform
-      // loads become s_load_dwordx16 and the taps stay in SGPRs (2 steps = 2R taps at a time
-      // keeps the kernel under 96 SGPRs: 8 waves per SIMD, two workgroups per CU)
-      const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (4 * R);
-      const float *xp = xs + xlane + delta_g * C;
-      const uint32_t n_it = (p.skip & 4u) ? 0 : p.l4 * (4 / STEPS);
-      const uint32_t tap_mask = (p.skip & 32u) ? 0u : ~0u;  // diagnostics: 32 = re-read tap block 0
-      for (uint32_t it = 0; it < n_it; it++) {
-        float tap[STEPS * R];
-#pragma unroll
-        for (int k = 0; k < STEPS * R; k++) tap[k] = trow[(it & tap_mask) * (STEPS * R) + k];
-#pragma unroll
-        for (int u = 0; u < STEPS; u++) {
-          float x[CT];
-          const float *px = xp + (it * STEPS + u) * C;
-          if (CT == 2) {
-            const float2 v = *reinterpret_cast<const float2 *>(px);
-            x[0] = v.x;
-            x[CT - 1] = v.y;
-          } else {
-            x[0] = *px;
-          }
-#pragma unroll
-          for (int i = 0; i < R; i++)
-#pragma unroll
-            for (int ct = 0; ct < CT; ct++) acc[i][ct] = fmaf(tap[u * R + i], x[ct], acc[i][ct]);
-        }
-      }
+  const uint32_t total = n_streams * tiles_per_stream;
+  uint32_t T = blockIdx.x;
+  u32x4 w[3];
+  WindowGeom wg;
+  StreamDesc d;
+  uint32_t m_lo = 0, m_cnt = 0;
+  auto open_tile = [&](uint32_t t) {  // descriptor + geometry + loads in flight for tile t
+    const uint32_t s = t / tiles_per_stream;
+    d = PACKED ? pack.d[s] : streams[s];
+    const uint32_t m_total = d.n_out ? (d.k_shift + d.n_out + p.den - 1) / p.den : 0;
+    m_lo = (t - s * tiles_per_stream) * p.lane_periods;
+    m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 0;
+    if (m_cnt) {
+      wg = window_geom(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt);
+      window_fetch<3>(wg, w);
     }
-    if (p.skip & 8u) {
-      if (via_lds) break;
-      continue;
-    }
-
-    if (via_lds) {
-      // ---- transpose through LDS: image[period][phase - r_lo][channel pair] of packed s16x2,
-      //      then each period's run goes out as consecutive dwords (full lines per wave).
-      __syncthreads();  // every wave is done reading the window
-      uint32_t *img = reinterpret_cast<uint32_t *>(xs);
-      if (has_group && pl < p.lane_periods) {
-#pragma unroll
-        for (int i = 0; i < R; i++) {
-          const uint32_t r = g * R + i;
-          if (r < r_hi) img[(pl * run + (r - r_lo)) * p.cgroups + cg] = round_pack_pcm(acc[i][0], acc[i][CT - 1]);
-        }
-      }
-      __syncthreads();
-      // wave w copies periods w, w+W, ...; lanes sweep a period's run 64 dwords at a time
-      const uint32_t row_dw = run * p.cgroups;  // dwords per period in the image
-      const uint32_t n_waves = blockDim.x >> 6;
-      for (uint32_t pp = wave; pp < m_cnt; pp += n_waves) {
-        const uint64_t K_row = static_cast<uint64_t>(m_lo + pp) * p.den + r_lo;
-        for (uint32_t w = lane; w < row_dw; w += 64) {
-          const uint32_t fr = p.cgroups == 1 ? w : w / p.cgroups;
-          const uint32_t cgi = p.cgroups == 1 ? 0 : w - fr * p.cgroups;
-          const uint64_t K = K_row + fr;
-          if (K < d.k_shift || K >= K_end) continue;
-          int16_t *o = d.out + (K - d.k_shift) * C + cgi * 2;
-          const uint32_t v = img[pp * row_dw + w];
-          if ((reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
-            *reinterpret_cast<uint32_t *>(o) = v;
-          } else {
-            o[0] = static_cast<int16_t>(v & 0xffffu);
-            o[1] = static_cast<int16_t>(v >> 16);
-          }
-        }
-      }
-      break;
-    }
-
-    // ---- direct stores (several rounds, or an odd channel count) -----------------------------
-    if (lane_live) {
-#pragma unroll
-      for (int i = 0; i < R; i++) {
-        const uint32_t r = g * R + i;
-        const uint64_t K = K_lane + r;
-        if (r >= p.den || K < d.k_shift || K >= K_end) continue;
-        int16_t *o = d.out + (K - d.k_shift) * C + cg * CT;
-        if (CT == 2) {
-          const uint32_t v = round_pack_pcm(acc[i][0], acc[i][CT - 1]);
-          if ((reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
-            *reinterpret_cast<uint32_t *>(o) = v;
-          } else {
-            o[0] = static_cast<int16_t>(v & 0xffffu);
-            o[1] = static_cast<int16_t>(v >> 16);
-          }
-        } else {
-          o[0] = static_cast<int16_t>(round_pack_pcm(acc[i][0], 0.f) & 0xffffu);
-        }
-      }
-    }
+  };
+  if (T < total) open_tile(T);
+  while (T < total) {
+    const StreamDesc d_cur = d;
+    const uint32_t m_lo_cur = m_lo, m_cnt_cur = m_cnt, xshift_cur = wg.xshift;
+    if (m_cnt_cur && !(p.skip & 2u)) window_commit<3>(xs, d_cur, wg, w);
+    __syncthreads();
+    const uint32_t Tn = T + gridDim.x;
+    if (Tn < total) open_tile(Tn);  // next window's loads fly during this tile's FIR
+    if (m_cnt_cur)
+      fir_tile<R, CT, ONE_GROUP>(p, rows, d_cur, xs, xshift_cur, m_lo_cur, m_cnt_cur, wave, lane, 0, 1);
+    __syncthreads();  // every wave is done with this window before it is overwritten
+    T = Tn;
   }
 }
 
-template <int R, int CT, int STEPS>
+template <int R, int CT, bool ONE_GROUP, bool PACKED>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period_persistent(
+    PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack,
+    uint32_t n_streams, uint32_t tiles_per_stream) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  persistent_body<R, CT, ONE_GROUP, PACKED>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
+}
+
+// Same walk without the SGPR cap: all 4R taps of an iteration arrive with ONE scalar-load wait
+// (~106 SGPRs -> 7 waves per SIMD -> one 16-wave workgroup per CU; the software pipeline, not
+// a second workgroup, hides the staging).
+template <int R, int CT, bool ONE_GROUP, bool PACKED>
+__global__ __launch_bounds__(1024) void resample_period_persistent_wide(
+    PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack,
+    uint32_t n_streams, uint32_t tiles_per_stream) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  persistent_body<R, CT, ONE_GROUP, PACKED>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
+}
+
+template <typename K>
+void opt_in_lds(K kern) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+}
+
+template <int R, int CT, bool ONE_GROUP>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
-                     uint32_t threads, size_t lds_bytes, hipStream_t stream) {
-  if (pack != nullptr) {
-    auto kern = resample_period<R, CT, STEPS, true>;
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      lds_opt_in = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, stream, p, p.rows, nullptr, *pack);
+                     uint32_t threads, size_t lds_bytes, uint32_t n_streams, uint32_t tiles_per_stream,
+                     bool persistent, hipStream_t stream) {
+  DescPack empty;
+  if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
+  static bool once = false;
+  if (!once) {
+    opt_in_lds(resample_period<R, CT, ONE_GROUP, true>);
+    opt_in_lds(resample_period<R, CT, ONE_GROUP, false>);
+    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, true>);
+    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, false>);
+    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, true>);
+    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, false>);
+    once = true;
+  }
+  static const bool wide = std::getenv("SPEEXHIP_WIDE") && std::atoi(std::getenv("SPEEXHIP_WIDE")) != 0;
+  if (persistent && wide) {
+    if (pack != nullptr)
+      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, true>), grid, dim3(threads), lds_bytes,
+                         stream, p, p.rows, nullptr, *pack, n_streams, tiles_per_stream);
+    else
+      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, false>), grid, dim3(threads), lds_bytes,
+                         stream, p, p.rows, d_descs, empty, n_streams, tiles_per_stream);
+  } else if (persistent) {
+    if (pack != nullptr)
+      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, true>), grid, dim3(threads), lds_bytes,
+                         stream, p, p.rows, nullptr, *pack, n_streams, tiles_per_stream);
+    else
+      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, false>), grid, dim3(threads), lds_bytes,
+                         stream, p, p.rows, d_descs, empty, n_streams, tiles_per_stream);
   } else {
-    DescPack empty;
-    std::memset(&empty, 0, sizeof(empty));
-    auto kern = resample_period<R, CT, STEPS, false>;
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      lds_opt_in = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(threads), lds_bytes, stream, p, p.rows, d_descs, empty);
+    if (pack != nullptr)
+      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, true>), grid, dim3(threads), lds_bytes, stream, p,
+                         p.rows, nullptr, *pack);
+    else
+      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, false>), grid, dim3(threads), lds_bytes, stream, p,
+                         p.rows, d_descs, empty);
   }
   return hipGetLastError();
 }
@@ -233,8 +345,10 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
   t.l4 = t.row_len / 4;
   t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * t.r * f.num) / f.den) + t.row_len;
   t.lane_periods = 64 / t.cgroups;
-  t.rows_floats = static_cast<size_t>(t.groups) * t.l4 * 4 * t.r;
-  t.window_bytes = ((static_cast<size_t>(t.lane_periods) - 1) * f.num + t.tail_frames) * channels * 4 + kSlack * 4;
+  // + one iteration (4R floats) of zero padding: the tap pipeline prefetches one past the end
+  t.rows_floats = static_cast<size_t>(t.groups) * t.l4 * 4 * t.r + 4 * t.r;
+  // (+ 4 frames: the tap/sample pipeline prefetches one bank past the last step)
+  t.window_bytes = ((static_cast<size_t>(t.lane_periods) - 1) * f.num + t.tail_frames + 4) * channels * 4 + kSlack * 4;
   // the same LDS later holds the tile's output image (one packed s16 pair per dword)
   t.window_bytes = std::max(t.window_bytes, static_cast<size_t>(t.lane_periods) * f.den * t.cgroups * 4);
   // needs enough phases to fill the R-wide register tile and a window that fits one CU's LDS
@@ -243,7 +357,12 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
 }
 
 void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<float> *rows) {
-  rows->assign(t.rows_floats, 0.f);
+  // taps, then one uint32 per group: delta_g = (g*R*num) div den (bit-copied into the float array)
+  rows->assign(t.rows_floats + t.groups, 0.f);
+  for (uint32_t g = 0; g < t.groups; g++) {
+    const uint32_t delta = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
+    std::memcpy(&(*rows)[t.rows_floats + g], &delta, sizeof(delta));
+  }
   std::vector<double> h(f.taps);
   for (uint32_t g = 0; g < t.groups; g++) {
     const uint64_t d0 = (static_cast<uint64_t>(g) * t.r * f.num) / f.den;
@@ -271,16 +390,28 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
     max_periods = std::max<uint32_t>(max_periods, static_cast<uint32_t>((k_end + f.den - 1) / f.den));
   }
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
-  // Few tiles (one short stream): split each tile's phase groups over several workgroups so
-  // the launch still covers the chip; many tiles: one workgroup of up to 16 waves per tile.
+  static const int device_cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  static const uint32_t per_cu = std::getenv("SPEEXHIP_WG_PER_CU") ? std::atoi(std::getenv("SPEEXHIP_WG_PER_CU")) : 2;
+  const uint32_t resident = per_cu * static_cast<uint32_t>(device_cus);  // two workgroups fit per CU
+  static const bool allow_persistent = !(std::getenv("SPEEXHIP_PERSISTENT") && std::atoi(std::getenv("SPEEXHIP_PERSISTENT")) == 0);
+  // More tiles than resident workgroups: persistent walk of the tile list.  Fewer: one workgroup
+  // per tile, and when even that leaves CUs idle (one short stream) the phase groups of a tile
+  // are split over several workgroups.
+  const bool persistent = allow_persistent && static_cast<uint64_t>(tiles) * n_streams > resident;
   uint32_t splits = 1;
-  while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= 512 &&
-         (t.groups + splits * 2 - 1) / (splits * 2) >= 2)
-    splits *= 2;
+  if (!persistent)
+    while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident &&
+           (t.groups + splits * 2 - 1) / (splits * 2) >= 2)
+      splits *= 2;
   static const uint32_t max_waves = std::getenv("SPEEXHIP_WAVES") ? std::atoi(std::getenv("SPEEXHIP_WAVES")) : 16;
   const uint32_t wave_groups = std::min<uint32_t>((t.groups + splits - 1) / splits, max_waves);
   PeriodParams p;
   p.rows = d_rows;
+  p.delta = reinterpret_cast<const uint32_t *>(d_rows + t.rows_floats);
   p.l4 = t.l4;
   p.groups = t.groups;
   p.num = f.num;
@@ -293,13 +424,18 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   p.tail_frames = t.tail_frames;
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
-  dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, splits);
   const uint32_t threads = wave_groups * 64;
-  static const int steps = std::getenv("SPEEXHIP_TAPSTEPS") ? std::atoi(std::getenv("SPEEXHIP_TAPSTEPS")) : 4;
-  if (t.ct == 2)
-    return steps == 2 ? launch_rc<kR, 2, 2>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
-                      : launch_rc<kR, 2, 4>(p, d_descs, pack, grid, threads, t.window_bytes, stream);
-  return launch_rc<kR, 1, 4>(p, d_descs, pack, grid, threads, t.window_bytes, stream);
+  dim3 grid = persistent ? dim3(resident, 1, 1) : dim3((max_periods == 0 ? 0 : tiles) + 1, n_streams, splits);
+#define SPEEXHIP_PERIOD_CASE(CTV, ONE)                                                                  \
+  return launch_rc<kR, CTV, ONE>(p, d_descs, pack, grid, threads, t.window_bytes, n_streams, tiles,   \
+                                 persistent, stream)
+  if (t.ct == 2) {
+    if (t.cgroups == 1) SPEEXHIP_PERIOD_CASE(2, true);
+    SPEEXHIP_PERIOD_CASE(2, false);
+  }
+  if (t.cgroups == 1) SPEEXHIP_PERIOD_CASE(1, true);
+  SPEEXHIP_PERIOD_CASE(1, false);
+#undef SPEEXHIP_PERIOD_CASE
 }
 
 }  // namespace speexhip
