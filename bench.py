@@ -24,12 +24,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "node-speex-resampler_amd", "python"))
 
 CONFIGS = {
-    # name: (channels, in_rate, out_rate, quality) -- BASELINE.json configs[1..3]
+    # name: (channels, in_rate, out_rate, quality) -- BASELINE.json configs[1..3] (+ SURVEY F3)
     "cfg2": (2, 44100, 48000, 7),
     "cfg3": (1, 24000, 48000, 10),
     "cfg4": (8, 48000, 44100, 5),
     "f3": (1, 24000, 48000, 5),
 }
+CONFIG_LABEL = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg4": "BASELINE configs[3]",
+                "f3": "SURVEY F3 (direct_single)"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
 
@@ -183,8 +185,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] per GPU x %d stream(s): %d->%d Hz, %dch int16, "
-                                   "q=%d, %d-frame chunk per stream per step" % (S, fi, fo, ch, q, F),
+            "config": {"workload": "%s per GPU x %d stream(s): %d->%d Hz, %dch int16, "
+                                   "q=%d, %d-frame chunk per stream per step" % (CONFIG_LABEL[args.config], S, fi,
+                                                                                 fo, ch, q, F),
                        "streams_per_gpu": S, "frames_per_chunk": F, "mode": args.mode,
                        "kernel": speexhip.KERNEL_NAMES[info["kernel"]], "fast_path": info["fast_path"],
                        "filt_len": info["filt_len"], "parallelism": "streams sharded, %d rank(s)" % world},

@@ -65,6 +65,7 @@ struct PeriodParams {
   uint32_t lane_periods;  // output periods per workgroup tile (= lanes / cgroups)
   uint32_t wave_groups;   // waves per workgroup; wave w of split z takes groups z*wave_groups+w, ...
   uint32_t tail_frames;   // input frames a period needs beyond its start
+  uint32_t history_block; // one-shot form: blockIdx.x of the workgroup that rolls the history
   uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP), 0 in normal operation
 };
 

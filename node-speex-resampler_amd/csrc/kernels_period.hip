@@ -188,11 +188,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
-  if (blockIdx.x == gridDim.x - 1) {
+  if (blockIdx.x == p.history_block) {
     if (blockIdx.z == 0) roll_history(p.taps, p.channels, d);
     return;
   }
-  if (d.n_out == 0) return;
+  if (d.n_out == 0 || blockIdx.x > p.history_block) return;
   const uint32_t K_end = d.k_shift + d.n_out;            // exclusive canonical output index
   const uint32_t m_total = (K_end + p.den - 1) / p.den;  // periods touched by this call
   const uint32_t m_lo = blockIdx.x * p.lane_periods;
@@ -422,10 +422,17 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   p.lane_periods = t.lane_periods;
   p.wave_groups = wave_groups;
   p.tail_frames = t.tail_frames;
+  p.history_block = max_periods == 0 ? 0 : tiles;
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
   const uint32_t threads = wave_groups * 64;
-  dim3 grid = persistent ? dim3(resident, 1, 1) : dim3((max_periods == 0 ? 0 : tiles) + 1, n_streams, splits);
+  // One-shot grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8
+  // when a tile is split: workgroups whose linear ids differ by a multiple of 8 share an XCD, so
+  // the `splits` workgroups that stage the same input window hit in that XCD's L2 instead of
+  // each fetching it from HBM (measured 2.7x read amplification without this).
+  uint32_t grid_x = (max_periods == 0 ? 0 : tiles) + 1;
+  if (splits > 1 && n_streams == 1) grid_x = (grid_x + 7) / 8 * 8;
+  dim3 grid = persistent ? dim3(resident, 1, 1) : dim3(grid_x, n_streams, splits);
 #define SPEEXHIP_PERIOD_CASE(CTV, ONE)                                                                  \
   return launch_rc<kR, CTV, ONE>(p, d_descs, pack, grid, threads, t.window_bytes, n_streams, tiles,   \
                                  persistent, stream)
