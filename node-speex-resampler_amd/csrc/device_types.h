@@ -55,6 +55,16 @@ struct TiledParams {
                           // bit3 stores -- phases to leave out when timing; 0 in normal operation
 };
 
+struct UpsampleParams {
+  const float *rows;        // taps [step][phase] (device, read by scalar loads)
+  uint32_t den, taps, channels;
+  uint32_t cgroups;         // lanes per lane block (channel pairs, or channels for phase pairing)
+  uint32_t blocks_per_wave; // lane blocks (P periods each) per wave
+  uint32_t blocks_per_tile; // ... per workgroup
+  uint32_t row_stride;      // floats between LDS rows (P frames + bank padding)
+  uint32_t skip;            // diagnostics only
+};
+
 struct PeriodParams {
   const float *rows;      // effective taps, layout [group][s][i] (device, read by scalar loads)
   const uint32_t *delta;  // per group: (g*R*num) div den, first-input offset of the group

@@ -92,6 +92,13 @@ int Batch::setup() {
     HIP_TRY(hipMalloc(&d_period_rows_, rows.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(d_period_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  upsample_ = plan_upsample(filter_, channels_);
+  if (upsample_.usable) {
+    std::vector<float> rows;
+    build_upsample_rows(filter_, upsample_, &rows);
+    HIP_TRY(hipMalloc(&d_upsample_rows_, rows.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_upsample_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   const char *fk = std::getenv("SPEEXHIP_FAST_KERNEL");
   prefer_tiled_ = fk != nullptr && std::strcmp(fk, "tiled") == 0;
   if (n_streams_ > static_cast<uint32_t>(kMaxPackedStreams)) {
@@ -111,6 +118,7 @@ Batch::~Batch() {
   (void)hipFree(d_hist_[1]);
   (void)hipFree(d_phase_rows_);
   (void)hipFree(d_period_rows_);
+  (void)hipFree(d_upsample_rows_);
   (void)hipFree(d_ring_);
   if (h_ring_) (void)hipHostFree(h_ring_);
   for (int i = 0; i < kRing; i++)
@@ -141,7 +149,8 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
   o->sinc_table_length = filter_.table_len;
   o->kernel = filter_.kind;
   o->mode = mode_;
-  o->fast_path = (period_.usable && !(prefer_tiled_ && tiled_.usable)) ? 2 : (tiled_.usable ? 1 : 0);
+  const bool pick_tiled = prefer_tiled_ && tiled_.usable;
+  o->fast_path = (period_.usable && !pick_tiled) ? 2 : (upsample_.usable && !pick_tiled) ? 3 : (tiled_.usable ? 1 : 0);
   if (s < n_streams_) {
     o->last_sample = pos_[s].last;
     o->samp_frac_num = pos_[s].frac;
@@ -211,6 +220,9 @@ int Batch::process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_
     if (mode_ == SPEEXHIP_MODE_FAST && period_.usable && !(prefer_tiled_ && tiled_.usable))
       e = launch_period(filter_, period_, d_period_rows_, channels_, descs, d_descs,
                         packed ? &pack : nullptr, n_streams_, stream);
+    else if (mode_ == SPEEXHIP_MODE_FAST && upsample_.usable && !(prefer_tiled_ && tiled_.usable))
+      e = launch_upsample(filter_, upsample_, d_upsample_rows_, channels_, descs, d_descs,
+                          packed ? &pack : nullptr, n_streams_, stream);
     else if (mode_ == SPEEXHIP_MODE_FAST && tiled_.usable)
       e = launch_tiled(filter_, tiled_, d_phase_rows_, channels_, descs, d_descs,
                        packed ? &pack : nullptr, n_streams_, max_out, stream);

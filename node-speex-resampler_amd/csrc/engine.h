@@ -58,6 +58,8 @@ class Batch {
   PeriodPlan period_;      // primary fast path (kernels_period.hip)
   float *d_period_rows_ = nullptr;
   bool prefer_tiled_ = false;  // env SPEEXHIP_FAST_KERNEL=tiled
+  UpsamplePlan upsample_;  // integer-ratio up-sampling fast path (kernels_upsample.hip)
+  float *d_upsample_rows_ = nullptr;
 
   // descriptor transport for batches larger than kMaxPackedStreams
   static const int kRing = 32;

@@ -59,4 +59,16 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
                          const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
                          uint32_t n_streams, hipStream_t stream);
 
+// ---- integer-ratio up-sampling fast kernel (kernels_upsample.hip): num == 1, den <= 6 -------
+struct UpsamplePlan {
+  bool usable = false;
+  bool pair_ch = true;      // packed FMA over channel pairs (even channel count) or phase pairs
+  uint32_t p = 8, np = 1, cgroups = 1, row_stride = 0;
+};
+UpsamplePlan plan_upsample(const FilterSpec &f, uint32_t channels);
+void build_upsample_rows(const FilterSpec &f, const UpsamplePlan &t, std::vector<float> *rows);
+hipError_t launch_upsample(const FilterSpec &f, const UpsamplePlan &t, const float *d_rows, uint32_t channels,
+                           const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                           uint32_t n_streams, hipStream_t stream);
+
 }  // namespace speexhip

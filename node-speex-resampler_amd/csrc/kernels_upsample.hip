@@ -1,0 +1,280 @@
+// kernels_upsample.hip -- fast gfx950 kernel for integer-ratio up-sampling (num == 1, den <= 6):
+// 24k->48k, 16k->48k, 8k->48k, same-rate ... (BASELINE configs[2]; the reference picks
+// resampler_basic_direct_{single,double} for these, deps/speex/resample.c:331-435).  +-1 LSB.
+//
+// With num == 1 output K = m*den + r reads V[base + m + s] for s < taps: consecutive periods m
+// slide over the input by ONE frame.  So a lane that owns P consecutive periods needs, for U
+// tap steps, only P-1+U input frames for P*den*U multiply-adds:
+//   lane  = block of P consecutive periods (x one channel pair): P*den accumulator pairs, a
+//           register window of P-1+U frames re-read from LDS once per iteration;
+//   taps  = wave-uniform (every lane is at the same step): scalar loads -> SGPR operands of
+//           v_pk_fma_f32, U*den taps per iteration;
+//   packing: even channel count -> one packed FMA = both channels of a frame (tap broadcast);
+//            odd  channel count -> one packed FMA = two phases of one sample (sample broadcast),
+//            den padded to even with a zero phase.
+//   LDS   = the tile's input as float in rows of P frames, one row per lane, row stride padded so
+//           that the 64 lanes of a wave hit distinct banks; iteration `it` of lane l reads rows
+//           l+it and l+it+1 (U == P, so the window advances exactly one row per iteration).
+//   out   = each lane owns P*den consecutive output frames: contiguous wide stores.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "device_helpers.h"
+#include "device_types.h"
+#include "filter_design.h"
+#include "kernels.h"
+
+namespace speexhip {
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned wide store
+typedef __attribute__((address_space(1))) u32x4_a4 g_u32x4_a4;
+
+// acc.xy += tap[hi].xx * x.xy   (channel-pair packing: tap broadcast from an SGPR pair)
+__device__ __forceinline__ void fma_bcast_tap(f32x2 &acc, const f32x2 &tap_pair, const f32x2 &x, bool hi) {
+  if (hi)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+}
+// acc.xy += tap.xy * x.xx       (phase-pair packing: sample broadcast from the low half of a pair)
+__device__ __forceinline__ void fma_bcast_x(f32x2 &acc, const f32x2 &tap_pair, const f32x2 &x) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+}
+
+// PAIR_CH: true = channel pairs (NP = den accumulators per period), false = phase pairs (NP = ceil(den/2)).
+// P: periods per lane = tap steps per iteration.
+template <int P, int NP, bool PAIR_CH, bool PACKED>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void resample_upsample(
+    UpsampleParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
+  if (blockIdx.x == gridDim.x - 1) {
+    roll_history(p.taps, p.channels, d);
+    return;
+  }
+  if (d.n_out == 0) return;
+  const uint32_t C = p.channels;
+  const uint32_t K_end = d.k_shift + d.n_out;
+  const uint32_t m_total = (K_end + p.den - 1) / p.den;
+  const uint32_t tile_periods = p.blocks_per_tile * P;  // lane blocks x P
+  const uint32_t m_lo = blockIdx.x * tile_periods;
+  if (m_lo >= m_total) return;
+  const uint32_t m_cnt = min(tile_periods, m_total - m_lo);
+
+  // ---- stage: frames [f0, f0 + m_cnt + taps) of V, frame f -> row f / P, column (f % P) * C + c ----
+  {
+    const int64_t hist_elems = static_cast<int64_t>(p.taps - 1) * C;
+    const int64_t in_elems = static_cast<int64_t>(d.in_frames) * C;
+    const int64_t q0 = (static_cast<int64_t>(d.base_shift) + m_lo) * C - hist_elems;  // input-relative
+    const uint32_t frames = m_cnt + p.taps + P;  // + one row of slack for the last iteration
+    const uint32_t total = frames * C;
+    const uint32_t row_elems = P * C;
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+      const uint32_t row = e / row_elems, col = e - row * row_elems;
+      xs[row * p.row_stride + col] = rel_sample(d, q0 + e, hist_elems, in_elems);
+    }
+  }
+  __syncthreads();
+
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t cg = lane % p.cgroups;        // channel pair (PAIR_CH) or channel (phase pairs)
+  const uint32_t lb = wave * p.blocks_per_wave + lane / p.cgroups;  // lane block inside the tile
+  const bool lane_live = (lane / p.cgroups) < p.blocks_per_wave && lb * P < m_cnt;
+  constexpr int CW = PAIR_CH ? 2 : 1;          // floats this lane reads per frame
+  const float *xrow = xs + min(lb, p.blocks_per_tile - 1) * p.row_stride + cg * CW;
+
+  f32x2 acc[P][NP];
+#pragma unroll
+  for (int pp = 0; pp < P; pp++)
+#pragma unroll
+    for (int r = 0; r < NP; r++) acc[pp][r] = f32x2{0.f, 0.f};
+
+  constexpr int TAPS_IT = PAIR_CH ? P * NP : P * NP * 2;  // tap floats per iteration
+  constexpr int TP = TAPS_IT / 2;                         // ... as SGPR pairs
+  static_assert(TAPS_IT % 2 == 0, "tap floats per iteration must pair up");
+  const float *__restrict__ trow = rows;  // wave-uniform, __restrict__ kernel argument -> s_load
+  const uint32_t n_it = (p.skip & 4u) ? 0 : p.taps / P;
+  for (uint32_t it = 0; it < n_it; it++, trow += TAPS_IT, xrow += p.row_stride) {
+    f32x2 tp[TP];
+#pragma unroll
+    for (int j = 0; j < TP; j++) tp[j] = *reinterpret_cast<const f32x2 *>(trow + 2 * j);
+    f32x2 xw[2 * P - 1];  // frames it*P .. it*P + 2P-2 of this lane's block
+#pragma unroll
+    for (int j = 0; j < 2 * P - 1; j++) {
+      const float *px = xrow + (j < P ? j * C : p.row_stride + (j - P) * C);
+      if (PAIR_CH) {
+        xw[j] = *reinterpret_cast<const f32x2 *>(px);
+      } else {
+        xw[j].x = *px;
+        xw[j].y = 0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < P; s++)
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+          if (PAIR_CH) {
+            const int k = s * NP + r;
+            fma_bcast_tap(acc[pp][r], tp[k >> 1], xw[pp + s], (k & 1) != 0);
+          } else {
+            fma_bcast_x(acc[pp][r], tp[s * NP + r], xw[pp + s]);
+          }
+        }
+  }
+  if (!lane_live || (p.skip & 8u)) return;
+
+  // ---- round, interleave, store: P*den consecutive output frames of this lane -----------------
+  const uint64_t K0 = static_cast<uint64_t>(m_lo + lb * P) * p.den;
+  uint32_t v[P * NP];  // packed s16 pairs in output order
+#pragma unroll
+  for (int pp = 0; pp < P; pp++)
+#pragma unroll
+    for (int r = 0; r < NP; r++) v[pp * NP + r] = round_pack_pcm(acc[pp][r].x, acc[pp][r].y);
+  // The lane's pairs are consecutive dwords of the output when a frame is exactly one pair
+  // (stereo) or phase pairs tile a mono period: wide dword-aligned stores, 16 bytes at a time.
+  const bool dense = PAIR_CH ? (C == 2) : (C == 1 && p.den == 2u * NP);
+  const bool inside = K0 >= d.k_shift && K0 + static_cast<uint64_t>(P) * p.den <= K_end;
+  g_i16 *o0 = as_global(d.out) + (static_cast<int64_t>(K0) - static_cast<int64_t>(d.k_shift)) * C;
+  if (dense && inside && (reinterpret_cast<uintptr_t>(o0) & 3u) == 0) {
+    static_assert((P * NP) % 4 == 0, "pairs per lane come in groups of 4");
+#pragma unroll
+    for (int q = 0; q < P * NP; q += 4)
+      *(g_u32x4_a4 *)(o0 + 2 * q) = u32x4_a4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+    return;
+  }
+#pragma unroll
+  for (int pp = 0; pp < P; pp++) {
+#pragma unroll
+    for (int r = 0; r < NP; r++) {
+      const uint32_t w = v[pp * NP + r];
+      if (PAIR_CH) {
+        const uint64_t K = K0 + static_cast<uint64_t>(pp) * p.den + r;
+        if (K < d.k_shift || K >= K_end) continue;
+        g_i16 *o = as_global(d.out) + (K - d.k_shift) * C + cg * 2;
+        o[0] = static_cast<int16_t>(w & 0xffffu);
+        o[1] = static_cast<int16_t>(w >> 16);
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const uint32_t ph = 2 * r + h;
+          const uint64_t K = K0 + static_cast<uint64_t>(pp) * p.den + ph;
+          if (ph >= p.den || K < d.k_shift || K >= K_end) continue;
+          as_global(d.out)[(K - d.k_shift) * C + cg] = static_cast<int16_t>(h ? (w >> 16) : (w & 0xffffu));
+        }
+      }
+    }
+  }
+}
+
+template <int P, int NP, bool PAIR_CH>
+hipError_t launch_up(const UpsampleParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
+                     uint32_t threads, size_t lds_bytes, hipStream_t stream) {
+  DescPack empty;
+  if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_upsample<P, NP, PAIR_CH, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_upsample<P, NP, PAIR_CH, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  if (pack != nullptr)
+    hipLaunchKernelGGL((resample_upsample<P, NP, PAIR_CH, true>), grid, dim3(threads), lds_bytes, stream, p,
+                       p.rows, nullptr, *pack);
+  else
+    hipLaunchKernelGGL((resample_upsample<P, NP, PAIR_CH, false>), grid, dim3(threads), lds_bytes, stream, p,
+                       p.rows, d_descs, empty);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+UpsamplePlan plan_upsample(const FilterSpec &f, uint32_t channels) {
+  UpsamplePlan t;
+  t.pair_ch = channels % 2 == 0;
+  t.np = t.pair_ch ? f.den : (f.den + 1) / 2;
+  t.cgroups = t.pair_ch ? channels / 2 : channels;
+  // accumulator pairs per lane P*NP <= 24 and tap floats per iteration <= 48
+  t.p = (t.pair_ch ? (f.den <= 3) : (t.np <= 2)) ? 8 : 4;
+  const uint32_t row_elems = t.p * channels;
+  // row stride: distinct banks for the lanes of a wave (ds_read_b64: stride/2 odd; b32: stride odd)
+  t.row_stride = row_elems;
+  if (t.pair_ch) {
+    if ((t.row_stride / 2) % 2 == 0) t.row_stride += 2;
+  } else {
+    if (t.row_stride % 2 == 0) t.row_stride += 1;
+  }
+  t.usable = f.num == 1 && f.den <= 6 && f.den != 5 && f.taps % t.p == 0 && t.cgroups <= 64;
+  return t;
+}
+
+void build_upsample_rows(const FilterSpec &f, const UpsamplePlan &t, std::vector<float> *rows) {
+  // [step][phase] (phase count padded to 2*np for phase pairs), + one iteration of zero padding
+  const uint32_t width = t.pair_ch ? f.den : 2 * t.np;
+  rows->assign(static_cast<size_t>(f.taps + t.p) * width, 0.f);
+  std::vector<double> h(f.taps);
+  for (uint32_t r = 0; r < f.den; r++) {
+    // num == 1: phase of row r is r, all rows start at the same input frame
+    phase_taps(f, r % f.den, h.data());
+    for (uint32_t s = 0; s < f.taps; s++) (*rows)[static_cast<size_t>(s) * width + r] = static_cast<float>(h[s]);
+  }
+}
+
+hipError_t launch_upsample(const FilterSpec &f, const UpsamplePlan &t, const float *d_rows, uint32_t channels,
+                           const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                           uint32_t n_streams, hipStream_t stream) {
+  uint32_t max_periods = 0;
+  for (uint32_t s = 0; s < n_streams; s++) {
+    if (h_descs[s].n_out == 0) continue;
+    const uint64_t k_end = static_cast<uint64_t>(h_descs[s].k_shift) + h_descs[s].n_out;
+    max_periods = std::max<uint32_t>(max_periods, static_cast<uint32_t>((k_end + f.den - 1) / f.den));
+  }
+  // lane blocks per wave, waves per workgroup: fewer waves when the launch is small, so that it
+  // still spreads over the chip
+  const uint32_t blocks_per_wave = 64 / t.cgroups;
+  uint32_t waves = 16;
+  while (waves > 2 && static_cast<uint64_t>(max_periods) * n_streams < 512ull * waves * blocks_per_wave * t.p)
+    waves /= 2;
+  UpsampleParams p;
+  p.rows = d_rows;
+  p.den = f.den;
+  p.taps = f.taps;
+  p.channels = channels;
+  p.cgroups = t.cgroups;
+  p.blocks_per_wave = blocks_per_wave;
+  p.blocks_per_tile = blocks_per_wave * waves;
+  p.row_stride = t.row_stride;
+  static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
+  p.skip = skip_mask;
+  const uint32_t tile_periods = p.blocks_per_tile * t.p;
+  const uint32_t tiles = (max_periods + tile_periods - 1) / tile_periods;
+  // LDS: rows for tile_periods + taps + P frames
+  const size_t rows_needed = (tile_periods + f.taps + t.p + t.p - 1) / t.p + 2;
+  const size_t lds = rows_needed * t.row_stride * 4;
+  dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
+  const uint32_t threads = waves * 64;
+#define SPEEXHIP_UP_CASE(PP, NPV, CHV) \
+  if (t.p == PP && t.np == NPV && t.pair_ch == CHV) return launch_up<PP, NPV, CHV>(p, d_descs, pack, grid, threads, lds, stream);
+  SPEEXHIP_UP_CASE(8, 1, true)
+  SPEEXHIP_UP_CASE(8, 2, true)
+  SPEEXHIP_UP_CASE(8, 3, true)
+  SPEEXHIP_UP_CASE(4, 4, true)
+  SPEEXHIP_UP_CASE(4, 6, true)
+  SPEEXHIP_UP_CASE(8, 1, false)
+  SPEEXHIP_UP_CASE(8, 2, false)
+  SPEEXHIP_UP_CASE(4, 3, false)
+#undef SPEEXHIP_UP_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace speexhip
