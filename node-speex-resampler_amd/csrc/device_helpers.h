@@ -126,12 +126,16 @@ struct WindowGeom {
   uint32_t head_end, tail_begin;  // scalar ranges [0, head_end) U [tail_begin, total)
   uint32_t u_begin, n_wide;    // wide groups: LDS floats [8*u_begin, 8*(u_begin+n_wide))
   uint32_t xshift;             // float index of the window's first frame inside the image
+  uint32_t pad, period_elems;  // bank padding: `pad` floats inserted after every period_elems
+                               // (= num*channels) floats counted from the window's first frame
 };
 
 __device__ __forceinline__ WindowGeom window_geom(const StreamDesc &d, uint32_t taps, uint32_t channels,
                                                   uint32_t num, uint32_t tail_frames, uint32_t m_lo,
-                                                  uint32_t m_cnt) {
+                                                  uint32_t m_cnt, uint32_t pad = 0) {
   WindowGeom w;
+  w.pad = pad;
+  w.period_elems = num * channels;
   w.hist_elems = static_cast<int64_t>(taps - 1) * channels;
   w.in_elems = static_cast<int64_t>(d.in_frames) * channels;
   const int64_t q_lo =
@@ -185,23 +189,60 @@ __device__ __forceinline__ void unpack8(const u32x4 &w, float4 *dst) {
   dst[1] = hi;
 }
 
+// LDS float position of image float j when the layout is padded (pad floats after every
+// period_elems floats counted from the window's first frame, i.e. from image float xshift)
+__device__ __forceinline__ uint32_t padded_pos(const WindowGeom &g, uint32_t j) {
+  return j + (j >= g.xshift ? (j - g.xshift) / g.period_elems : 0u) * g.pad;
+}
+
+// 8 consecutive image floats starting at j (multiple of 8): two 16-byte writes unless the group
+// straddles a padding boundary
+__device__ __forceinline__ void commit8(float *xs, const WindowGeom &g, uint32_t j, const u32x4 &w) {
+  if (g.pad == 0) {
+    unpack8(w, reinterpret_cast<float4 *>(xs + j));
+    return;
+  }
+  const uint32_t a = padded_pos(g, j), b = padded_pos(g, j + 7);
+  if (b - a == 7 && (a & 3u) == 0) {
+    unpack8(w, reinterpret_cast<float4 *>(xs + a));
+  } else {
+    float4 t[2];
+    unpack8(w, t);
+    const float *f = reinterpret_cast<const float *>(t);
+#pragma unroll
+    for (int k = 0; k < 8; k++) xs[padded_pos(g, j + k)] = f[k];
+  }
+}
+
 template <int UNR>
 __device__ __forceinline__ void window_commit(float *xs, const StreamDesc &d, const WindowGeom &g,
                                               const u32x4 (&w)[UNR]) {
 #pragma unroll
   for (int u = 0; u < UNR; u++) {
     const uint32_t unit = u * blockDim.x + threadIdx.x;
-    if (unit < g.n_wide) unpack8(w[u], reinterpret_cast<float4 *>(xs + 8 * static_cast<size_t>(g.u_begin + unit)));
+    if (unit < g.n_wide) commit8(xs, g, 8 * (g.u_begin + unit), w[u]);
   }
-  // groups beyond the prefetched UNR per lane (very wide windows): fetch them now
-  for (uint32_t unit = UNR * blockDim.x + threadIdx.x; unit < g.n_wide; unit += blockDim.x) {
-    const u32x4 v = *(g_cuint4 *)(g.src + 8 * static_cast<size_t>(unit));
-    unpack8(v, reinterpret_cast<float4 *>(xs + 8 * static_cast<size_t>(g.u_begin + unit)));
+  // groups beyond the prefetched UNR per lane (small workgroups, very wide windows): further
+  // rounds of UNR loads in flight at a time
+  for (uint32_t base = UNR * blockDim.x; base < g.n_wide; base += UNR * blockDim.x) {
+    u32x4 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const uint32_t unit = base + u * blockDim.x + threadIdx.x;
+      v[u] = *(g_cuint4 *)(g.src + 8 * static_cast<size_t>(min(unit, g.n_wide - 1)));
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; u++) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const uint32_t unit = base + u * blockDim.x + threadIdx.x;
+      if (unit < g.n_wide) commit8(xs, g, 8 * (g.u_begin + unit), v[u]);
+    }
   }
   for (uint32_t j = threadIdx.x; j < g.head_end; j += blockDim.x)
-    xs[j] = rel_sample(d, g.q_base + j, g.hist_elems, g.in_elems);
+    xs[g.pad ? padded_pos(g, j) : j] = rel_sample(d, g.q_base + j, g.hist_elems, g.in_elems);
   for (uint32_t j = g.tail_begin + threadIdx.x; j < g.total; j += blockDim.x)
-    xs[j] = rel_sample(d, g.q_base + j, g.hist_elems, g.in_elems);
+    xs[g.pad ? padded_pos(g, j) : j] = rel_sample(d, g.q_base + j, g.hist_elems, g.in_elems);
 }
 
 // Two floats -> packed s16 pair {lo, hi} with the reference's rounding: floor(x + .5), then

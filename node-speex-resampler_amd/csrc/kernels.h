@@ -51,6 +51,7 @@ struct PeriodPlan {         // per filter, fixed at init
   bool usable = false;
   uint32_t r = 10, ct = 1, cgroups = 0, groups = 0;
   uint32_t row_len = 0, l4 = 0, tail_frames = 0, lane_periods = 0;
+  uint32_t pad = 0;          // LDS bank padding (floats after every period), 0 = none needed
   size_t rows_floats = 0, window_bytes = 0;
 };
 PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget);

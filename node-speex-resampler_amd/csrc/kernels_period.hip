@@ -54,7 +54,7 @@ __device__ __forceinline__ void fma_tap(f32x2 &acc, const f32x2 &tap_pair, const
 
 // FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
 // followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
-template <int R, int CT, bool ONE_GROUP>
+template <int R, int CT, bool ONE_GROUP, bool PADDED>
 __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__restrict__ rows,
                                          const StreamDesc &d, const float *xs, uint32_t xshift,
                                          uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
@@ -66,7 +66,10 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
   const uint32_t pl = ONE_GROUP ? lane : lane / p.cgroups;  // period of this lane inside the tile
   const bool lane_live = pl < m_cnt;
   // float index of this lane's first sample of a group with delta_g = 0
-  const uint32_t xlane = xshift + min(pl, p.lane_periods - 1) * p.num * C + cg * CT;
+  // PADDED: the LDS image carries p.pad floats after every period (num frames) so that the
+  // lanes of a wave -- num*C floats apart, a multiple of the bank count for e.g. 8 channels at
+  // num = 160 -- hit distinct banks; the per-step offset is then wave-uniform scalar arithmetic.
+  const uint32_t xlane = xshift + min(pl, p.lane_periods - 1) * (p.num * C + (PADDED ? p.pad : 0u)) + cg * CT;
   const uint64_t K_lane = static_cast<uint64_t>(m_lo + pl) * p.den;
 
   const uint32_t g_step = p.wave_groups * nsplit;
@@ -75,20 +78,21 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 #pragma unroll
     for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
     const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
-    const float *xp = xs + xlane + delta_g * C;
+    const float *xp = xs + xlane + delta_g * C;  // delta_g < num: no padding boundary before it
     const uint32_t n_it = (p.skip & 4u) ? 0 : p.l4;
+    // padded layout: the host shifted this group's start by <= 3 frames so that the one padding
+    // boundary its window crosses falls between iterations wrap_it-1 and wrap_it
+    const uint32_t wrap_it = PADDED ? p.delta[p.groups + g] : 0xffffffffu;
     // Taps are wave-uniform: they travel HBM/L2 -> scalar cache -> SGPRs (s_load: the row pointer
     // is a __restrict__ kernel argument, so the loads are provably invariant) and feed
-    // v_pk_fma_f32 directly.  The 4R taps of an iteration live in two banks (steps 0-1, steps
-    // 2-3) written in software-pipelined order: each bank is re-loaded while the other bank's
-    // 2R FMAs issue, so a scalar-load round trip overlaps FMAs of the same wave.
-    const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (4 * R);
+    // v_pk_fma_f32 directly.
     // Bank A = steps 0-1 of an iteration, bank B = steps 2-3: each bank is its 2R taps (R SGPR
     // pairs) plus its two sample reads.  Order per iteration, pinned with sched_barrier:
     //   wait A | issue loads B | 2R FMAs A | wait B | issue loads A(next) | 2R FMAs B
     // A wait is lgkmcnt(0) (scalar loads return out of order and share the counter with LDS),
     // so a bank's loads must be issued right AFTER the other bank's wait; `touch_bank` is an
     // empty asm that reads the bank and thereby makes hipcc put the wait exactly there.
+    const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (4 * R);
     f32x2 ta[R], tb[R], xa[2], xb[2];
     auto load_bank = [&](f32x2 (&t)[R], f32x2 (&x)[2], const float *tp, const float *sp) {
 #pragma unroll
@@ -125,7 +129,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
       touch_bank(tb, xb);
       __builtin_amdgcn_sched_barrier(0);
       trow += 4 * R;
-      xp += 4 * C;
+      xp += 4 * C + ((PADDED && it + 1 == wrap_it) ? p.pad : 0u);  // wave-uniform select
       // next iteration's bank A: the rows carry one iteration of zero padding past the last
       // group and the window one step group of slack, so the final prefetch stays in bounds
       load_bank(ta, xa, trow, xp);
@@ -183,7 +187,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 //
 // One-shot form: workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one
 // of gridDim.z shares of its phase groups.  Used when a launch has too few tiles to loop over.
-template <int R, int CT, bool ONE_GROUP, bool PACKED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   if (m_lo >= m_total) return;
   const uint32_t m_cnt = min(p.lane_periods, m_total - m_lo);
 
-  const WindowGeom wg = window_geom(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt);
+  const WindowGeom wg = window_geom(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
   if (!(p.skip & 2u)) {
     u32x4 w[3];
     window_fetch<3>(wg, w);
@@ -207,8 +211,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   }
   __syncthreads();
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  fir_tile<R, CT, ONE_GROUP>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z,
-                             gridDim.z);
+  fir_tile<R, CT, ONE_GROUP, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
+                                     blockIdx.z, gridDim.z);
 }
 
 // Persistent form: gridDim.x workgroups (two per CU) walk the launch's flat tile list
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
 // next tile's input window are already in flight (registers), so HBM latency, the int16->float
 // conversion and the stores of one workgroup hide behind the other's FMAs and the workgroups
 // never fall into lock-step the way back-to-back launches of the one-shot form do.
-template <int R, int CT, bool ONE_GROUP, bool PACKED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED>
 __device__ __forceinline__ void persistent_body(const PeriodParams &p, const float *__restrict__ rows,
                                                 const StreamDesc *streams, const DescPack &pack,
                                                 uint32_t n_streams, uint32_t tiles_per_stream, float *xs) {
@@ -238,7 +242,7 @@ __device__ __forceinline__ void persistent_body(const PeriodParams &p, const flo
     m_lo = (t - s * tiles_per_stream) * p.lane_periods;
     m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 0;
     if (m_cnt) {
-      wg = window_geom(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt);
+      wg = window_geom(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
       window_fetch<3>(wg, w);
     }
   };
@@ -251,29 +255,29 @@ __device__ __forceinline__ void persistent_body(const PeriodParams &p, const flo
     const uint32_t Tn = T + gridDim.x;
     if (Tn < total) open_tile(Tn);  // next window's loads fly during this tile's FIR
     if (m_cnt_cur)
-      fir_tile<R, CT, ONE_GROUP>(p, rows, d_cur, xs, xshift_cur, m_lo_cur, m_cnt_cur, wave, lane, 0, 1);
+      fir_tile<R, CT, ONE_GROUP, PADDED>(p, rows, d_cur, xs, xshift_cur, m_lo_cur, m_cnt_cur, wave, lane, 0, 1);
     __syncthreads();  // every wave is done with this window before it is overwritten
     T = Tn;
   }
 }
 
-template <int R, int CT, bool ONE_GROUP, bool PACKED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period_persistent(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack,
     uint32_t n_streams, uint32_t tiles_per_stream) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  persistent_body<R, CT, ONE_GROUP, PACKED>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
+  persistent_body<R, CT, ONE_GROUP, PADDED, PACKED>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
 }
 
 // Same walk without the SGPR cap: all 4R taps of an iteration arrive with ONE scalar-load wait
 // (~106 SGPRs -> 7 waves per SIMD -> one 16-wave workgroup per CU; the software pipeline, not
 // a second workgroup, hides the staging).
-template <int R, int CT, bool ONE_GROUP, bool PACKED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED>
 __global__ __launch_bounds__(1024) void resample_period_persistent_wide(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack,
     uint32_t n_streams, uint32_t tiles_per_stream) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  persistent_body<R, CT, ONE_GROUP, PACKED>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
+  persistent_body<R, CT, ONE_GROUP, PADDED, PACKED>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
 }
 
 template <typename K>
@@ -282,7 +286,7 @@ void opt_in_lds(K kern) {
                             160 * 1024);
 }
 
-template <int R, int CT, bool ONE_GROUP>
+template <int R, int CT, bool ONE_GROUP, bool PADDED>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, uint32_t n_streams, uint32_t tiles_per_stream,
                      bool persistent, hipStream_t stream) {
@@ -290,35 +294,35 @@ hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const Des
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static bool once = false;
   if (!once) {
-    opt_in_lds(resample_period<R, CT, ONE_GROUP, true>);
-    opt_in_lds(resample_period<R, CT, ONE_GROUP, false>);
-    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, true>);
-    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, false>);
-    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, true>);
-    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, false>);
+    opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, true>);
+    opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, false>);
+    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, true>);
+    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, false>);
+    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true>);
+    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false>);
     once = true;
   }
   static const bool wide = std::getenv("SPEEXHIP_WIDE") && std::atoi(std::getenv("SPEEXHIP_WIDE")) != 0;
   if (persistent && wide) {
     if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, true>), grid, dim3(threads), lds_bytes,
+      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true>), grid, dim3(threads), lds_bytes,
                          stream, p, p.rows, nullptr, *pack, n_streams, tiles_per_stream);
     else
-      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, false>), grid, dim3(threads), lds_bytes,
+      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false>), grid, dim3(threads), lds_bytes,
                          stream, p, p.rows, d_descs, empty, n_streams, tiles_per_stream);
   } else if (persistent) {
     if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, true>), grid, dim3(threads), lds_bytes,
+      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, PADDED, true>), grid, dim3(threads), lds_bytes,
                          stream, p, p.rows, nullptr, *pack, n_streams, tiles_per_stream);
     else
-      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, false>), grid, dim3(threads), lds_bytes,
+      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, PADDED, false>), grid, dim3(threads), lds_bytes,
                          stream, p, p.rows, d_descs, empty, n_streams, tiles_per_stream);
   } else {
     if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, true>), grid, dim3(threads), lds_bytes, stream, p,
+      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true>), grid, dim3(threads), lds_bytes, stream, p,
                          p.rows, nullptr, *pack);
     else
-      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, false>), grid, dim3(threads), lds_bytes, stream, p,
+      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false>), grid, dim3(threads), lds_bytes, stream, p,
                          p.rows, d_descs, empty);
   }
   return hipGetLastError();
@@ -347,8 +351,57 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
   t.lane_periods = 64 / t.cgroups;
   // + one iteration (4R floats) of zero padding: the tap pipeline prefetches one past the end
   t.rows_floats = static_cast<size_t>(t.groups) * t.l4 * 4 * t.r + 4 * t.r;
-  // (+ 4 frames: the tap/sample pipeline prefetches one bank past the last step)
-  t.window_bytes = ((static_cast<size_t>(t.lane_periods) - 1) * f.num + t.tail_frames + 4) * channels * 4 + kSlack * 4;
+  // Bank padding: the lanes of a wave read the window num*channels floats apart.  Find the
+  // smallest pad (multiple of 4 floats, inserted after every period) for which the 32 lanes of a
+  // half-wave hit 32 distinct banks (ds_read_b32) / bank pairs (ds_read_b64).
+  t.pad = 0;
+  {
+    const uint32_t unit = t.ct;  // floats per lane access
+    for (uint32_t pad = 0; pad <= 64; pad += 4) {
+      const uint32_t stride = f.num * channels + pad;
+      bool seen[64] = {false};
+      bool ok = true;
+      for (uint32_t lane = 0; lane < 32 && ok; lane++) {
+        const uint32_t cg = lane % t.cgroups, pl = lane / t.cgroups;
+        if (pl >= t.lane_periods) break;
+        const uint32_t slot = ((pl * stride + cg * t.ct) / unit) % (64 / unit);
+        ok = !seen[slot];
+        seen[slot] = true;
+      }
+      if (ok) {
+        t.pad = pad;
+        break;
+      }
+    }
+  }
+  static const bool no_pad = std::getenv("SPEEXHIP_NO_PAD") != nullptr;
+  if (no_pad) t.pad = 0;
+  if (t.pad != 0) {
+    // A padded window is only walked cheaply if each group crosses at most ONE period boundary
+    // and that boundary can be moved onto an iteration boundary by starting the group k <= 3
+    // frames early (k extra zero taps in front of its rows).
+    const uint32_t row_len = (f.taps + dmax + 3 + 3) / 4 * 4;
+    bool ok = true;
+    for (uint32_t g = 0; g < t.groups && ok; g++) {
+      const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
+      if (dg + row_len + 4 <= f.num) continue;                 // never reaches the boundary
+      const uint32_t k = (dg % 4 + 4 - f.num % 4) % 4;  // delta' = dg - k == num (mod 4)
+      ok = dg >= k && (dg - k) + row_len + 4 <= 2 * f.num;     // shiftable, and a single crossing
+    }
+    if (ok) {
+      t.row_len = row_len;
+      t.l4 = row_len / 4;
+      t.rows_floats = static_cast<size_t>(t.groups) * t.l4 * 4 * t.r + 4 * t.r;
+      t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * t.r * f.num) / f.den) + t.row_len;
+    } else {
+      t.pad = 0;
+    }
+  }
+  // (+ 4 frames: the tap/sample pipeline prefetches one bank past the last step; + the padding
+  //  of every period the window can touch)
+  const size_t pad_floats = static_cast<size_t>(t.pad) * (t.lane_periods + t.tail_frames / f.num + 2);
+  t.window_bytes = (((static_cast<size_t>(t.lane_periods) - 1) * f.num + t.tail_frames + 4) * channels + pad_floats) * 4 +
+                   kSlack * 4;
   // the same LDS later holds the tile's output image (one packed s16 pair per dword)
   t.window_bytes = std::max(t.window_bytes, static_cast<size_t>(t.lane_periods) * f.den * t.cgroups * 4);
   // needs enough phases to fill the R-wide register tile and a window that fits one CU's LDS
@@ -356,16 +409,31 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
   return t;
 }
 
+// Start-of-group adjustment for a padded window: k frames early so that (num - delta') % 4 == 0
+static uint32_t group_shift(const FilterSpec &f, const PeriodPlan &t, uint32_t g) {
+  if (t.pad == 0) return 0;
+  const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
+  if (dg + t.row_len + 4 <= f.num) return 0;  // this group never reaches the period boundary
+  return (dg % 4 + 4 - f.num % 4) % 4;
+}
+
 void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<float> *rows) {
-  // taps, then one uint32 per group: delta_g = (g*R*num) div den (bit-copied into the float array)
-  rows->assign(t.rows_floats + t.groups, 0.f);
+  // taps, then per group two uint32 tables (bit-copied into the float array):
+  //   delta'[g] = (g*R*num) div den - k_g   first input frame of the group inside a period
+  //   wrap[g]   = iteration before which the window pointer skips the bank padding (~0u: never)
+  rows->assign(t.rows_floats + 2 * t.groups, 0.f);
   for (uint32_t g = 0; g < t.groups; g++) {
-    const uint32_t delta = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
+    const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
+    const uint32_t k = group_shift(f, t, g);
+    const uint32_t delta = dg - k;
+    uint32_t wrap = 0xffffffffu;
+    if (t.pad != 0 && delta + t.row_len + 4 > f.num) wrap = (f.num - delta) / 4;
     std::memcpy(&(*rows)[t.rows_floats + g], &delta, sizeof(delta));
+    std::memcpy(&(*rows)[t.rows_floats + t.groups + g], &wrap, sizeof(wrap));
   }
   std::vector<double> h(f.taps);
   for (uint32_t g = 0; g < t.groups; g++) {
-    const uint64_t d0 = (static_cast<uint64_t>(g) * t.r * f.num) / f.den;
+    const uint64_t d0 = (static_cast<uint64_t>(g) * t.r * f.num) / f.den - group_shift(f, t, g);
     for (uint32_t i = 0; i < t.r; i++) {
       const uint32_t r = g * t.r + i;
       if (r >= f.den) continue;  // padding phases of the last group stay zero
@@ -403,8 +471,13 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   // are split over several workgroups.
   const bool persistent = allow_persistent && static_cast<uint64_t>(tiles) * n_streams > resident;
   uint32_t splits = 1;
-  if (!persistent)
-    while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident &&
+  static const uint32_t force_splits = std::getenv("SPEEXHIP_SPLITS") ? std::atoi(std::getenv("SPEEXHIP_SPLITS")) : 0;
+  if (!persistent && force_splits)
+    splits = std::min<uint32_t>(force_splits, t.groups);
+  else if (!persistent)
+    // (measured on cfg2, one stream: 1/2/4/8 shares -> 19.6/15.1/16.0/27.3 us: split until the
+    //  launch has about one workgroup per CU, not more -- every share re-stages the window)
+    while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident / 2 &&
            (t.groups + splits * 2 - 1) / (splits * 2) >= 2)
       splits *= 2;
   static const uint32_t max_waves = std::getenv("SPEEXHIP_WAVES") ? std::atoi(std::getenv("SPEEXHIP_WAVES")) : 16;
@@ -422,6 +495,7 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   p.lane_periods = t.lane_periods;
   p.wave_groups = wave_groups;
   p.tail_frames = t.tail_frames;
+  p.pad = t.pad;
   p.history_block = max_periods == 0 ? 0 : tiles;
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
@@ -433,15 +507,20 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   uint32_t grid_x = (max_periods == 0 ? 0 : tiles) + 1;
   if (splits > 1 && n_streams == 1) grid_x = (grid_x + 7) / 8 * 8;
   dim3 grid = persistent ? dim3(resident, 1, 1) : dim3(grid_x, n_streams, splits);
-#define SPEEXHIP_PERIOD_CASE(CTV, ONE)                                                                  \
-  return launch_rc<kR, CTV, ONE>(p, d_descs, pack, grid, threads, t.window_bytes, n_streams, tiles,   \
-                                 persistent, stream)
+#define SPEEXHIP_PERIOD_CASE(CTV, ONE, PADV)                                                              \
+  return launch_rc<kR, CTV, ONE, PADV>(p, d_descs, pack, grid, threads, t.window_bytes, n_streams, tiles, \
+                                       persistent, stream)
+  const bool padded = t.pad != 0;
   if (t.ct == 2) {
-    if (t.cgroups == 1) SPEEXHIP_PERIOD_CASE(2, true);
-    SPEEXHIP_PERIOD_CASE(2, false);
+    if (t.cgroups == 1 && !padded) SPEEXHIP_PERIOD_CASE(2, true, false);
+    if (t.cgroups == 1) SPEEXHIP_PERIOD_CASE(2, true, true);
+    if (!padded) SPEEXHIP_PERIOD_CASE(2, false, false);
+    SPEEXHIP_PERIOD_CASE(2, false, true);
   }
-  if (t.cgroups == 1) SPEEXHIP_PERIOD_CASE(1, true);
-  SPEEXHIP_PERIOD_CASE(1, false);
+  if (t.cgroups == 1 && !padded) SPEEXHIP_PERIOD_CASE(1, true, false);
+  if (t.cgroups == 1) SPEEXHIP_PERIOD_CASE(1, true, true);
+  if (!padded) SPEEXHIP_PERIOD_CASE(1, false, false);
+  SPEEXHIP_PERIOD_CASE(1, false, true);
 #undef SPEEXHIP_PERIOD_CASE
 }
 

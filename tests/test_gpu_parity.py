@@ -261,3 +261,63 @@ def test_node_drop_in_harness():
     res = subprocess.run(["node", script], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "ALL NODE TESTS PASSED" in res.stdout
+
+
+def test_integer_ratio_upsampling_kernel_variants():
+    """kernels_upsample.hip: every (den, channel parity, quality) instantiation -- channel-pair and
+    phase-pair packing, P = 8 and P = 4 -- in multi-call streams, vs the oracle."""
+    cases = [(1, 24000, 48000, 10), (2, 24000, 48000, 10), (1, 16000, 48000, 5), (2, 16000, 48000, 7),
+             (1, 8000, 48000, 8), (2, 8000, 48000, 3), (1, 12000, 48000, 9), (4, 11025, 44100, 4),
+             (1, 48000, 48000, 6), (2, 24000, 24000, 5), (3, 22050, 44100, 6), (6, 8000, 16000, 0)]
+    for (ch, i, o, q) in cases:
+        ref = orc.Oracle(ch, i, o, q)
+        r = speexhip.Resampler(ch, i, o, q)
+        assert r.info()["fast_path"] == 3, (ch, i, o, q, r.info()["fast_path"])
+        for call, frames in enumerate([1, 3000, 777, 20000]):
+            x = orc.lcg_pcm(frames * ch, 31 * call + ch).reshape(frames, ch)
+            cap = 7 * frames // 2 if call == 2 else 1 << 20  # one capacity-bound call
+            got, used = r.process(x, cap)
+            want, wu = ref.process(x, cap)
+            assert used == wu and r.position() == ref.position(), (ch, i, o, q, call)
+            assert_close(got, want, "upsample %s call %d" % ((ch, i, o, q), call))
+        r.close()
+
+
+def test_persistent_tile_walk_with_many_ragged_streams():
+    """More tiles than resident workgroups -> resample_period_persistent; ragged stream lengths
+    leave some workgroups with empty tiles; descriptors travel through the device ring."""
+    import torch
+    ch, i, o, q, S, frames = 2, 44100, 48000, 7, 40, 100000
+    lens = [frames - 997 * (s % 7) for s in range(S)]
+    xs = np.stack([orc.lcg_pcm(frames * ch, 900 + s).reshape(frames, ch) for s in range(S)])
+    cap = 110000
+    d_in = torch.from_numpy(xs).cuda()
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    b = speexhip.Batch(S, ch, i, o, q)
+    assert b.info()["fast_path"] == 2
+    refs = [orc.Oracle(ch, i, o, q) for _ in range(S)]
+    for call in range(2):
+        used, made = b.process_device(d_in.data_ptr(), frames * ch, lens, d_out.data_ptr(), cap * ch, cap,
+                                      torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        for s in range(S):
+            want, wu = refs[s].process(xs[s][: lens[s]], cap)
+            assert (used[s], made[s]) == (wu, want.shape[0])
+            assert_close(out[s, : made[s]], want, "persistent s=%d call=%d" % (s, call))
+    b.close()
+
+
+def test_eight_channel_padded_window_and_odd_channel_counts():
+    """48k->44.1k 8 ch takes the bank-padded LDS window; 3 and 5 channels take the single-channel
+    (non-packed) lanes of the period kernel."""
+    for (ch, i, o, q) in [(8, 48000, 44100, 5), (3, 44100, 48000, 7), (5, 32000, 44100, 2), (4, 44100, 32000, 8)]:
+        ref = orc.Oracle(ch, i, o, q)
+        r = speexhip.Resampler(ch, i, o, q)
+        for call, frames in enumerate([5000, 1, 20000]):
+            x = orc.tone_pcm(frames, ch, seed=call) if call else orc.lcg_pcm(frames * ch, 5).reshape(frames, ch)
+            got, used = r.process(x, 1 << 20)
+            want, wu = ref.process(x, 1 << 20)
+            assert used == wu and r.position() == ref.position()
+            assert_close(got, want, "multi-channel %s call %d" % ((ch, i, o, q), call))
+        r.close()
