@@ -50,10 +50,12 @@ def lcg_pcm(n, seed):
     return (s >> np.uint32(16)).astype(np.uint16).view(np.int16)
 
 
-def cpu_baseline(cfg, frames, budget_s=12.0, max_chunks=32):
-    """Time the CPU path on this box's host cores on a bounded sample of the same workload.
-    Prefers oracle/_ref (the reference's own C, kind "reference"); else the restatement
-    ("port").  This is the only place bench.py touches oracle/ -- as a reported baseline."""
+def cpu_baseline(cfg, frames, gpu_first_chunk=None, budget_s=12.0, max_chunks=32):
+    """The CPU leg (the ONLY place bench.py touches oracle/): time the CPU path on this box's host
+    cores on a bounded sample of the same workload -- oracle/_ref (the reference's own C, kind
+    "reference") when present, else the restatement ("port") -- and, since its warm-up chunk is
+    the very chunk the GPU processed first, use it as the checker of that chunk (parity)."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     ch, fi, fo, q = cfg
@@ -61,7 +63,15 @@ def cpu_baseline(cfg, frames, budget_s=12.0, max_chunks=32):
     eng = (orc.Reference if kind == "reference" else orc.Oracle)(ch, fi, fo, q)
     x = lcg_pcm(frames * ch, 12345).reshape(frames, ch)
     cap = wrapper_capacity(x.size * 2, fi, fo, ch)
-    eng.process(x, cap)  # warm-up chunk
+    want, want_used = eng.process(x, cap)  # warm-up chunk == the GPU's first chunk
+    parity = None
+    if gpu_first_chunk is not None:
+        got, used, made = gpu_first_chunk
+        diff = np.abs(got.astype(np.int32) - want.astype(np.int32)) if got.shape == want.shape else None
+        parity = {"checked_frames": int(want.shape[0]),
+                  "max_abs_diff_lsb": int(diff.max()) if diff is not None else -1,
+                  "mismatch_rate": float((diff != 0).mean()) if diff is not None else 1.0,
+                  "counters_equal": bool(used == want_used and made == want.shape[0])}
     t0 = time.perf_counter()
     chunks = 0
     while chunks < max_chunks and (time.perf_counter() - t0) < budget_s:
@@ -71,7 +81,7 @@ def cpu_baseline(cfg, frames, budget_s=12.0, max_chunks=32):
     return {"value": round(chunks * frames * ch / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
             "kind": kind,
             "sample": "%d chunks of %d frames x %d ch, same rates/quality, 1 thread, %.1f s" % (
-                chunks, frames, ch, dt)}
+                chunks, frames, ch, dt)}, parity
 
 
 def main():
@@ -80,6 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--custom", default=None, help="channels,in_rate,out_rate,quality (overrides --config)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU (configs[4] uses 32)")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
@@ -99,6 +110,9 @@ def main():
     dev = torch.device("cuda", local)
 
     cfg = CONFIGS[args.config]
+    if args.custom:
+        cfg = tuple(int(v) for v in args.custom.split(","))
+        CONFIG_LABEL[args.config] = "custom"
     ch, fi, fo, q = cfg
     S, F = args.streams, args.frames
     cap = wrapper_capacity(F * ch * 2, fi, fo, ch)
@@ -122,21 +136,10 @@ def main():
         b = i % nbuf
         return batch.process_device(d_in[b].data_ptr(), F * ch, F, d_out[b].data_ptr(), cap * ch, cap, sp)
 
-    # ---- parity spot-check of the first chunk (outside the timed region) ----------------------
-    parity = None
+    # first chunk (outside the timed region); kept for the CPU leg's parity check
     used, made = step(0)
     torch.cuda.synchronize()
-    if rank == 0 and not args.no_parity:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as orc
-        want, want_used = orc.Oracle(ch, fi, fo, q).process(base[0], cap)
-        got = d_out[0][0, : made[0]].cpu().numpy()
-        diff = np.abs(got.astype(np.int32) - want.astype(np.int32)) if got.shape == want.shape else None
-        parity = {"checked_frames": int(want.shape[0]),
-                  "max_abs_diff_lsb": int(diff.max()) if diff is not None else -1,
-                  "mismatch_rate": float((diff != 0).mean()) if diff is not None else 1.0,
-                  "counters_equal": bool(used[0] == want_used and made[0] == want.shape[0])}
-        assert parity["counters_equal"] and 0 <= parity["max_abs_diff_lsb"] <= 1, parity
+    first_chunk = (d_out[0][0, : made[0]].cpu().numpy(), used[0], made[0]) if rank == 0 else None
 
     for i in range(args.warmup):
         step(i + 1)
@@ -200,10 +203,11 @@ def main():
                      "frac": round(tfl / VALU_PEAK_TFLOPS, 4), "flops_per_launch": int(flops)},
             "checksum": checksum,
         }
-        if parity is not None:
-            line["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, F)
+            line["cpu_baseline"], parity = cpu_baseline(cfg, F, None if args.no_parity else first_chunk)
+            if parity is not None:
+                line["parity"] = parity
+                assert parity["counters_equal"] and 0 <= parity["max_abs_diff_lsb"] <= 1, parity
         print(json.dumps(line), flush=True)
     batch.close()
     dist_util.finish()

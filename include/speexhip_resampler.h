@@ -115,8 +115,8 @@ typedef struct SpeexHipInfo {
   int32_t kernel;                /* SPEEXHIP_KERNEL_* */
   int32_t mode;                  /* SPEEXHIP_MODE_* */
   int32_t fast_path;             /* what FAST mode runs for this configuration: 2 = period-lane
-                                    kernel, 3 = integer-ratio up-sampling kernel, 1 = tiled kernel,
-                                    0 = falls back to the exact kernel */
+                                    kernel, 3 = small-ratio sliding-window kernel, 0 = falls back
+                                    to the exact kernel (exotic ratios) */
   int32_t last_sample;           /* stream position, resample.c:135 */
   uint32_t samp_frac_num;        /* stream phase, resample.c:136 */
   int32_t device;                /* HIP device ordinal the state lives on */

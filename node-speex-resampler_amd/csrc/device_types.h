@@ -37,27 +37,10 @@ struct ExactParams {
   uint32_t span_cap;        // frames of LDS sample window per workgroup
 };
 
-struct TiledParams {
-  const float *rows;      // phase rows, layout [s/4][i][g] of float4 (device)
-  uint32_t table_f4;      // float4 count of the rows
-  uint32_t l4;            // row length / 4
-  uint32_t groups;        // phase groups (R phases each)
-  uint32_t cgroups;       // channel groups (CT channels each)
-  uint32_t num, den, taps, channels;
-  uint32_t periods;       // output periods (den outputs each) per workgroup
-  uint32_t mgroups;       // periods / M
-  uint32_t ksplit;        // lanes sharing one output's tap range (1, 2 or 4)
-  uint32_t s4_per_slice;  // float4 steps per tap slice
-  uint32_t slice_f4;      // float4 per tap slice in the global rows (s4_per_slice * R * groups)
-  uint32_t slice_pad_f4;  // float4 of LDS padding between slices (bank-conflict-free slices)
-  uint32_t tail_frames;   // input frames a period needs beyond its start
-  uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP): bit0 rows, bit1 window, bit2 FIR loop,
-                          // bit3 stores -- phases to leave out when timing; 0 in normal operation
-};
-
-struct UpsampleParams {
-  const float *rows;        // taps [step][phase] (device, read by scalar loads)
+struct SlideParams {
+  const float *rows;        // taps [step][phase], phase rows shifted by delta_r (device, scalar loads)
   uint32_t den, taps, channels;
+  uint32_t row_len;         // steps per phase row (taps + largest shift, rounded to the iteration)
   uint32_t cgroups;         // lanes per lane block (channel pairs, or channels for phase pairing)
   uint32_t blocks_per_wave; // lane blocks (P periods each) per wave
   uint32_t blocks_per_tile; // ... per workgroup

@@ -78,13 +78,6 @@ int Batch::setup() {
     HIP_TRY(hipMemset(d_hist_[i], 0, hist_bytes));  // resample.c:721-725: history starts silent
   }
   exact_geo_ = exact_geometry(filter_, channels_, kLdsBudget);
-  tiled_ = plan_tiled(filter_, channels_, kLdsBudget);
-  if (tiled_.usable) {
-    std::vector<float> rows;
-    build_phase_rows(filter_, tiled_, &rows);
-    HIP_TRY(hipMalloc(&d_phase_rows_, rows.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(d_phase_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
-  }
   period_ = plan_period(filter_, channels_, kLdsBudget);
   if (period_.usable) {
     std::vector<float> rows;
@@ -92,15 +85,15 @@ int Batch::setup() {
     HIP_TRY(hipMalloc(&d_period_rows_, rows.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(d_period_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
   }
-  upsample_ = plan_upsample(filter_, channels_);
-  if (upsample_.usable) {
+  slide_ = plan_slide(filter_, channels_);
+  if (slide_.usable && !period_.usable) {
     std::vector<float> rows;
-    build_upsample_rows(filter_, upsample_, &rows);
-    HIP_TRY(hipMalloc(&d_upsample_rows_, rows.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(d_upsample_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    build_slide_rows(filter_, slide_, &rows);
+    HIP_TRY(hipMalloc(&d_slide_rows_, rows.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_slide_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    slide_.usable = false;
   }
-  const char *fk = std::getenv("SPEEXHIP_FAST_KERNEL");
-  prefer_tiled_ = fk != nullptr && std::strcmp(fk, "tiled") == 0;
   if (n_streams_ > static_cast<uint32_t>(kMaxPackedStreams)) {
     const size_t ring_bytes = sizeof(StreamDesc) * n_streams_ * kRing;
     HIP_TRY(hipHostMalloc(&h_ring_, ring_bytes, hipHostMallocDefault));
@@ -116,9 +109,8 @@ Batch::~Batch() {
   (void)hipFree(d_table_);
   (void)hipFree(d_hist_[0]);
   (void)hipFree(d_hist_[1]);
-  (void)hipFree(d_phase_rows_);
   (void)hipFree(d_period_rows_);
-  (void)hipFree(d_upsample_rows_);
+  (void)hipFree(d_slide_rows_);
   (void)hipFree(d_ring_);
   if (h_ring_) (void)hipHostFree(h_ring_);
   for (int i = 0; i < kRing; i++)
@@ -149,8 +141,7 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
   o->sinc_table_length = filter_.table_len;
   o->kernel = filter_.kind;
   o->mode = mode_;
-  const bool pick_tiled = prefer_tiled_ && tiled_.usable;
-  o->fast_path = (period_.usable && !pick_tiled) ? 2 : (upsample_.usable && !pick_tiled) ? 3 : (tiled_.usable ? 1 : 0);
+  o->fast_path = period_.usable ? 2 : (slide_.usable ? 3 : 0);
   if (s < n_streams_) {
     o->last_sample = pos_[s].last;
     o->samp_frac_num = pos_[s].frac;
@@ -217,15 +208,12 @@ int Batch::process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_
       d_descs = dst;
     }
     hipError_t e;
-    if (mode_ == SPEEXHIP_MODE_FAST && period_.usable && !(prefer_tiled_ && tiled_.usable))
+    if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)
       e = launch_period(filter_, period_, d_period_rows_, channels_, descs, d_descs,
                         packed ? &pack : nullptr, n_streams_, stream);
-    else if (mode_ == SPEEXHIP_MODE_FAST && upsample_.usable && !(prefer_tiled_ && tiled_.usable))
-      e = launch_upsample(filter_, upsample_, d_upsample_rows_, channels_, descs, d_descs,
-                          packed ? &pack : nullptr, n_streams_, stream);
-    else if (mode_ == SPEEXHIP_MODE_FAST && tiled_.usable)
-      e = launch_tiled(filter_, tiled_, d_phase_rows_, channels_, descs, d_descs,
-                       packed ? &pack : nullptr, n_streams_, max_out, stream);
+    else if (mode_ == SPEEXHIP_MODE_FAST && slide_.usable)
+      e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, d_descs,
+                       packed ? &pack : nullptr, n_streams_, stream);
     else
       e = launch_exact(filter_, exact_geo_, d_table_, channels_, d_descs, packed ? &pack : nullptr,
                        n_streams_, max_out, stream);

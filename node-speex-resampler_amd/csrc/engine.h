@@ -53,13 +53,10 @@ class Batch {
   int hist_cur_ = 0;
 
   ExactGeometry exact_geo_;
-  TiledPlan tiled_;        // fast path (kernels_tiled.hip); tiled_.usable == false -> exact
-  float *d_phase_rows_ = nullptr;
   PeriodPlan period_;      // primary fast path (kernels_period.hip)
   float *d_period_rows_ = nullptr;
-  bool prefer_tiled_ = false;  // env SPEEXHIP_FAST_KERNEL=tiled
-  UpsamplePlan upsample_;  // integer-ratio up-sampling fast path (kernels_upsample.hip)
-  float *d_upsample_rows_ = nullptr;
+  SlidePlan slide_;        // small-ratio fast path (kernels_slide.hip); neither usable -> exact
+  float *d_slide_rows_ = nullptr;
 
   // descriptor transport for batches larger than kMaxPackedStreams
   static const int kRing = 32;

@@ -25,27 +25,6 @@ hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float
                         uint32_t channels, const StreamDesc *d_descs, const DescPack *pack,
                         uint32_t n_streams, uint32_t max_n_out, hipStream_t stream);
 
-// ---- fast tiled kernel (kernels_tiled.hip) -------------------------------------------------
-struct TiledPlan {          // per filter, fixed at init
-  bool usable = false;      // false: this configuration runs the exact kernel in FAST mode too
-  int r = 1, m = 1, ct = 1; // register tile: phases x periods x channels per lane
-  uint32_t groups = 0, cgroups = 0;
-  uint32_t row_len = 0, l4 = 0, table_f4 = 0, tail_frames = 0;
-  size_t table_bytes = 0, lds_budget = 0;
-};
-struct TiledLaunch {        // per call
-  uint32_t periods = 0, mgroups = 0, ksplit = 1, s4_per_slice = 0, threads = 0, blocks = 0;
-  uint32_t slice_f4 = 0, slice_pad_f4 = 0;
-  size_t lds_bytes = 0;
-};
-TiledPlan plan_tiled(const FilterSpec &f, uint32_t channels, size_t lds_budget);
-void build_phase_rows(const FilterSpec &f, const TiledPlan &t, std::vector<float> *rows);
-TiledLaunch tiled_geometry(const FilterSpec &f, const TiledPlan &t, uint32_t channels,
-                           uint32_t n_streams, uint32_t max_periods, uint32_t target_workgroups);
-hipError_t launch_tiled(const FilterSpec &f, const TiledPlan &t, const float *d_rows, uint32_t channels,
-                        const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                        uint32_t n_streams, uint32_t max_n_out, hipStream_t stream);
-
 // ---- primary fast kernel: period-lane mapping, taps in SGPRs (kernels_period.hip) ----------
 struct PeriodPlan {         // per filter, fixed at init
   bool usable = false;
@@ -60,16 +39,16 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
                          const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
                          uint32_t n_streams, hipStream_t stream);
 
-// ---- integer-ratio up-sampling fast kernel (kernels_upsample.hip): num == 1, den <= 6 -------
-struct UpsamplePlan {
+// ---- small-ratio fast kernel (kernels_slide.hip): den <= 6, num <= 4 -------------------------
+struct SlidePlan {
   bool usable = false;
   bool pair_ch = true;      // packed FMA over channel pairs (even channel count) or phase pairs
-  uint32_t p = 8, np = 1, cgroups = 1, row_stride = 0;
+  uint32_t p = 8, num = 1, np = 1, cgroups = 1, row_stride = 0, row_len = 0;
 };
-UpsamplePlan plan_upsample(const FilterSpec &f, uint32_t channels);
-void build_upsample_rows(const FilterSpec &f, const UpsamplePlan &t, std::vector<float> *rows);
-hipError_t launch_upsample(const FilterSpec &f, const UpsamplePlan &t, const float *d_rows, uint32_t channels,
-                           const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                           uint32_t n_streams, hipStream_t stream);
+SlidePlan plan_slide(const FilterSpec &f, uint32_t channels);
+void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float> *rows);
+hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
+                        const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                        uint32_t n_streams, hipStream_t stream);
 
 }  // namespace speexhip

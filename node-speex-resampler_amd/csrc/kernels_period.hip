@@ -1,6 +1,6 @@
 // kernels_period.hip -- the primary fast gfx950 FIR kernel ("period-lane" mapping).
 //
-// Same algebra as kernels_tiled.hip: with K = k_shift + k = m*den + r every output is
+// With K = k_shift + k = m*den + r (stream_plan.h) every output of every stream is
 //     Out[r, m, c] = sum_s Tp[r][s] * V[base + m*num + delta_{g*R} + s][c]
 // where Tp[r] are the effective taps of phase (r*num) mod den (the reference's four
 // interpolation accumulators collapsed, deps/speex/resample.c:438-558; the direct kernels

@@ -1,20 +1,22 @@
-// kernels_upsample.hip -- fast gfx950 kernel for integer-ratio up-sampling (num == 1, den <= 6):
-// 24k->48k, 16k->48k, 8k->48k, same-rate ... (BASELINE configs[2]; the reference picks
-// resampler_basic_direct_{single,double} for these, deps/speex/resample.c:331-435).  +-1 LSB.
+// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6, num <= 4):
+// integer up-sampling 24k->48k, 16k->48k, 8k->48k, same-rate, 2:1 / 3:1 / 4:1 decimation, 3:2,
+// 2:3 ... (BASELINE configs[2]; the reference picks resampler_basic_direct_* for
+// most of these, deps/speex/resample.c:331-435).  +-1 LSB.
 //
-// With num == 1 output K = m*den + r reads V[base + m + s] for s < taps: consecutive periods m
-// slide over the input by ONE frame.  So a lane that owns P consecutive periods needs, for U
-// tap steps, only P-1+U input frames for P*den*U multiply-adds:
-//   lane  = block of P consecutive periods (x one channel pair): P*den accumulator pairs, a
-//           register window of P-1+U frames re-read from LDS once per iteration;
+// Output K = m*den + r reads V[base + m*num + delta_r + s] for s < taps.  Consecutive periods m
+// slide over the input by only `num` frames, so a lane that owns P consecutive periods needs,
+// for U tap steps, just (P-1)*num + U input frames for P*den*U multiply-adds:
+//   lane  = block of P consecutive periods (x one channel pair): P*den accumulator pairs and a
+//           register window of (2P-1)*num frames re-read from LDS once per iteration
+//           (U = P*num steps, so the window advances exactly one LDS row per iteration);
 //   taps  = wave-uniform (every lane is at the same step): scalar loads -> SGPR operands of
-//           v_pk_fma_f32, U*den taps per iteration;
+//           v_pk_fma_f32, U*den taps per iteration; the rows of phase r are pre-shifted by
+//           delta_r = (r*num) div den so all phases of a period read the same sample per step;
 //   packing: even channel count -> one packed FMA = both channels of a frame (tap broadcast);
 //            odd  channel count -> one packed FMA = two phases of one sample (sample broadcast),
 //            den padded to even with a zero phase.
-//   LDS   = the tile's input as float in rows of P frames, one row per lane, row stride padded so
-//           that the 64 lanes of a wave hit distinct banks; iteration `it` of lane l reads rows
-//           l+it and l+it+1 (U == P, so the window advances exactly one row per iteration).
+//   LDS   = the tile's input as float in rows of P*num frames, one row per lane, row stride
+//           padded so that the 64 lanes of a wave hit distinct banks.
 //   out   = each lane owns P*den consecutive output frames: contiguous wide stores.
 #include <hip/hip_runtime.h>
 
@@ -48,10 +50,10 @@ __device__ __forceinline__ void fma_bcast_x(f32x2 &acc, const f32x2 &tap_pair, c
 }
 
 // PAIR_CH: true = channel pairs (NP = den accumulators per period), false = phase pairs (NP = ceil(den/2)).
-// P: periods per lane = tap steps per iteration.
-template <int P, int NP, bool PAIR_CH, bool PACKED>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void resample_upsample(
-    UpsampleParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
+// P: periods per lane; NUM: input frames per period; U = P*NUM tap steps per iteration.
+template <int P, int NUM, int NP, bool PAIR_CH, bool PACKED>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void resample_slide(
+    SlideParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
@@ -67,14 +69,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   if (m_lo >= m_total) return;
   const uint32_t m_cnt = min(tile_periods, m_total - m_lo);
 
-  // ---- stage: frames [f0, f0 + m_cnt + taps) of V, frame f -> row f / P, column (f % P) * C + c ----
+  // ---- stage: frames [f0, f0 + m_cnt*num + row_len) of V; frame f -> row f / (P*NUM), column ... ----
   {
     const int64_t hist_elems = static_cast<int64_t>(p.taps - 1) * C;
     const int64_t in_elems = static_cast<int64_t>(d.in_frames) * C;
-    const int64_t q0 = (static_cast<int64_t>(d.base_shift) + m_lo) * C - hist_elems;  // input-relative
-    const uint32_t frames = m_cnt + p.taps + P;  // + one row of slack for the last iteration
+    const int64_t q0 = (static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * NUM) * C - hist_elems;
+    const uint32_t frames = m_cnt * NUM + p.row_len + P * NUM;  // + one row of slack for the last iteration
     const uint32_t total = frames * C;
-    const uint32_t row_elems = P * C;
+    const uint32_t row_elems = P * NUM * C;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
       const uint32_t row = e / row_elems, col = e - row * row_elems;
       xs[row * p.row_stride + col] = rel_sample(d, q0 + e, hist_elems, in_elems);
@@ -96,19 +98,21 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
 #pragma unroll
     for (int r = 0; r < NP; r++) acc[pp][r] = f32x2{0.f, 0.f};
 
-  constexpr int TAPS_IT = PAIR_CH ? P * NP : P * NP * 2;  // tap floats per iteration
+  constexpr int U = P * NUM;                               // tap steps per iteration
+  constexpr int TAPS_IT = PAIR_CH ? U * NP : U * NP * 2;   // tap floats per iteration
   constexpr int TP = TAPS_IT / 2;                         // ... as SGPR pairs
   static_assert(TAPS_IT % 2 == 0, "tap floats per iteration must pair up");
   const float *__restrict__ trow = rows;  // wave-uniform, __restrict__ kernel argument -> s_load
-  const uint32_t n_it = (p.skip & 4u) ? 0 : p.taps / P;
+  const uint32_t n_it = (p.skip & 4u) ? 0 : p.row_len / U;
   for (uint32_t it = 0; it < n_it; it++, trow += TAPS_IT, xrow += p.row_stride) {
     f32x2 tp[TP];
 #pragma unroll
     for (int j = 0; j < TP; j++) tp[j] = *reinterpret_cast<const f32x2 *>(trow + 2 * j);
-    f32x2 xw[2 * P - 1];  // frames it*P .. it*P + 2P-2 of this lane's block
+    constexpr int W = (2 * P - 1) * NUM;  // frames it*U .. it*U + W-1 of this lane's block
+    f32x2 xw[W];
 #pragma unroll
-    for (int j = 0; j < 2 * P - 1; j++) {
-      const float *px = xrow + (j < P ? j * C : p.row_stride + (j - P) * C);
+    for (int j = 0; j < W; j++) {
+      const float *px = xrow + (j < U ? j * C : p.row_stride + (j - U) * C);
       if (PAIR_CH) {
         xw[j] = *reinterpret_cast<const f32x2 *>(px);
       } else {
@@ -117,16 +121,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
       }
     }
 #pragma unroll
-    for (int s = 0; s < P; s++)
+    for (int s = 0; s < U; s++)
 #pragma unroll
       for (int pp = 0; pp < P; pp++)
 #pragma unroll
         for (int r = 0; r < NP; r++) {
           if (PAIR_CH) {
             const int k = s * NP + r;
-            fma_bcast_tap(acc[pp][r], tp[k >> 1], xw[pp + s], (k & 1) != 0);
+            fma_bcast_tap(acc[pp][r], tp[k >> 1], xw[pp * NUM + s], (k & 1) != 0);
           } else {
-            fma_bcast_x(acc[pp][r], tp[s * NP + r], xw[pp + s]);
+            fma_bcast_x(acc[pp][r], tp[s * NP + r], xw[pp * NUM + s]);
           }
         }
   }
@@ -175,38 +179,60 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   }
 }
 
-template <int P, int NP, bool PAIR_CH>
-hipError_t launch_up(const UpsampleParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
+template <int P, int NUM, int NP, bool PAIR_CH>
+hipError_t launch_up(const SlideParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_upsample<P, NP, PAIR_CH, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_upsample<P, NP, PAIR_CH, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
   if (pack != nullptr)
-    hipLaunchKernelGGL((resample_upsample<P, NP, PAIR_CH, true>), grid, dim3(threads), lds_bytes, stream, p,
+    hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, true>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, nullptr, *pack);
   else
-    hipLaunchKernelGGL((resample_upsample<P, NP, PAIR_CH, false>), grid, dim3(threads), lds_bytes, stream, p,
+    hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, false>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, d_descs, empty);
   return hipGetLastError();
 }
 
 }  // namespace
 
-UpsamplePlan plan_upsample(const FilterSpec &f, uint32_t channels) {
-  UpsamplePlan t;
+namespace {
+struct SlideShape { uint32_t num, np; bool pair_ch; uint32_t p; };
+// the instantiated (num, accumulator pairs per period, packing) -> periods per lane.  Bounds kept:
+// tap floats per iteration <= 48, window (2P-1)*num <= 31 frames, P*np <= 24 accumulator pairs.
+const SlideShape kShapes[] = {
+    {1, 1, true, 8}, {1, 2, true, 8}, {1, 3, true, 8}, {1, 4, true, 4}, {1, 6, true, 4},
+    {1, 1, false, 8}, {1, 2, false, 8}, {1, 3, false, 4},
+    {2, 1, true, 8}, {2, 3, true, 4}, {2, 1, false, 8}, {2, 2, false, 4},
+    {3, 1, true, 4}, {3, 2, true, 4}, {3, 1, false, 4},
+    {4, 1, true, 4}, {4, 1, false, 4},
+};
+}  // namespace
+
+SlidePlan plan_slide(const FilterSpec &f, uint32_t channels) {
+  SlidePlan t;
   t.pair_ch = channels % 2 == 0;
   t.np = t.pair_ch ? f.den : (f.den + 1) / 2;
   t.cgroups = t.pair_ch ? channels / 2 : channels;
-  // accumulator pairs per lane P*NP <= 24 and tap floats per iteration <= 48
-  t.p = (t.pair_ch ? (f.den <= 3) : (t.np <= 2)) ? 8 : 4;
-  const uint32_t row_elems = t.p * channels;
+  t.num = f.num;
+  t.usable = false;
+  for (const SlideShape &sh : kShapes)
+    if (sh.num == f.num && sh.np == t.np && sh.pair_ch == t.pair_ch) {
+      t.p = sh.p;
+      t.usable = f.den <= 6 && t.cgroups <= 64;
+    }
+  if (!t.usable) return t;
+  const uint32_t steps = t.p * f.num;  // tap steps per iteration
+  const uint32_t dmax = static_cast<uint32_t>((static_cast<uint64_t>(f.den - 1) * f.num) / f.den);
+  t.row_len = (f.taps + dmax + steps - 1) / steps * steps;
+  const uint32_t row_elems = steps * channels;
   // row stride: distinct banks for the lanes of a wave (ds_read_b64: stride/2 odd; b32: stride odd)
   t.row_stride = row_elems;
   if (t.pair_ch) {
@@ -214,25 +240,27 @@ UpsamplePlan plan_upsample(const FilterSpec &f, uint32_t channels) {
   } else {
     if (t.row_stride % 2 == 0) t.row_stride += 1;
   }
-  t.usable = f.num == 1 && f.den <= 6 && f.den != 5 && f.taps % t.p == 0 && t.cgroups <= 64;
   return t;
 }
 
-void build_upsample_rows(const FilterSpec &f, const UpsamplePlan &t, std::vector<float> *rows) {
-  // [step][phase] (phase count padded to 2*np for phase pairs), + one iteration of zero padding
+void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float> *rows) {
+  // [step][phase] (phase count padded to 2*np for phase pairs), rows of phase r shifted by
+  // delta_r, + one iteration of zero padding
   const uint32_t width = t.pair_ch ? f.den : 2 * t.np;
-  rows->assign(static_cast<size_t>(f.taps + t.p) * width, 0.f);
+  rows->assign(static_cast<size_t>(t.row_len + t.p * f.num) * width, 0.f);
   std::vector<double> h(f.taps);
   for (uint32_t r = 0; r < f.den; r++) {
-    // num == 1: phase of row r is r, all rows start at the same input frame
-    phase_taps(f, r % f.den, h.data());
-    for (uint32_t s = 0; s < f.taps; s++) (*rows)[static_cast<size_t>(s) * width + r] = static_cast<float>(h[s]);
+    const uint32_t phase = static_cast<uint32_t>((static_cast<uint64_t>(r) * f.num) % f.den);
+    const uint32_t shift = static_cast<uint32_t>((static_cast<uint64_t>(r) * f.num) / f.den);
+    phase_taps(f, phase, h.data());
+    for (uint32_t j = 0; j < f.taps; j++)
+      (*rows)[static_cast<size_t>(j + shift) * width + r] = static_cast<float>(h[j]);
   }
 }
 
-hipError_t launch_upsample(const FilterSpec &f, const UpsamplePlan &t, const float *d_rows, uint32_t channels,
-                           const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                           uint32_t n_streams, hipStream_t stream) {
+hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
+                        const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                        uint32_t n_streams, hipStream_t stream) {
   uint32_t max_periods = 0;
   for (uint32_t s = 0; s < n_streams; s++) {
     if (h_descs[s].n_out == 0) continue;
@@ -245,10 +273,11 @@ hipError_t launch_upsample(const FilterSpec &f, const UpsamplePlan &t, const flo
   uint32_t waves = 16;
   while (waves > 2 && static_cast<uint64_t>(max_periods) * n_streams < 512ull * waves * blocks_per_wave * t.p)
     waves /= 2;
-  UpsampleParams p;
+  SlideParams p;
   p.rows = d_rows;
   p.den = f.den;
   p.taps = f.taps;
+  p.row_len = t.row_len;
   p.channels = channels;
   p.cgroups = t.cgroups;
   p.blocks_per_wave = blocks_per_wave;
@@ -258,22 +287,33 @@ hipError_t launch_upsample(const FilterSpec &f, const UpsamplePlan &t, const flo
   p.skip = skip_mask;
   const uint32_t tile_periods = p.blocks_per_tile * t.p;
   const uint32_t tiles = (max_periods + tile_periods - 1) / tile_periods;
-  // LDS: rows for tile_periods + taps + P frames
-  const size_t rows_needed = (tile_periods + f.taps + t.p + t.p - 1) / t.p + 2;
+  // LDS: one row per lane block, + the rows the last lane's window runs into
+  const uint32_t steps = t.p * f.num;
+  const size_t rows_needed = p.blocks_per_tile + t.row_len / steps + 2;
   const size_t lds = rows_needed * t.row_stride * 4;
   dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
   const uint32_t threads = waves * 64;
-#define SPEEXHIP_UP_CASE(PP, NPV, CHV) \
-  if (t.p == PP && t.np == NPV && t.pair_ch == CHV) return launch_up<PP, NPV, CHV>(p, d_descs, pack, grid, threads, lds, stream);
-  SPEEXHIP_UP_CASE(8, 1, true)
-  SPEEXHIP_UP_CASE(8, 2, true)
-  SPEEXHIP_UP_CASE(8, 3, true)
-  SPEEXHIP_UP_CASE(4, 4, true)
-  SPEEXHIP_UP_CASE(4, 6, true)
-  SPEEXHIP_UP_CASE(8, 1, false)
-  SPEEXHIP_UP_CASE(8, 2, false)
-  SPEEXHIP_UP_CASE(4, 3, false)
-#undef SPEEXHIP_UP_CASE
+#define SPEEXHIP_SLIDE_CASE(PP, NUMV, NPV, CHV)                           \
+  if (t.p == PP && t.num == NUMV && t.np == NPV && t.pair_ch == CHV)      \
+    return launch_up<PP, NUMV, NPV, CHV>(p, d_descs, pack, grid, threads, lds, stream);
+  SPEEXHIP_SLIDE_CASE(8, 1, 1, true)
+  SPEEXHIP_SLIDE_CASE(8, 1, 2, true)
+  SPEEXHIP_SLIDE_CASE(8, 1, 3, true)
+  SPEEXHIP_SLIDE_CASE(4, 1, 4, true)
+  SPEEXHIP_SLIDE_CASE(4, 1, 6, true)
+  SPEEXHIP_SLIDE_CASE(8, 1, 1, false)
+  SPEEXHIP_SLIDE_CASE(8, 1, 2, false)
+  SPEEXHIP_SLIDE_CASE(4, 1, 3, false)
+  SPEEXHIP_SLIDE_CASE(8, 2, 1, true)
+  SPEEXHIP_SLIDE_CASE(4, 2, 3, true)
+  SPEEXHIP_SLIDE_CASE(8, 2, 1, false)
+  SPEEXHIP_SLIDE_CASE(4, 2, 2, false)
+  SPEEXHIP_SLIDE_CASE(4, 3, 1, true)
+  SPEEXHIP_SLIDE_CASE(4, 3, 2, true)
+  SPEEXHIP_SLIDE_CASE(4, 3, 1, false)
+  SPEEXHIP_SLIDE_CASE(4, 4, 1, true)
+  SPEEXHIP_SLIDE_CASE(4, 4, 1, false)
+#undef SPEEXHIP_SLIDE_CASE
   return hipErrorInvalidValue;
 }
 

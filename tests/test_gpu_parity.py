@@ -263,12 +263,16 @@ def test_node_drop_in_harness():
     assert "ALL NODE TESTS PASSED" in res.stdout
 
 
-def test_integer_ratio_upsampling_kernel_variants():
-    """kernels_upsample.hip: every (den, channel parity, quality) instantiation -- channel-pair and
-    phase-pair packing, P = 8 and P = 4 -- in multi-call streams, vs the oracle."""
+def test_small_ratio_sliding_window_kernel_variants():
+    """kernels_slide.hip: every (num, den, channel parity) instantiation -- channel-pair and
+    phase-pair packing, P = 8 and P = 4, num = 1..4 -- in multi-call streams, vs the oracle."""
     cases = [(1, 24000, 48000, 10), (2, 24000, 48000, 10), (1, 16000, 48000, 5), (2, 16000, 48000, 7),
              (1, 8000, 48000, 8), (2, 8000, 48000, 3), (1, 12000, 48000, 9), (4, 11025, 44100, 4),
-             (1, 48000, 48000, 6), (2, 24000, 24000, 5), (3, 22050, 44100, 6), (6, 8000, 16000, 0)]
+             (1, 48000, 48000, 6), (2, 24000, 24000, 5), (3, 22050, 44100, 6), (6, 8000, 16000, 0),
+             # num > 1: 2:1, 3:1, 4:1 decimation, 3:2, 2:3
+             (2, 96000, 48000, 7), (1, 48000, 24000, 10), (2, 48000, 16000, 5), (1, 48000, 16000, 8),
+             (2, 48000, 12000, 4), (1, 32000, 8000, 6), (2, 48000, 32000, 7), (1, 48000, 32000, 3),
+             (2, 32000, 48000, 9), (1, 32000, 48000, 5)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
