@@ -325,3 +325,21 @@ def test_eight_channel_padded_window_and_odd_channel_counts():
             assert used == wu and r.position() == ref.position()
             assert_close(got, want, "multi-channel %s call %d" % ((ch, i, o, q), call))
         r.close()
+
+
+def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
+    """Ratios no fast kernel covers (den = 5, 6:1, filters too long for LDS) must still be right:
+    FAST mode falls back to the bit-exact kernel (fast_path == 0), staged in LDS or streaming
+    straight from L2 when the filter does not fit."""
+    for (ch, i, o, q, frames) in [(1, 48000, 8000, 5, 30000), (2, 8000, 40000, 4, 4000),
+                                  (1, 192000, 1000, 10, 120000), (2, 96000, 1500, 3, 90000)]:
+        ref = orc.Oracle(ch, i, o, q)
+        r = speexhip.Resampler(ch, i, o, q)
+        assert r.info()["fast_path"] == 0, (ch, i, o, q)
+        x = orc.lcg_pcm(frames * ch, 77).reshape(frames, ch)
+        for part in (x[: frames // 3], x[frames // 3:]):
+            got, used = r.process(part, 1 << 20)
+            want, wu = ref.process(part, 1 << 20)
+            assert used == wu and r.position() == ref.position()
+            assert np.array_equal(got, want), "exact fallback differs for %s" % ((ch, i, o, q),)
+        r.close()
