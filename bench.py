@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU (configs[4] uses 32)")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--io", default="int16", choices=["int16", "float"],
+                    help="sample type of the buffers: int16 = the BASELINE metric; float = the N2 entry point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
@@ -123,23 +125,28 @@ def main():
     # Synthetic input: LCG white noise, seed 12345 + global stream id.  To keep the
     # inputs in HBM rather than in the 256 MiB Infinity Cache, steps rotate over enough distinct
     # buffer pairs that one rotation exceeds ~600 MB of traffic.
-    in_bytes, out_bytes = S * F * ch * 2, S * cap * ch * 2
+    fio = args.io == "float"
+    es = 4 if fio else 2
+    in_bytes, out_bytes = S * F * ch * es, S * cap * ch * es
     nbuf = max(2, min(256, int(math.ceil(600e6 / (in_bytes + out_bytes)))))
     base = np.stack([lcg_pcm(F * ch, 12345 + rank * S + s).reshape(F, ch) for s in range(S)])
     d_base = torch.from_numpy(base).to(dev)
+    if fio:
+        d_base = d_base.to(torch.float32) / 32768.0
     d_in = [d_base] + [torch.roll(d_base, shifts=17 * i, dims=1).contiguous() for i in range(1, nbuf)]
-    d_out = [torch.zeros((S, cap, ch), dtype=torch.int16, device=dev) for _ in range(nbuf)]
+    d_out = [torch.zeros((S, cap, ch), dtype=torch.float32 if fio else torch.int16, device=dev) for _ in range(nbuf)]
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
 
     def step(i):
         b = i % nbuf
-        return batch.process_device(d_in[b].data_ptr(), F * ch, F, d_out[b].data_ptr(), cap * ch, cap, sp)
+        return batch.process_device(d_in[b].data_ptr(), F * ch, F, d_out[b].data_ptr(), cap * ch, cap, sp,
+                                    float_io=fio)
 
     # first chunk (outside the timed region); kept for the CPU leg's parity check
     used, made = step(0)
     torch.cuda.synchronize()
-    first_chunk = (d_out[0][0, : made[0]].cpu().numpy(), used[0], made[0]) if rank == 0 else None
+    first_chunk = (d_out[0][0, : made[0]].cpu().numpy(), used[0], made[0]) if rank == 0 and not fio else None
 
     for i in range(args.warmup):
         step(i + 1)
@@ -163,14 +170,14 @@ def main():
     elapsed_max = dist_util.reduce_scalar(elapsed, "max", dev)
     total_in_samples = dist_util.reduce_int(args.steps * S * F * ch, dev)
     total_out_samples = dist_util.reduce_int(produced * ch, dev)
-    checksum = dist_util.reduce_int(int(d_out[0].to(torch.int64).sum().item()), dev)
+    checksum = dist_util.reduce_int(int((d_out[0] * (32768.0 if fio else 1)).to(torch.int64).sum().item()), dev)
 
     if rank == 0:
         value = total_in_samples / elapsed_max / 1e6
         # dominant kernel = the one launch per step; algorithmic bytes per launch:
         # 2*ch*consumed read + 2*ch*produced written, per stream, per call
         launch_ms = gpu_ms / args.steps
-        alg_bytes = (consumed + produced) * ch * 2 / args.steps
+        alg_bytes = (consumed + produced) * ch * es / args.steps
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         flops = 2.0 * info["filt_len"] * produced * ch / args.steps  # minimal form, 2*N per output
         tfl = flops / (launch_ms * 1e-3) / 1e12
@@ -191,7 +198,7 @@ def main():
             "config": {"workload": "%s per GPU x %d stream(s): %d->%d Hz, %dch int16, "
                                    "q=%d, %d-frame chunk per stream per step" % (CONFIG_LABEL[args.config], S, fi,
                                                                                  fo, ch, q, F),
-                       "streams_per_gpu": S, "frames_per_chunk": F, "mode": args.mode,
+                       "streams_per_gpu": S, "frames_per_chunk": F, "mode": args.mode, "io": args.io,
                        "kernel": speexhip.KERNEL_NAMES[info["kernel"]], "fast_path": info["fast_path"],
                        "filt_len": info["filt_len"], "parallelism": "streams sharded, %d rank(s)" % world},
             "output_msamples_per_s": round(total_out_samples / elapsed_max / 1e6, 1),

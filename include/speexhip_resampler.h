@@ -76,6 +76,14 @@ SPEEXHIP_API int speexhip_resampler_process_interleaved_int(SpeexHipResamplerSta
                                                             const int16_t *in, uint32_t *in_len,
                                                             int16_t *out, uint32_t *out_len);
 
+/* Float I/O entry point: replaces speex_resampler_process_interleaved_float
+ * (speex_resampler.h:202-206, resample.c:1038-1059 -> :927-963).  Same stream state as the
+ * int16 call (int and float calls may be mixed); samples are not rounded or saturated, and a
+ * 160-frame input block is not limited to 1024 outputs (resample.c:943 vs :982-991). */
+SPEEXHIP_API int speexhip_resampler_process_interleaved_float(SpeexHipResamplerState *st,
+                                                              const float *in, uint32_t *in_len,
+                                                              float *out, uint32_t *out_len);
+
 /* Replaces speex_resampler_get_rate (speex_resampler.h:237-239, resample.c:1089). */
 SPEEXHIP_API void speexhip_resampler_get_rate(SpeexHipResamplerState *st, uint32_t *in_rate,
                                               uint32_t *out_rate);
@@ -99,6 +107,12 @@ SPEEXHIP_API int speexhip_resampler_process_interleaved_int_device(SpeexHipResam
                                                                    uint32_t *in_len, int16_t *d_out,
                                                                    uint32_t *out_len,
                                                                    void *hip_stream);
+
+SPEEXHIP_API int speexhip_resampler_process_interleaved_float_device(SpeexHipResamplerState *st,
+                                                                     const float *d_in,
+                                                                     uint32_t *in_len, float *d_out,
+                                                                     uint32_t *out_len,
+                                                                     void *hip_stream);
 
 /* SPEEXHIP_MODE_FAST (default; +-1 LSB) or SPEEXHIP_MODE_EXACT (bit-identical arithmetic
  * order, slower).  The environment variable SPEEXHIP_MODE=exact|fast sets the initial mode. */
@@ -124,9 +138,10 @@ typedef struct SpeexHipInfo {
 
 SPEEXHIP_API int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info);
 
-/* Copies the last filt_len-1 consumed frames (interleaved s16, what the next call's first
- * outputs are computed from; resample.c:898-899) to the host.  dst holds (filt_len-1)*ch. */
-SPEEXHIP_API int speexhip_resampler_get_history(SpeexHipResamplerState *st, int16_t *dst);
+/* Copies the last filt_len-1 consumed frames (interleaved float, the reference's `mem`: what
+ * the next call's first outputs are computed from; resample.c:898-899) to the host.  dst holds
+ * (filt_len-1)*ch floats. */
+SPEEXHIP_API int speexhip_resampler_get_history(SpeexHipResamplerState *st, float *dst);
 
 /* Batched streams: n_streams independent resamplers with one shared (rates, quality,
  * channels) filter, processed by ONE launch per call.  Device pointers; stream s reads
@@ -142,6 +157,10 @@ SPEEXHIP_API int speexhip_batch_get_info(SpeexHipBatch *b, uint32_t stream, Spee
 SPEEXHIP_API int speexhip_batch_process_interleaved_int_device(
     SpeexHipBatch *b, const int16_t *d_in, uint64_t in_stream_stride, uint32_t *in_len,
     int16_t *d_out, uint64_t out_stream_stride, uint32_t *out_len, void *hip_stream);
+
+SPEEXHIP_API int speexhip_batch_process_interleaved_float_device(
+    SpeexHipBatch *b, const float *d_in, uint64_t in_stream_stride, uint32_t *in_len, float *d_out,
+    uint64_t out_stream_stride, uint32_t *out_len, void *hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Host-only pieces of the path, callable without a GPU (used by the CPU test-suite).

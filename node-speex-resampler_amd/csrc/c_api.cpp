@@ -38,15 +38,39 @@ int speexhip_resampler_process_interleaved_int(SpeexHipResamplerState *st, const
                                                uint32_t *in_len, int16_t *out, uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
     return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_host(in, in_len, out, out_len);
+  return st->batch->process_host(in, in_len, out, out_len, false);
 }
 
 int speexhip_resampler_process_interleaved_int_device(SpeexHipResamplerState *st, const int16_t *d_in,
                                                       uint32_t *in_len, int16_t *d_out,
                                                       uint32_t *out_len, void *hip_stream) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_device(d_in, 0, in_len, d_out, 0, out_len,
+  return st->batch->process_device(d_in, 0, in_len, d_out, 0, out_len, false,
                                    static_cast<hipStream_t>(hip_stream));
+}
+
+int speexhip_resampler_process_interleaved_float(SpeexHipResamplerState *st, const float *in,
+                                                 uint32_t *in_len, float *out, uint32_t *out_len) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
+    return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->process_host(in, in_len, out, out_len, true);
+}
+
+int speexhip_resampler_process_interleaved_float_device(SpeexHipResamplerState *st, const float *d_in,
+                                                        uint32_t *in_len, float *d_out, uint32_t *out_len,
+                                                        void *hip_stream) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->process_device(d_in, 0, in_len, d_out, 0, out_len, true,
+                                   static_cast<hipStream_t>(hip_stream));
+}
+
+int speexhip_batch_process_interleaved_float_device(SpeexHipBatch *b, const float *d_in,
+                                                    uint64_t in_stream_stride, uint32_t *in_len, float *d_out,
+                                                    uint64_t out_stream_stride, uint32_t *out_len,
+                                                    void *hip_stream) {
+  if (b == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return b->batch->process_device(d_in, in_stream_stride, in_len, d_out, out_stream_stride, out_len, true,
+                                  static_cast<hipStream_t>(hip_stream));
 }
 
 void speexhip_resampler_get_rate(SpeexHipResamplerState *st, uint32_t *in_rate, uint32_t *out_rate) {
@@ -76,7 +100,7 @@ int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info) 
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-int speexhip_resampler_get_history(SpeexHipResamplerState *st, int16_t *dst) {
+int speexhip_resampler_get_history(SpeexHipResamplerState *st, float *dst) {
   if (st == nullptr || dst == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
   return st->batch->history(0, dst);
 }
@@ -114,7 +138,7 @@ int speexhip_batch_process_interleaved_int_device(SpeexHipBatch *b, const int16_
                                                   int16_t *d_out, uint64_t out_stream_stride,
                                                   uint32_t *out_len, void *hip_stream) {
   if (b == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return b->batch->process_device(d_in, in_stream_stride, in_len, d_out, out_stream_stride, out_len,
+  return b->batch->process_device(d_in, in_stream_stride, in_len, d_out, out_stream_stride, out_len, false,
                                   static_cast<hipStream_t>(hip_stream));
 }
 

@@ -8,10 +8,11 @@ namespace speexhip {
 // sequence the FIR windows index (history = the last taps-1 consumed frames, zeros at start:
 // reference resample.c:721-725, 898-899).
 struct StreamDesc {
-  const int16_t *in;    // interleaved s16, in_frames frames (device); NULL = silence
-  const int16_t *hist;  // (taps-1) frames, interleaved (device)
-  int16_t *out;         // interleaved s16, room for n_out frames (device)
-  int16_t *hist_next;   // where this call leaves the next call's history
+  const void *in;       // interleaved s16 or f32 (the call's sample type), in_frames frames
+                        // (device); NULL = silence
+  const float *hist;    // (taps-1) frames, interleaved, always float like the reference's `mem`
+  void *out;            // interleaved s16 or f32, room for n_out frames (device)
+  float *hist_next;     // where this call leaves the next call's history
   uint32_t in_frames;
   uint32_t n_out;       // frames to produce (host planner)
   uint32_t consumed;    // input frames entering the history

@@ -72,7 +72,7 @@ int Batch::setup() {
   HIP_TRY(hipMemcpy(d_table_, filter_.table.data(), sizeof(float) * filter_.table_len,
                     hipMemcpyHostToDevice));
   hist_elems_ = static_cast<size_t>(filter_.taps - 1) * channels_;
-  const size_t hist_bytes = std::max<size_t>(hist_elems_ * n_streams_ * sizeof(int16_t), 16);
+  const size_t hist_bytes = std::max<size_t>(hist_elems_ * n_streams_ * sizeof(float), 16);
   for (int i = 0; i < 2; i++) {
     HIP_TRY(hipMalloc(&d_hist_[i], hist_bytes));
     HIP_TRY(hipMemset(d_hist_[i], 0, hist_bytes));  // resample.c:721-725: history starts silent
@@ -149,17 +149,21 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
   o->device = device_;
 }
 
-int Batch::history(uint32_t s, int16_t *dst) {
+int Batch::history(uint32_t s, float *dst) {
   if (s >= n_streams_) return SPEEXHIP_ERR_INVALID_ARG;
   HIP_TRY(hipDeviceSynchronize());
   if (hist_elems_)
-    HIP_TRY(hipMemcpy(dst, d_hist_[hist_cur_] + s * hist_elems_, hist_elems_ * sizeof(int16_t),
+    HIP_TRY(hipMemcpy(dst, d_hist_[hist_cur_] + s * hist_elems_, hist_elems_ * sizeof(float),
                       hipMemcpyDeviceToHost));
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-int Batch::process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_len, int16_t *d_out,
-                          uint64_t out_stride, uint32_t *out_len, hipStream_t stream) {
+int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len, void *d_out,
+                          uint64_t out_stride, uint32_t *out_len, bool float_io, hipStream_t stream) {
+  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
+  // the int16 entry point emits at most 1024 outputs per 160-frame block (its stack buffer,
+  // resample.c:982-991); the float entry point has no such cap (resample.c:943)
+  const uint32_t block_out = float_io ? 0xffffffffu : kBlockOut;
   const bool packed = n_streams_ <= static_cast<uint32_t>(kMaxPackedStreams);
   DescPack pack;
   StreamDesc *descs = pack.d;
@@ -180,12 +184,12 @@ int Batch::process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_
   bool any_work = false;
   std::vector<CallPlan> plans(n_streams_);
   for (uint32_t s = 0; s < n_streams_; s++) {
-    const CallPlan plan = plan_call(filter_.num, filter_.den, in_len[s], out_len[s], pos_[s]);
+    const CallPlan plan = plan_call(filter_.num, filter_.den, in_len[s], out_len[s], pos_[s], block_out);
     plans[s] = plan;
     StreamDesc &d = descs[s];
-    d.in = d_in ? d_in + s * in_stride : nullptr;
+    d.in = d_in ? static_cast<const char *>(d_in) + s * in_stride * es : nullptr;
     d.hist = d_hist_[hist_cur_] + s * hist_elems_;
-    d.out = d_out + s * out_stride;
+    d.out = static_cast<char *>(d_out) + s * out_stride * es;
     d.hist_next = d_hist_[hist_cur_ ^ 1] + s * hist_elems_;
     d.in_frames = in_len[s];
     d.n_out = plan.produced;
@@ -210,13 +214,13 @@ int Batch::process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_
     hipError_t e;
     if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)
       e = launch_period(filter_, period_, d_period_rows_, channels_, descs, d_descs,
-                        packed ? &pack : nullptr, n_streams_, stream);
+                        packed ? &pack : nullptr, n_streams_, float_io, stream);
     else if (mode_ == SPEEXHIP_MODE_FAST && slide_.usable)
       e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, d_descs,
-                       packed ? &pack : nullptr, n_streams_, stream);
+                       packed ? &pack : nullptr, n_streams_, float_io, stream);
     else
       e = launch_exact(filter_, exact_geo_, d_table_, channels_, d_descs, packed ? &pack : nullptr,
-                       n_streams_, max_out, stream);
+                       n_streams_, max_out, float_io, stream);
     if (hip_failed(e, "kernel launch")) return SPEEXHIP_ERR_DEVICE;
     if (!packed) {
       HIP_TRY(hipEventRecord(ring_done_[slot], stream));
@@ -232,58 +236,57 @@ int Batch::process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-int Batch::ensure_stage(size_t in_elems, size_t out_elems) {
+int Batch::ensure_stage(size_t in_bytes, size_t out_bytes) {
   if (own_stream_ == nullptr) HIP_TRY(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
-  if (in_elems > stage_in_cap_) {  // grow-only, like the wrapper's heap buffers (src/index.ts:71-87)
+  if (in_bytes > stage_in_cap_) {  // grow-only, like the wrapper's heap buffers (src/index.ts:71-87)
     (void)hipFree(d_stage_in_);
     if (h_pin_in_) (void)hipHostFree(h_pin_in_);
     d_stage_in_ = nullptr;
     h_pin_in_ = nullptr;
     stage_in_cap_ = 0;
-    const size_t cap = std::max<size_t>(in_elems + in_elems / 4, 4096);
-    HIP_TRY(hipMalloc(&d_stage_in_, cap * sizeof(int16_t)));
-    HIP_TRY(hipHostMalloc(&h_pin_in_, cap * sizeof(int16_t), hipHostMallocDefault));
+    const size_t cap = std::max<size_t>(in_bytes + in_bytes / 4, 8192);
+    HIP_TRY(hipMalloc(&d_stage_in_, cap));
+    HIP_TRY(hipHostMalloc(&h_pin_in_, cap, hipHostMallocDefault));
     stage_in_cap_ = cap;
   }
-  if (out_elems > stage_out_cap_) {
+  if (out_bytes > stage_out_cap_) {
     (void)hipFree(d_stage_out_);
     if (h_pin_out_) (void)hipHostFree(h_pin_out_);
     d_stage_out_ = nullptr;
     h_pin_out_ = nullptr;
     stage_out_cap_ = 0;
-    const size_t cap = std::max<size_t>(out_elems + out_elems / 4, 4096);
-    HIP_TRY(hipMalloc(&d_stage_out_, cap * sizeof(int16_t)));
-    HIP_TRY(hipHostMalloc(&h_pin_out_, cap * sizeof(int16_t), hipHostMallocDefault));
+    const size_t cap = std::max<size_t>(out_bytes + out_bytes / 4, 8192);
+    HIP_TRY(hipMalloc(&d_stage_out_, cap));
+    HIP_TRY(hipHostMalloc(&h_pin_out_, cap, hipHostMallocDefault));
     stage_out_cap_ = cap;
   }
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-int Batch::process_host(const int16_t *in, uint32_t *in_len, int16_t *out, uint32_t *out_len) {
+int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io) {
   if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
   HIP_TRY(hipSetDevice(device_));
+  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
   const uint32_t frames = *in_len;
   // only as many output frames as this call can produce need a device buffer
   const uint32_t will_make =
       produced_closed_form(filter_.num, filter_.den, frames, *out_len, pos_[0]);
-  const size_t in_elems = static_cast<size_t>(frames) * channels_;
-  const size_t out_elems = static_cast<size_t>(will_make) * channels_;
-  int rc = ensure_stage(in_elems, out_elems);
+  const size_t in_bytes = static_cast<size_t>(frames) * channels_ * es;
+  const size_t out_bytes = static_cast<size_t>(will_make) * channels_ * es;
+  int rc = ensure_stage(in_bytes, out_bytes);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  if (in != nullptr && in_elems != 0) {
-    std::memcpy(h_pin_in_, in, in_elems * sizeof(int16_t));
-    HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, in_elems * sizeof(int16_t), hipMemcpyHostToDevice,
-                           own_stream_));
+  if (in != nullptr && in_bytes != 0) {
+    std::memcpy(h_pin_in_, in, in_bytes);
+    HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, in_bytes, hipMemcpyHostToDevice, own_stream_));
   }
-  rc = process_device(in != nullptr ? d_stage_in_ : nullptr, 0, in_len, d_stage_out_, 0, out_len,
+  rc = process_device(in != nullptr ? d_stage_in_ : nullptr, 0, in_len, d_stage_out_, 0, out_len, float_io,
                       own_stream_);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  const size_t made = static_cast<size_t>(*out_len) * channels_;
+  const size_t made = static_cast<size_t>(*out_len) * channels_ * es;
   if (made != 0)
-    HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, made * sizeof(int16_t), hipMemcpyDeviceToHost,
-                           own_stream_));
+    HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, made, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
-  if (made != 0) std::memcpy(out, h_pin_out_, made * sizeof(int16_t));
+  if (made != 0) std::memcpy(out, h_pin_out_, made);
   return SPEEXHIP_ERR_SUCCESS;
 }
 

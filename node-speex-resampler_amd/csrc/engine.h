@@ -25,21 +25,23 @@ class Batch {
   ~Batch();
 
   // Device-resident call for all streams; asynchronous on `stream`.
-  int process_device(const int16_t *d_in, uint64_t in_stride, uint32_t *in_len, int16_t *d_out,
-                     uint64_t out_stride, uint32_t *out_len, hipStream_t stream);
+  // float_io selects the sample type of in/out: int16 (process_interleaved_int) or float
+  // (process_interleaved_float); strides are in samples of that type.
+  int process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len, void *d_out,
+                     uint64_t out_stride, uint32_t *out_len, bool float_io, hipStream_t stream);
   // Host-buffer call for a single-stream batch; synchronous (H2D, kernels, D2H).
-  int process_host(const int16_t *in, uint32_t *in_len, int16_t *out, uint32_t *out_len);
+  int process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io);
 
   int set_mode(int mode);
   void info(uint32_t stream, SpeexHipInfo *out) const;
-  int history(uint32_t stream, int16_t *dst);
+  int history(uint32_t stream, float *dst);
   const FilterSpec &filter() const { return filter_; }
   uint32_t n_streams() const { return n_streams_; }
 
  private:
   Batch() = default;
   int setup();
-  int ensure_stage(size_t in_elems, size_t out_elems);
+  int ensure_stage(size_t in_bytes, size_t out_bytes);
 
   FilterSpec filter_;
   uint32_t n_streams_ = 0, channels_ = 0;
@@ -48,7 +50,7 @@ class Batch {
   std::vector<StreamPos> pos_;
 
   float *d_table_ = nullptr;
-  int16_t *d_hist_[2] = {nullptr, nullptr};
+  float *d_hist_[2] = {nullptr, nullptr};  // float, like the reference's `mem`
   size_t hist_elems_ = 0;  // per stream: (taps-1)*channels
   int hist_cur_ = 0;
 
@@ -68,9 +70,9 @@ class Batch {
 
   // host-buffer path (single stream)
   hipStream_t own_stream_ = nullptr;
-  int16_t *d_stage_in_ = nullptr, *d_stage_out_ = nullptr;
-  int16_t *h_pin_in_ = nullptr, *h_pin_out_ = nullptr;
-  size_t stage_in_cap_ = 0, stage_out_cap_ = 0;
+  char *d_stage_in_ = nullptr, *d_stage_out_ = nullptr;
+  char *h_pin_in_ = nullptr, *h_pin_out_ = nullptr;
+  size_t stage_in_cap_ = 0, stage_out_cap_ = 0;  // bytes
 };
 
 }  // namespace speexhip

@@ -23,7 +23,7 @@ struct ExactGeometry {
 ExactGeometry exact_geometry(const FilterSpec &f, uint32_t channels, size_t lds_budget);
 hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float *d_table,
                         uint32_t channels, const StreamDesc *d_descs, const DescPack *pack,
-                        uint32_t n_streams, uint32_t max_n_out, hipStream_t stream);
+                        uint32_t n_streams, uint32_t max_n_out, bool float_io, hipStream_t stream);
 
 // ---- primary fast kernel: period-lane mapping, taps in SGPRs (kernels_period.hip) ----------
 struct PeriodPlan {         // per filter, fixed at init
@@ -37,7 +37,7 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
 void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<float> *rows);
 hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
                          const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                         uint32_t n_streams, hipStream_t stream);
+                         uint32_t n_streams, bool float_io, hipStream_t stream);
 
 // ---- small-ratio fast kernel (kernels_slide.hip): den <= 6, num <= 4 -------------------------
 struct SlidePlan {
@@ -49,6 +49,6 @@ SlidePlan plan_slide(const FilterSpec &f, uint32_t channels);
 void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float> *rows);
 hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
                         const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                        uint32_t n_streams, hipStream_t stream);
+                        uint32_t n_streams, bool float_io, hipStream_t stream);
 
 }  // namespace speexhip

@@ -20,6 +20,7 @@
 
 #include <cstring>
 
+#include "device_helpers.h"
 #include "device_types.h"
 #include "filter_design.h"
 #include "kernels.h"
@@ -29,12 +30,14 @@
 namespace speexhip {
 namespace {
 
+// V = history ++ input at V-frame v, channel c (history is float, the input has the call's type T)
+template <typename T>
 __device__ __forceinline__ float virtual_sample(const StreamDesc &d, uint32_t hist_frames,
                                                 uint32_t channels, int64_t v, uint32_t c) {
-  if (v < static_cast<int64_t>(hist_frames)) return static_cast<float>(d.hist[v * channels + c]);
+  if (v < static_cast<int64_t>(hist_frames)) return hist_ptr(d)[v * channels + c];
   v -= hist_frames;
   if (d.in == nullptr || v >= static_cast<int64_t>(d.in_frames)) return 0.f;
-  return static_cast<float>(d.in[v * channels + c]);
+  return static_cast<float>(in_ptr<T>(d)[v * channels + c]);
 }
 
 // reference arch.h:208-209 -- the add and the floor are double
@@ -52,27 +55,9 @@ __device__ __forceinline__ void cubic_weights(float f, float w[4]) {
   w[2] = static_cast<float>(1. - w[0] - w[1] - w[3]);
 }
 
-// The next call's history: the last taps-1 frames of (history ++ input[0..consumed)),
-// reference resample.c:898-899 applied over the whole call.
-__device__ void write_next_history(const ExactParams &p, const StreamDesc &d) {
-  const uint32_t hist_frames = p.taps - 1;
-  const uint32_t total = hist_frames * p.channels;
-  for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
-    const uint32_t h = i / p.channels, c = i - h * p.channels;
-    const int64_t v = static_cast<int64_t>(d.consumed) + h;
-    int16_t s;
-    if (v < static_cast<int64_t>(hist_frames)) {
-      s = d.hist[v * p.channels + c];
-    } else {
-      const int64_t f = v - hist_frames;
-      s = (d.in != nullptr && f < static_cast<int64_t>(d.in_frames)) ? d.in[f * p.channels + c]
-                                                                      : static_cast<int16_t>(0);
-    }
-    d.hist_next[i] = s;
-  }
-}
-
-template <int KIND, int CT, bool STAGED, bool PACKED>
+// T = sample type of the call: int16_t (round + saturate on the way out, resample.c:1018-1022)
+// or float (the FIR value as is, resample.c:927-963).
+template <int KIND, int CT, bool STAGED, bool PACKED, typename T>
 __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const StreamDesc *streams,
                                                       DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -81,7 +66,7 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
   const uint32_t hist_frames = p.taps - 1;
 
   if (blockIdx.x == gridDim.x - 1) {  // one extra workgroup per stream rolls the history
-    if (blockIdx.z == 0) write_next_history(p, d);
+    if (blockIdx.z == 0) roll_history<T>(p.taps, p.channels, d);
     return;
   }
   const uint32_t k_first = blockIdx.x * p.outs_per_block;
@@ -106,7 +91,7 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
     for (uint32_t i = threadIdx.x; i < span * CT; i += blockDim.x) {
       const uint32_t f = i / CT, ct = i - f * CT;
       const uint32_t c = c_first + ct;
-      xs_lds[i] = c < C ? virtual_sample(d, hist_frames, C, base + f, c) : 0.f;
+      xs_lds[i] = c < C ? virtual_sample<T>(d, hist_frames, C, base + f, c) : 0.f;
     }
     __syncthreads();
     tab = tab_lds;
@@ -124,7 +109,7 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
   auto sample = [&](int j, int ct) -> float {
     if (STAGED) return xs[(rel + j) * CT + ct];
     const uint32_t c = c_first + ct;
-    return c < C ? virtual_sample(d, hist_frames, C, pos + j, c) : 0.f;
+    return c < C ? virtual_sample<T>(d, hist_frames, C, pos + j, c) : 0.f;
   };
 
   float y[CT];
@@ -208,25 +193,32 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
     }
   }
 
-  int16_t *o = d.out + static_cast<size_t>(k) * C + c_first;
-  if (CT == 2 && c_first + 1 < C && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
-    // both channels of an even-channel frame: one aligned 32-bit store
-    const uint32_t packed = static_cast<uint16_t>(word2int(y[0])) |
-                            (static_cast<uint32_t>(static_cast<uint16_t>(word2int(y[CT - 1]))) << 16);
-    *reinterpret_cast<uint32_t *>(o) = packed;
-  } else {
+  if constexpr (sizeof(T) == 4) {  // float I/O: no rounding
+    G<float> *o = out_ptr<float>(d) + static_cast<size_t>(k) * C + c_first;
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
-      if (c_first + ct < C) o[ct] = word2int(y[ct]);
+      if (c_first + ct < C) o[ct] = y[ct];
+  } else {
+    G<int16_t> *o = out_ptr<int16_t>(d) + static_cast<size_t>(k) * C + c_first;
+    if (CT == 2 && c_first + 1 < C && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+      // both channels of an even-channel frame: one aligned 32-bit store
+      const uint32_t packed = static_cast<uint16_t>(word2int(y[0])) |
+                              (static_cast<uint32_t>(static_cast<uint16_t>(word2int(y[CT - 1]))) << 16);
+      *(g_u32 *)o = packed;
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < CT; ct++)
+        if (c_first + ct < C) o[ct] = word2int(y[ct]);
+    }
   }
 }
 
-template <int KIND, int CT, bool STAGED>
+template <int KIND, int CT, bool STAGED, typename T>
 hipError_t launch_k(const ExactParams &p, const StreamDesc *d_descs, const DescPack *pack,
                     dim3 grid, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack != nullptr) {
-    auto kern = resample_exact<KIND, CT, STAGED, true>;
+    auto kern = resample_exact<KIND, CT, STAGED, true, T>;
     static bool lds_opt_in = false;  // once per kernel: allow the full 160 KiB of dynamic LDS
     if (!lds_opt_in) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -235,7 +227,7 @@ hipError_t launch_k(const ExactParams &p, const StreamDesc *d_descs, const DescP
     }
     hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, nullptr, *pack);
   } else {
-    auto kern = resample_exact<KIND, CT, STAGED, false>;
+    auto kern = resample_exact<KIND, CT, STAGED, false, T>;
     static bool lds_opt_in = false;  // once per kernel: allow the full 160 KiB of dynamic LDS
     if (!lds_opt_in) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -248,14 +240,26 @@ hipError_t launch_k(const ExactParams &p, const StreamDesc *d_descs, const DescP
   return hipGetLastError();
 }
 
-template <int KIND>
+template <int KIND, typename T>
 hipError_t launch_kind(const ExactParams &p, const StreamDesc *d, const DescPack *pack, int ct,
                        bool staged, dim3 grid, size_t lds, hipStream_t s) {
   if (ct == 2)
-    return staged ? launch_k<KIND, 2, true>(p, d, pack, grid, lds, s)
-                  : launch_k<KIND, 2, false>(p, d, pack, grid, 0, s);
-  return staged ? launch_k<KIND, 1, true>(p, d, pack, grid, lds, s)
-                : launch_k<KIND, 1, false>(p, d, pack, grid, 0, s);
+    return staged ? launch_k<KIND, 2, true, T>(p, d, pack, grid, lds, s)
+                  : launch_k<KIND, 2, false, T>(p, d, pack, grid, 0, s);
+  return staged ? launch_k<KIND, 1, true, T>(p, d, pack, grid, lds, s)
+                : launch_k<KIND, 1, false, T>(p, d, pack, grid, 0, s);
+}
+
+template <typename T>
+hipError_t launch_typed(const FilterSpec &f, const ExactParams &p, const StreamDesc *d, const DescPack *pack,
+                        const ExactGeometry &g, dim3 grid, hipStream_t s) {
+  switch (f.kind) {
+    case kDirectSingle: return launch_kind<kDirectSingle, T>(p, d, pack, g.ct, g.staged, grid, g.lds_bytes, s);
+    case kDirectDouble: return launch_kind<kDirectDouble, T>(p, d, pack, g.ct, g.staged, grid, g.lds_bytes, s);
+    case kInterpolateSingle:
+      return launch_kind<kInterpolateSingle, T>(p, d, pack, g.ct, g.staged, grid, g.lds_bytes, s);
+    default: return launch_kind<kInterpolateDouble, T>(p, d, pack, g.ct, g.staged, grid, g.lds_bytes, s);
+  }
 }
 
 }  // namespace
@@ -285,7 +289,7 @@ ExactGeometry exact_geometry(const FilterSpec &f, uint32_t channels, size_t lds_
 
 hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float *d_table,
                         uint32_t channels, const StreamDesc *d_descs, const DescPack *pack,
-                        uint32_t n_streams, uint32_t max_n_out, hipStream_t stream) {
+                        uint32_t n_streams, uint32_t max_n_out, bool float_io, hipStream_t stream) {
   ExactParams p;
   p.table = d_table;
   p.table_len = f.table_len;
@@ -298,16 +302,8 @@ hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float
   p.span_cap = g.span_cap;
   const uint32_t blocks = (max_n_out + g.outs_per_block - 1) / g.outs_per_block;
   dim3 grid(blocks + 1, n_streams, g.channel_groups);
-  switch (f.kind) {
-    case kDirectSingle:
-      return launch_kind<kDirectSingle>(p, d_descs, pack, g.ct, g.staged, grid, g.lds_bytes, stream);
-    case kDirectDouble:
-      return launch_kind<kDirectDouble>(p, d_descs, pack, g.ct, g.staged, grid, g.lds_bytes, stream);
-    case kInterpolateSingle:
-      return launch_kind<kInterpolateSingle>(p, d_descs, pack, g.ct, g.staged, grid, g.lds_bytes, stream);
-    default:
-      return launch_kind<kInterpolateDouble>(p, d_descs, pack, g.ct, g.staged, grid, g.lds_bytes, stream);
-  }
+  return float_io ? launch_typed<float>(f, p, d_descs, pack, g, grid, stream)
+                  : launch_typed<int16_t>(f, p, d_descs, pack, g, grid, stream);
 }
 
 }  // namespace speexhip

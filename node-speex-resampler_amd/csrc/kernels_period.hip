@@ -40,6 +40,7 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef __attribute__((address_space(1))) u32x4_a4 g_u32x4_a4;
 typedef __attribute__((address_space(1))) u32x2_a4 g_u32x2_a4;
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // acc += tap * x on both halves, the tap being element HI of a wave-uniform pair held in SGPRs.
 // Written as one instruction so that the odd element is selected in place with op_sel: left to
@@ -54,7 +55,7 @@ __device__ __forceinline__ void fma_tap(f32x2 &acc, const f32x2 &tap_pair, const
 
 // FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
 // followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T>
 __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__restrict__ rows,
                                          const StreamDesc &d, const float *xs, uint32_t xshift,
                                          uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
@@ -150,33 +151,51 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
                                                          static_cast<int64_t>(d.n_out) - k0));
     const int i_lo = static_cast<int>(min(lo64, static_cast<int64_t>(R)));
     const int i_hi = static_cast<int>(max(hi64, static_cast<int64_t>(0)));
-    g_i16 *o = as_global(d.out) + k0 * static_cast<int64_t>(C) + cg * CT;
-    const bool aligned = CT == 2 && ((reinterpret_cast<uintptr_t>(d.out) | (C * 2u)) & 3u) == 0;
-    if (ONE_GROUP && CT == 2 && aligned && i_lo == 0 && i_hi == R) {
-      // the lane's R frames are R consecutive dwords: 16 + 16 + 8 bytes instead of R narrow
-      // stores (each store instruction costs one line request per lane whatever its width)
-      uint32_t v[R];
+    if constexpr (sizeof(T) == 4) {
+      // float I/O (resample.c:927-963): the FIR value as is
+      G<float> *o = out_ptr<float>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
+      if (ONE_GROUP && CT == 2 && i_lo == 0 && i_hi == R) {
+        static_assert(R % 2 == 0, "R frames of 2 floats go out as R/2 float4");
 #pragma unroll
-      for (int i = 0; i < R; i++) v[i] = round_pack_pcm(acc[i].x, acc[i].y);
-      g_u32x4_a4 *o4 = (g_u32x4_a4 *)o;
-      o4[0] = u32x4_a4{v[0], v[1], v[2], v[3]};
-      o4[1] = u32x4_a4{v[4], v[5], v[6], v[7]};
-      *(g_u32x2_a4 *)(o + 16) = u32x2_a4{v[8], v[9]};
-      continue;
-    }
+        for (int i = 0; i < R; i += 2)
+          *(G<f32x4_a4> *)(o + 2 * i) = f32x4_a4{acc[i].x, acc[i].y, acc[i + 1].x, acc[i + 1].y};
+        continue;
+      }
 #pragma unroll
-    for (int i = 0; i < R; i++, o += C) {
-      if (i < i_lo || i >= i_hi) continue;
-      if (CT == 2) {
-        const uint32_t v = round_pack_pcm(acc[i].x, acc[i].y);
-        if (aligned) {
-          *(g_u32 *)o = v;
+      for (int i = 0; i < R; i++, o += C) {
+        if (i < i_lo || i >= i_hi) continue;
+        o[0] = acc[i].x;
+        if (CT == 2) o[1] = acc[i].y;
+      }
+    } else {
+      g_i16 *o = out_ptr<int16_t>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
+      const bool aligned = CT == 2 && ((reinterpret_cast<uintptr_t>(d.out) | (C * 2u)) & 3u) == 0;
+      if (ONE_GROUP && CT == 2 && aligned && i_lo == 0 && i_hi == R) {
+        // the lane's R frames are R consecutive dwords: 16 + 16 + 8 bytes instead of R narrow
+        // stores (each store instruction costs one line request per lane whatever its width)
+        uint32_t v[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) v[i] = round_pack_pcm(acc[i].x, acc[i].y);
+        g_u32x4_a4 *o4 = (g_u32x4_a4 *)o;
+        o4[0] = u32x4_a4{v[0], v[1], v[2], v[3]};
+        o4[1] = u32x4_a4{v[4], v[5], v[6], v[7]};
+        *(g_u32x2_a4 *)(o + 16) = u32x2_a4{v[8], v[9]};
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < R; i++, o += C) {
+        if (i < i_lo || i >= i_hi) continue;
+        if (CT == 2) {
+          const uint32_t v = round_pack_pcm(acc[i].x, acc[i].y);
+          if (aligned) {
+            *(g_u32 *)o = v;
+          } else {
+            o[0] = static_cast<int16_t>(v & 0xffffu);
+            o[1] = static_cast<int16_t>(v >> 16);
+          }
         } else {
-          o[0] = static_cast<int16_t>(v & 0xffffu);
-          o[1] = static_cast<int16_t>(v >> 16);
+          o[0] = static_cast<int16_t>(round_pack_pcm(acc[i].x, 0.f) & 0xffffu);
         }
-      } else {
-        o[0] = static_cast<int16_t>(round_pack_pcm(acc[i].x, 0.f) & 0xffffu);
       }
     }
   }
@@ -187,13 +206,13 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 //
 // One-shot form: workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one
 // of gridDim.z shares of its phase groups.  Used when a launch has too few tiles to loop over.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == p.history_block) {
-    if (blockIdx.z == 0) roll_history(p.taps, p.channels, d);
+    if (blockIdx.z == 0) roll_history<T>(p.taps, p.channels, d);
     return;
   }
   if (d.n_out == 0 || blockIdx.x > p.history_block) return;
@@ -203,15 +222,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   if (m_lo >= m_total) return;
   const uint32_t m_cnt = min(p.lane_periods, m_total - m_lo);
 
-  const WindowGeom wg = window_geom(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
+  const WindowGeom wg = window_geom<T>(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
   if (!(p.skip & 2u)) {
     u32x4 w[3];
-    window_fetch<3>(wg, w);
-    window_commit<3>(xs, d, wg, w);
+    window_fetch<3, T>(wg, w);
+    window_commit<3, T>(xs, d, wg, w);
   }
   __syncthreads();
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  fir_tile<R, CT, ONE_GROUP, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
+  fir_tile<R, CT, ONE_GROUP, PADDED, T>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
                                      blockIdx.z, gridDim.z);
 }
 
@@ -220,17 +239,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
 // next tile's input window are already in flight (registers), so HBM latency, the int16->float
 // conversion and the stores of one workgroup hide behind the other's FMAs and the workgroups
 // never fall into lock-step the way back-to-back launches of the one-shot form do.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
 __device__ __forceinline__ void persistent_body(const PeriodParams &p, const float *__restrict__ rows,
                                                 const StreamDesc *streams, const DescPack &pack,
                                                 uint32_t n_streams, uint32_t tiles_per_stream, float *xs) {
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t s = blockIdx.x; s < n_streams; s += gridDim.x)  // history rolls ride along
-    roll_history(p.taps, p.channels, PACKED ? pack.d[s] : streams[s]);
+    roll_history<T>(p.taps, p.channels, PACKED ? pack.d[s] : streams[s]);
 
   const uint32_t total = n_streams * tiles_per_stream;
-  uint32_t T = blockIdx.x;
+  uint32_t tile = blockIdx.x;
   u32x4 w[3];
   WindowGeom wg;
   StreamDesc d;
@@ -242,42 +261,42 @@ __device__ __forceinline__ void persistent_body(const PeriodParams &p, const flo
     m_lo = (t - s * tiles_per_stream) * p.lane_periods;
     m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 0;
     if (m_cnt) {
-      wg = window_geom(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
-      window_fetch<3>(wg, w);
+      wg = window_geom<T>(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
+      window_fetch<3, T>(wg, w);
     }
   };
-  if (T < total) open_tile(T);
-  while (T < total) {
+  if (tile < total) open_tile(tile);
+  while (tile < total) {
     const StreamDesc d_cur = d;
     const uint32_t m_lo_cur = m_lo, m_cnt_cur = m_cnt, xshift_cur = wg.xshift;
-    if (m_cnt_cur && !(p.skip & 2u)) window_commit<3>(xs, d_cur, wg, w);
+    if (m_cnt_cur && !(p.skip & 2u)) window_commit<3, T>(xs, d_cur, wg, w);
     __syncthreads();
-    const uint32_t Tn = T + gridDim.x;
-    if (Tn < total) open_tile(Tn);  // next window's loads fly during this tile's FIR
+    const uint32_t next = tile + gridDim.x;
+    if (next < total) open_tile(next);  // next window's loads fly during this tile's FIR
     if (m_cnt_cur)
-      fir_tile<R, CT, ONE_GROUP, PADDED>(p, rows, d_cur, xs, xshift_cur, m_lo_cur, m_cnt_cur, wave, lane, 0, 1);
+      fir_tile<R, CT, ONE_GROUP, PADDED, T>(p, rows, d_cur, xs, xshift_cur, m_lo_cur, m_cnt_cur, wave, lane, 0, 1);
     __syncthreads();  // every wave is done with this window before it is overwritten
-    T = Tn;
+    tile = next;
   }
 }
 
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period_persistent(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack,
     uint32_t n_streams, uint32_t tiles_per_stream) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  persistent_body<R, CT, ONE_GROUP, PADDED, PACKED>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
+  persistent_body<R, CT, ONE_GROUP, PADDED, PACKED, T>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
 }
 
 // Same walk without the SGPR cap: all 4R taps of an iteration arrive with ONE scalar-load wait
 // (~106 SGPRs -> 7 waves per SIMD -> one 16-wave workgroup per CU; the software pipeline, not
 // a second workgroup, hides the staging).
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
 __global__ __launch_bounds__(1024) void resample_period_persistent_wide(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack,
     uint32_t n_streams, uint32_t tiles_per_stream) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  persistent_body<R, CT, ONE_GROUP, PADDED, PACKED>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
+  persistent_body<R, CT, ONE_GROUP, PADDED, PACKED, T>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
 }
 
 template <typename K>
@@ -286,7 +305,7 @@ void opt_in_lds(K kern) {
                             160 * 1024);
 }
 
-template <int R, int CT, bool ONE_GROUP, bool PADDED>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, uint32_t n_streams, uint32_t tiles_per_stream,
                      bool persistent, hipStream_t stream) {
@@ -294,35 +313,35 @@ hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const Des
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static bool once = false;
   if (!once) {
-    opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, true>);
-    opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, false>);
-    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, true>);
-    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, false>);
-    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true>);
-    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false>);
+    opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, true, T>);
+    opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, false, T>);
+    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, true, T>);
+    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, false, T>);
+    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true, T>);
+    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false, T>);
     once = true;
   }
   static const bool wide = std::getenv("SPEEXHIP_WIDE") && std::atoi(std::getenv("SPEEXHIP_WIDE")) != 0;
   if (persistent && wide) {
     if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true>), grid, dim3(threads), lds_bytes,
+      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes,
                          stream, p, p.rows, nullptr, *pack, n_streams, tiles_per_stream);
     else
-      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false>), grid, dim3(threads), lds_bytes,
+      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false, T>), grid, dim3(threads), lds_bytes,
                          stream, p, p.rows, d_descs, empty, n_streams, tiles_per_stream);
   } else if (persistent) {
     if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, PADDED, true>), grid, dim3(threads), lds_bytes,
+      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes,
                          stream, p, p.rows, nullptr, *pack, n_streams, tiles_per_stream);
     else
-      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, PADDED, false>), grid, dim3(threads), lds_bytes,
+      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, PADDED, false, T>), grid, dim3(threads), lds_bytes,
                          stream, p, p.rows, d_descs, empty, n_streams, tiles_per_stream);
   } else {
     if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true>), grid, dim3(threads), lds_bytes, stream, p,
+      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes, stream, p,
                          p.rows, nullptr, *pack);
     else
-      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false>), grid, dim3(threads), lds_bytes, stream, p,
+      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T>), grid, dim3(threads), lds_bytes, stream, p,
                          p.rows, d_descs, empty);
   }
   return hipGetLastError();
@@ -450,7 +469,7 @@ void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<flo
 
 hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
                          const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                         uint32_t n_streams, hipStream_t stream) {
+                         uint32_t n_streams, bool float_io, hipStream_t stream) {
   uint32_t max_periods = 0;
   for (uint32_t s = 0; s < n_streams; s++) {
     if (h_descs[s].n_out == 0) continue;
@@ -507,9 +526,11 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   uint32_t grid_x = (max_periods == 0 ? 0 : tiles) + 1;
   if (splits > 1 && n_streams == 1) grid_x = (grid_x + 7) / 8 * 8;
   dim3 grid = persistent ? dim3(resident, 1, 1) : dim3(grid_x, n_streams, splits);
-#define SPEEXHIP_PERIOD_CASE(CTV, ONE, PADV)                                                              \
-  return launch_rc<kR, CTV, ONE, PADV>(p, d_descs, pack, grid, threads, t.window_bytes, n_streams, tiles, \
-                                       persistent, stream)
+#define SPEEXHIP_PERIOD_CASE(CTV, ONE, PADV)                                                            \
+  return float_io ? launch_rc<kR, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, \
+                                                         n_streams, tiles, persistent, stream)           \
+                  : launch_rc<kR, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, \
+                                                           n_streams, tiles, persistent, stream)
   const bool padded = t.pad != 0;
   if (t.ct == 2) {
     if (t.cgroups == 1 && !padded) SPEEXHIP_PERIOD_CASE(2, true, false);

@@ -36,6 +36,7 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned wide store
 typedef __attribute__((address_space(1))) u32x4_a4 g_u32x4_a4;
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // acc.xy += tap[hi].xx * x.xy   (channel-pair packing: tap broadcast from an SGPR pair)
 __device__ __forceinline__ void fma_bcast_tap(f32x2 &acc, const f32x2 &tap_pair, const f32x2 &x, bool hi) {
@@ -51,13 +52,13 @@ __device__ __forceinline__ void fma_bcast_x(f32x2 &acc, const f32x2 &tap_pair, c
 
 // PAIR_CH: true = channel pairs (NP = den accumulators per period), false = phase pairs (NP = ceil(den/2)).
 // P: periods per lane; NUM: input frames per period; U = P*NUM tap steps per iteration.
-template <int P, int NUM, int NP, bool PAIR_CH, bool PACKED>
+template <int P, int NUM, int NP, bool PAIR_CH, bool PACKED, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void resample_slide(
     SlideParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
-    roll_history(p.taps, p.channels, d);
+    roll_history<T>(p.taps, p.channels, d);
     return;
   }
   if (d.n_out == 0) return;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
     const uint32_t row_elems = P * NUM * C;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
       const uint32_t row = e / row_elems, col = e - row * row_elems;
-      xs[row * p.row_stride + col] = rel_sample(d, q0 + e, hist_elems, in_elems);
+      xs[row * p.row_stride + col] = rel_sample<T>(d, q0 + e, hist_elems, in_elems);
     }
   }
   __syncthreads();
@@ -138,6 +139,35 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
 
   // ---- round, interleave, store: P*den consecutive output frames of this lane -----------------
   const uint64_t K0 = static_cast<uint64_t>(m_lo + lb * P) * p.den;
+  const bool inside = K0 >= d.k_shift && K0 + static_cast<uint64_t>(P) * p.den <= K_end;
+  if constexpr (sizeof(T) == 4) {
+    // float I/O (resample.c:927-963): the FIR values as they are
+    G<float> *o0 = out_ptr<float>(d) + (static_cast<int64_t>(K0) - static_cast<int64_t>(d.k_shift)) * C;
+    const bool dense = PAIR_CH ? (C == 2) : (C == 1 && p.den == 2u * NP);
+    if (dense && inside) {  // the lane's P*NP pairs are 2*P*NP consecutive floats
+      static_assert((P * NP) % 2 == 0, "pairs per lane come in groups of 2");
+#pragma unroll
+      for (int q = 0; q < P * NP; q += 2) {
+        const f32x2 a = acc[q / NP][q % NP], b = acc[(q + 1) / NP][(q + 1) % NP];
+        *(G<f32x4_a4> *)(o0 + 2 * q) = f32x4_a4{a.x, a.y, b.x, b.y};
+      }
+      return;
+    }
+#pragma unroll
+    for (int pp = 0; pp < P; pp++)
+#pragma unroll
+      for (int r = 0; r < NP; r++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          // channel pairs: h = channel of the pair, phase r; phase pairs: phase 2r + h
+          const uint32_t ph = PAIR_CH ? r : 2 * r + h;
+          const uint64_t K = K0 + static_cast<uint64_t>(pp) * p.den + ph;
+          if (ph >= p.den || K < d.k_shift || K >= K_end) continue;
+          out_ptr<float>(d)[(K - d.k_shift) * C + (PAIR_CH ? cg * 2 + h : cg)] = h ? acc[pp][r].y : acc[pp][r].x;
+        }
+      }
+    return;
+  } else {
   uint32_t v[P * NP];  // packed s16 pairs in output order
 #pragma unroll
   for (int pp = 0; pp < P; pp++)
@@ -146,8 +176,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   // The lane's pairs are consecutive dwords of the output when a frame is exactly one pair
   // (stereo) or phase pairs tile a mono period: wide dword-aligned stores, 16 bytes at a time.
   const bool dense = PAIR_CH ? (C == 2) : (C == 1 && p.den == 2u * NP);
-  const bool inside = K0 >= d.k_shift && K0 + static_cast<uint64_t>(P) * p.den <= K_end;
-  g_i16 *o0 = as_global(d.out) + (static_cast<int64_t>(K0) - static_cast<int64_t>(d.k_shift)) * C;
+  g_i16 *o0 = out_ptr<int16_t>(d) + (static_cast<int64_t>(K0) - static_cast<int64_t>(d.k_shift)) * C;
   if (dense && inside && (reinterpret_cast<uintptr_t>(o0) & 3u) == 0) {
     static_assert((P * NP) % 4 == 0, "pairs per lane come in groups of 4");
 #pragma unroll
@@ -163,7 +192,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
       if (PAIR_CH) {
         const uint64_t K = K0 + static_cast<uint64_t>(pp) * p.den + r;
         if (K < d.k_shift || K >= K_end) continue;
-        g_i16 *o = as_global(d.out) + (K - d.k_shift) * C + cg * 2;
+        g_i16 *o = out_ptr<int16_t>(d) + (K - d.k_shift) * C + cg * 2;
         o[0] = static_cast<int16_t>(w & 0xffffu);
         o[1] = static_cast<int16_t>(w >> 16);
       } else {
@@ -172,31 +201,32 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
           const uint32_t ph = 2 * r + h;
           const uint64_t K = K0 + static_cast<uint64_t>(pp) * p.den + ph;
           if (ph >= p.den || K < d.k_shift || K >= K_end) continue;
-          as_global(d.out)[(K - d.k_shift) * C + cg] = static_cast<int16_t>(h ? (w >> 16) : (w & 0xffffu));
+          out_ptr<int16_t>(d)[(K - d.k_shift) * C + cg] = static_cast<int16_t>(h ? (w >> 16) : (w & 0xffffu));
         }
       }
     }
   }
+  }
 }
 
-template <int P, int NUM, int NP, bool PAIR_CH>
+template <int P, int NUM, int NP, bool PAIR_CH, typename T>
 hipError_t launch_up(const SlideParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, true, T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, false, T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
   if (pack != nullptr)
-    hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, true>), grid, dim3(threads), lds_bytes, stream, p,
+    hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, true, T>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, nullptr, *pack);
   else
-    hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, false>), grid, dim3(threads), lds_bytes, stream, p,
+    hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, false, T>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, d_descs, empty);
   return hipGetLastError();
 }
@@ -260,7 +290,7 @@ void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float
 
 hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
                         const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                        uint32_t n_streams, hipStream_t stream) {
+                        uint32_t n_streams, bool float_io, hipStream_t stream) {
   uint32_t max_periods = 0;
   for (uint32_t s = 0; s < n_streams; s++) {
     if (h_descs[s].n_out == 0) continue;
@@ -295,7 +325,8 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   const uint32_t threads = waves * 64;
 #define SPEEXHIP_SLIDE_CASE(PP, NUMV, NPV, CHV)                           \
   if (t.p == PP && t.num == NUMV && t.np == NPV && t.pair_ch == CHV)      \
-    return launch_up<PP, NUMV, NPV, CHV>(p, d_descs, pack, grid, threads, lds, stream);
+    return float_io ? launch_up<PP, NUMV, NPV, CHV, float>(p, d_descs, pack, grid, threads, lds, stream) \
+                    : launch_up<PP, NUMV, NPV, CHV, int16_t>(p, d_descs, pack, grid, threads, lds, stream);
   SPEEXHIP_SLIDE_CASE(8, 1, 1, true)
   SPEEXHIP_SLIDE_CASE(8, 1, 2, true)
   SPEEXHIP_SLIDE_CASE(8, 1, 3, true)

@@ -19,7 +19,7 @@ uint32_t produced_closed_form(uint32_t num, uint32_t den, uint32_t in_frames,
 }
 
 CallPlan plan_call(uint32_t num, uint32_t den, uint32_t in_frames, uint32_t out_capacity,
-                   StreamPos pos) {
+                   StreamPos pos, uint32_t block_out) {
   CallPlan plan;
   plan.begin = pos;
   int64_t last = pos.last;
@@ -31,7 +31,7 @@ CallPlan plan_call(uint32_t num, uint32_t den, uint32_t in_frames, uint32_t out_
   // consumes exactly kBlockIn frames and ends with its position past the block, so the state
   // after b blocks is the state after P(b) = #outputs starting before frame 160*b.
   const uint64_t per_block_max = ceil_div(static_cast<uint64_t>(kBlockIn) * den, num) + 1;
-  if (per_block_max <= kBlockOut && in_left > 2 * kBlockIn && out_left > 2 * per_block_max) {
+  if (per_block_max <= block_out && in_left > 2 * kBlockIn && out_left > 2 * per_block_max) {
     uint64_t lo = 0, hi = in_left / kBlockIn - 1;  // keep at least one block for the loop below
     const uint64_t room = out_left - 2 * per_block_max;
     while (lo < hi) {  // largest b with P(b) <= room
@@ -54,7 +54,7 @@ CallPlan plan_call(uint32_t num, uint32_t den, uint32_t in_frames, uint32_t out_
   }
   while (in_left && out_left) {
     const uint64_t blk_in = in_left < kBlockIn ? in_left : kBlockIn;
-    const uint64_t blk_out = out_left < kBlockOut ? out_left : kBlockOut;
+    const uint64_t blk_out = out_left < block_out ? out_left : block_out;
     uint64_t made = outputs_before(num, den, last, static_cast<uint32_t>(frac),
                                    static_cast<int64_t>(blk_in));
     if (made > blk_out) made = blk_out;

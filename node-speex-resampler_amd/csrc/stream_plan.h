@@ -27,8 +27,10 @@ struct CallPlan {
 static const uint32_t kBlockIn = 160;    // st->buffer_size, resample.c:835
 static const uint32_t kBlockOut = 1024;  // FIXED_STACK_ALLOC, resample.c:111
 
+// block_out: outputs one block may emit -- kBlockOut for the int16 entry point (its stack
+// buffer, resample.c:982-991), unlimited for the float entry point (resample.c:943).
 CallPlan plan_call(uint32_t num, uint32_t den, uint32_t in_frames, uint32_t out_capacity,
-                   StreamPos pos);
+                   StreamPos pos, uint32_t block_out = kBlockOut);
 
 // Closed form for `produced` alone (used as a cross-check): outputs whose window starts
 // inside the call's input, capped by the capacity.

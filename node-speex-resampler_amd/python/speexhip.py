@@ -19,7 +19,9 @@ ERR_DEVICE = 6
 
 EXPORTS = [
     "speexhip_resampler_init", "speexhip_resampler_destroy",
-    "speexhip_resampler_process_interleaved_int", "speexhip_resampler_get_rate",
+    "speexhip_resampler_process_interleaved_int", "speexhip_resampler_process_interleaved_float",
+    "speexhip_resampler_process_interleaved_float_device",
+    "speexhip_batch_process_interleaved_float_device", "speexhip_resampler_get_rate",
     "speexhip_resampler_strerror", "speexhip_resampler_process_interleaved_int_device",
     "speexhip_resampler_set_mode", "speexhip_resampler_get_info", "speexhip_resampler_get_history",
     "speexhip_batch_init", "speexhip_batch_destroy", "speexhip_batch_set_mode",
@@ -67,6 +69,14 @@ def lib():
         L.speexhip_resampler_process_interleaved_int.argtypes = [p, pi16, pu32, pi16, pu32]
         L.speexhip_resampler_process_interleaved_int_device.restype = i32
         L.speexhip_resampler_process_interleaved_int_device.argtypes = [p, p, pu32, p, pu32, p]
+        pf32 = C.POINTER(C.c_float)
+        L.speexhip_resampler_process_interleaved_float.restype = i32
+        L.speexhip_resampler_process_interleaved_float.argtypes = [p, pf32, pu32, pf32, pu32]
+        L.speexhip_resampler_process_interleaved_float_device.restype = i32
+        L.speexhip_resampler_process_interleaved_float_device.argtypes = [p, p, pu32, p, pu32, p]
+        L.speexhip_batch_process_interleaved_float_device.restype = i32
+        L.speexhip_batch_process_interleaved_float_device.argtypes = [p, p, C.c_uint64, pu32, p,
+                                                                      C.c_uint64, pu32, p]
         L.speexhip_resampler_get_rate.argtypes = [p, pu32, pu32]
         L.speexhip_resampler_strerror.restype = C.c_char_p
         L.speexhip_resampler_strerror.argtypes = [i32]
@@ -75,7 +85,7 @@ def lib():
         L.speexhip_resampler_get_info.restype = i32
         L.speexhip_resampler_get_info.argtypes = [p, C.POINTER(Info)]
         L.speexhip_resampler_get_history.restype = i32
-        L.speexhip_resampler_get_history.argtypes = [p, pi16]
+        L.speexhip_resampler_get_history.argtypes = [p, C.POINTER(C.c_float)]
         L.speexhip_batch_init.restype = p
         L.speexhip_batch_init.argtypes = [u32, u32, u32, u32, i32, C.POINTER(C.c_int)]
         L.speexhip_batch_destroy.argtypes = [p]
@@ -156,8 +166,9 @@ class Resampler:
         return i["last_sample"], i["samp_frac_num"]
 
     def history(self):
-        buf = np.zeros(((self.taps - 1), self.channels), np.int16)
-        rc = lib().speexhip_resampler_get_history(self._h, buf.ctypes.data_as(C.POINTER(C.c_int16)))
+        """(taps-1, channels) float32: the reference's `mem` after the last call"""
+        buf = np.zeros(((self.taps - 1), self.channels), np.float32)
+        rc = lib().speexhip_resampler_get_history(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)))
         if rc:
             raise RuntimeError(strerror(rc))
         return buf
@@ -171,6 +182,20 @@ class Resampler:
         rc = lib().speexhip_resampler_process_interleaved_int(
             self._h, frames.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(il),
             out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(ol))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return out[: ol.value].copy(), il.value
+
+    def process_float(self, frames, out_capacity):
+        """speexhip_resampler_process_interleaved_float with host buffers (float32 in / out)."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        if frames.ndim == 1:
+            frames = frames.reshape(-1, self.channels)
+        out = np.zeros((max(int(out_capacity), 1), self.channels), np.float32)
+        il, ol = C.c_uint32(frames.shape[0]), C.c_uint32(int(out_capacity))
+        rc = lib().speexhip_resampler_process_interleaved_float(
+            self._h, frames.ctypes.data_as(C.POINTER(C.c_float)), C.byref(il),
+            out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ol))
         if rc:
             raise RuntimeError(strerror(rc))
         return out[: ol.value].copy(), il.value
@@ -213,12 +238,15 @@ class Batch:
         return i.as_dict()
 
     def process_device(self, d_in_ptr, in_stride, in_frames, d_out_ptr, out_stride, out_capacity,
-                       stream_ptr=0):
-        """in_frames / out_capacity: int (same for all streams) or sequences of n_streams."""
+                       stream_ptr=0, float_io=False):
+        """in_frames / out_capacity: int (same for all streams) or sequences of n_streams.
+        float_io: the buffers hold float32 samples (strides in samples either way)."""
         n = self.n_streams
         il = (C.c_uint32 * n)(*([in_frames] * n if np.isscalar(in_frames) else in_frames))
         ol = (C.c_uint32 * n)(*([out_capacity] * n if np.isscalar(out_capacity) else out_capacity))
-        rc = lib().speexhip_batch_process_interleaved_int_device(
+        fn = (lib().speexhip_batch_process_interleaved_float_device if float_io
+              else lib().speexhip_batch_process_interleaved_int_device)
+        rc = fn(
             self._h, C.c_void_p(d_in_ptr), in_stride, il, C.c_void_p(d_out_ptr), out_stride, ol,
             C.c_void_p(stream_ptr))
         if rc:

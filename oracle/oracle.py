@@ -72,7 +72,23 @@ class _Base:
         return out[: ol.value].copy(), il.value
 
 
-class Oracle(_Base):
+class _FloatMixin:
+    def process_float(self, frames, out_capacity):
+        """speex_resampler_process_interleaved_float: float32 frames in, float32 frames out."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        if frames.ndim == 1:
+            frames = frames.reshape(-1, self.channels)
+        out = np.zeros((max(int(out_capacity), 1), self.channels), np.float32)
+        il = C.c_uint32(frames.shape[0])
+        ol = C.c_uint32(int(out_capacity))
+        rc = self._process_float(frames.ctypes.data_as(C.POINTER(C.c_float)), C.byref(il),
+                                 out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ol))
+        if rc != 0:
+            raise RuntimeError("process failed: %d" % rc)
+        return out[: ol.value].copy(), il.value
+
+
+class Oracle(_Base, _FloatMixin):
     """Our CPU restatement."""
 
     _lib = None
@@ -90,6 +106,10 @@ class Oracle(_Base):
             L.orc_process_interleaved_int.argtypes = [C.c_void_p, C.POINTER(C.c_int16),
                                                       C.POINTER(C.c_uint32), C.POINTER(C.c_int16),
                                                       C.POINTER(C.c_uint32)]
+            L.orc_process_interleaved_float.restype = C.c_int
+            L.orc_process_interleaved_float.argtypes = [C.c_void_p, C.POINTER(C.c_float),
+                                                        C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                                                        C.POINTER(C.c_uint32)]
             L.orc_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
             L.orc_table.restype = C.POINTER(C.c_float)
             L.orc_table.argtypes = [C.c_void_p]
@@ -116,6 +136,9 @@ class Oracle(_Base):
 
     def _process(self, i, il, o, ol):
         return self.lib().orc_process_interleaved_int(self._h, i, il, o, ol)
+
+    def _process_float(self, i, il, o, ol):
+        return self.lib().orc_process_interleaved_float(self._h, i, il, o, ol)
 
     def table(self):
         p = self.lib().orc_table(self._h)
@@ -153,7 +176,7 @@ class _RefState(C.Structure):
     ]
 
 
-class Reference(_Base):
+class Reference(_Base, _FloatMixin):
     """The reference's own C implementation (oracle/_ref/libspeexref.so)."""
 
     _lib = None
@@ -170,6 +193,10 @@ class Reference(_Base):
             L.speex_resampler_process_interleaved_int.argtypes = [
                 C.POINTER(_RefState), C.POINTER(C.c_int16), C.POINTER(C.c_uint32),
                 C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]
+            L.speex_resampler_process_interleaved_float.restype = C.c_int
+            L.speex_resampler_process_interleaved_float.argtypes = [
+                C.POINTER(_RefState), C.POINTER(C.c_float), C.POINTER(C.c_uint32),
+                C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
             L.speex_resampler_strerror.restype = C.c_char_p
             L.speex_resampler_strerror.argtypes = [C.c_int]
             cls._lib = L
@@ -193,6 +220,9 @@ class Reference(_Base):
 
     def _process(self, i, il, o, ol):
         return self.lib().speex_resampler_process_interleaved_int(self._h, i, il, o, ol)
+
+    def _process_float(self, i, il, o, ol):
+        return self.lib().speex_resampler_process_interleaved_float(self._h, i, il, o, ol)
 
     def table(self):
         return np.ctypeslib.as_array(self._h.contents.sinc_table, shape=(self.table_len,)).copy()

@@ -9,7 +9,8 @@
  * What it restates (all citations relative to /root/reference/):
  *   - filter design         deps/speex/resample.c:148-298, 605-702
  *   - the four FIR kernels  deps/speex/resample.c:331-558
- *   - stream bookkeeping    deps/speex/resample.c:878-902, 968-1036, 1061-1082
+ *   - stream bookkeeping    deps/speex/resample.c:878-902, 968-1036, 1061-1082 (int16 entry)
+ *                           and 927-963, 1038-1059 (float entry)
  *   - float build typedefs  deps/speex/arch.h:131-209 (FLOATING_POINT)
  * as built by scripts/build_emscripten.sh:18-19 (-D FLOATING_POINT -D OUTSIDE_SPEEX).
  *
@@ -355,6 +356,59 @@ int orc_process_interleaved_int(orc_state *o, const int16_t *in, uint32_t *in_le
     *in_len = want_in;
     *out_len = want_out;
     run_channel(o, c, in ? in + c : NULL, o->channels, in_len, out + c, out_len);
+  }
+  return ORC_OK;
+}
+
+/* One channel of one call through the FLOAT entry point (resample.c:927-963): input frames are
+ * copied as they are, the FIR values are written unrounded, and -- unlike the int16 entry
+ * point -- a block's output is limited only by the room left (resample.c:943), not by 1024. */
+static void run_channel_float(orc_state *o, uint32_t c, const float *in, uint32_t stride,
+                              uint32_t *in_len, float *out, uint32_t *out_len) {
+  float *x = o->lines + (size_t)c * o->line;
+  const uint32_t hist = o->taps - 1;
+  uint32_t in_left = *in_len, out_left = *out_len;
+  while (in_left && out_left) {
+    uint32_t nin = in_left > ORC_BLOCK_IN ? ORC_BLOCK_IN : in_left;
+    uint32_t nout_max = out_left;
+    for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? in[(size_t)j * stride] : 0.f;
+
+    int32_t pos = o->pos[c];
+    uint32_t phase = o->phase[c];
+    uint32_t made = 0;
+    while (!(pos >= (int32_t)nin || made >= nout_max)) {
+      out[(size_t)made * stride] = fir_sample(o, x + pos, phase);
+      made++;
+      pos += o->step_int;
+      phase += o->step_frac;
+      if (phase >= o->den) {
+        phase -= o->den;
+        pos++;
+      }
+    }
+    uint32_t used = nin;
+    if (pos < (int32_t)nin) used = pos;
+    o->pos[c] = pos - (int32_t)used;
+    o->phase[c] = phase;
+    for (uint32_t j = 0; j < hist; j++) x[j] = x[j + used];
+
+    in_left -= used;
+    out_left -= made;
+    out += (size_t)made * stride;
+    if (in) in += (size_t)used * stride;
+  }
+  *in_len -= in_left;
+  *out_len -= out_left;
+}
+
+/* resample.c:1038-1059 */
+int orc_process_interleaved_float(orc_state *o, const float *in, uint32_t *in_len, float *out,
+                                  uint32_t *out_len) {
+  const uint32_t want_in = *in_len, want_out = *out_len;
+  for (uint32_t c = 0; c < o->channels; c++) {
+    *in_len = want_in;
+    *out_len = want_out;
+    run_channel_float(o, c, in ? in + c : NULL, o->channels, in_len, out + c, out_len);
   }
   return ORC_OK;
 }

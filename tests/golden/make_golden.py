@@ -170,6 +170,42 @@ def planner_cases():
     return out
 
 
+FLOAT_CASES = [  # (name, channels, in_rate, out_rate, quality, frames, call plan [(frames, capacity)...])
+    ("f_interp_single", 2, 44100, 48000, 7, 6000), ("f_interp_double", 2, 44100, 48000, 10, 6000),
+    ("f_direct_single", 1, 24000, 48000, 5, 6000), ("f_direct_double", 1, 24000, 48000, 10, 6000),
+    ("f_down_8ch", 8, 48000, 44100, 5, 4000), ("f_decim3", 2, 48000, 16000, 6, 6000),
+    ("f_up6_blockcap", 1, 8000, 48000, 3, 6000),  # > 1024 outputs per 160-frame block: float path only
+]
+
+
+def float_input(frames, ch, seed):
+    """deterministic float32 in [-1, 1): the LCG samples scaled by 2^-15"""
+    return (orc.lcg_pcm(frames * ch, seed).astype(np.float32) / np.float32(32768.0)).reshape(frames, ch)
+
+
+def float_cases():
+    """speex_resampler_process_interleaved_float on the native reference (the WASM build does not
+    export it): mixed call sizes incl. capacity-bound ones; digests of the float32 bytes."""
+    rows = []
+    for k, (name, ch, i, o, q, frames) in enumerate(FLOAT_CASES):
+        x = float_input(frames, ch, 4000 + k)
+        r = orc.Reference(ch, i, o, q)
+        outs, calls, off = [], [], 0
+        for n, cap in [(1, 1 << 20), (999, 1 << 20), (2000, 1500), (frames, 1 << 20)]:
+            part = x[off: off + n]
+            y, used = r.process_float(part, cap)
+            pos, ph = r.position()
+            calls.append([int(part.shape[0]), cap, used, int(y.shape[0]), int(pos), int(ph)])
+            outs.append(y)
+            off += used
+        out = np.concatenate(outs)
+        rows.append(dict(name=name, channels=ch, in_rate=i, out_rate=o, quality=q, frames=frames, seed=4000 + k,
+                         kind=r.kind, calls=calls, out_frames=int(out.shape[0]), out_sha1=sha1(out),
+                         head=[float(v) for v in out[:4].reshape(-1)]))
+        print("%-34s %-20s out=%8d %s (float)" % (name, r.kind, out.shape[0], rows[-1]["out_sha1"][:12]))
+    return rows
+
+
 def resource_cases():
     """The reference's own fixtures (resources/*.pcm; read whole, header and all, like
     src/test.ts:29).  Only digests are stored; the test needs /root/reference to re-run them."""
@@ -224,7 +260,7 @@ def main():
         sources=["oracle/_ref/libspeexref.so (reference deps/speex/resample.c, -DFLOATING_POINT "
                  "-DOUTSIDE_SPEEX)", "reference app/speex_wasm.js via node"],
         lcg="s=s*1664525+1013904223 mod 2^32; sample=int16(s>>16); seed per case",
-        cases=cases, planner=planner_cases(), resources=resource_cases())
+        cases=cases, planner=planner_cases(), resources=resource_cases(), float_cases=float_cases())
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     print("wrote golden.json: %d cases, %d planner sets, %d resource rows" %

@@ -77,7 +77,7 @@ def test_history_after_each_call_equals_the_reference_memory():
             assert_close(got, want, "history case")
             h = r.history()
             for c in range(ch):
-                assert np.array_equal(h[:, c].astype(np.float32), ref.history(c))
+                assert np.array_equal(h[:, c], ref.history(c))
 
 
 @pytest.mark.parametrize("name,ch,i,o,q", [
@@ -343,3 +343,66 @@ def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
             assert used == wu and r.position() == ref.position()
             assert np.array_equal(got, want), "exact fallback differs for %s" % ((ch, i, o, q),)
         r.close()
+
+
+def test_float_entry_point_exact_and_fast(golden):
+    """speexhip_resampler_process_interleaved_float.  EXACT mode reproduces the
+    reference's float32 output bit for bit; FAST mode within 2e-6 of full scale (the fp32
+    re-association error of a <= 268-tap FMA chain; inputs are in [-1, 1))."""
+    from make_golden import float_input
+    for c in golden["float_cases"]:
+        x = float_input(c["frames"], c["channels"], c["seed"])
+        for mode in (speexhip.MODE_EXACT, speexhip.MODE_FAST):
+            r = speexhip.Resampler(c["channels"], c["in_rate"], c["out_rate"], c["quality"], mode=mode)
+            ref = orc.Oracle(c["channels"], c["in_rate"], c["out_rate"], c["quality"])
+            outs, off = [], 0
+            for (n, cap, used, made, pos, ph) in c["calls"]:
+                y, u = r.process_float(x[off: off + n], cap)
+                want, wu = ref.process_float(x[off: off + n], cap)
+                assert (u, y.shape[0]) + r.position() == (used, made, pos, ph), (c["name"], mode)
+                if mode == speexhip.MODE_FAST:
+                    assert y.shape == want.shape and np.abs(y - want).max(initial=0.0) <= 2e-6, c["name"]
+                outs.append(y)
+                off += u
+            if mode == speexhip.MODE_EXACT:
+                assert sha1(np.concatenate(outs)) == c["out_sha1"], c["name"] + ": EXACT float differs"
+            for ch in range(c["channels"]):
+                assert np.array_equal(r.history()[:, ch], ref.history(ch)), c["name"]
+            r.close()
+
+
+def test_int16_and_float_calls_share_one_stream_state():
+    """The reference keeps one float history for both entry points (resample.c:139): mixing
+    them on one state must match the oracle doing the same."""
+    ch, i, o, q = 2, 44100, 48000, 7
+    r = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT)
+    ref = orc.Oracle(ch, i, o, q)
+    xi = orc.lcg_pcm(3000 * ch, 1).reshape(-1, ch)
+    xf = (orc.lcg_pcm(3000 * ch, 2).astype(np.float32) * np.float32(0.37)).reshape(-1, ch)
+    for step in range(4):
+        if step % 2 == 0:
+            got, used = r.process(xi, 1 << 20)
+            want, wu = ref.process(xi, 1 << 20)
+        else:
+            got, used = r.process_float(xf, 1 << 20)
+            want, wu = ref.process_float(xf, 1 << 20)
+        assert used == wu and r.position() == ref.position() and np.array_equal(got, want), step
+
+
+def test_float_batched_device_pointers():
+    import torch
+    ch, i, o, q, S, frames, cap = 2, 44100, 48000, 7, 5, 20000, 30000
+    xs = np.stack([(orc.lcg_pcm(frames * ch, 60 + s).astype(np.float32) / np.float32(32768)).reshape(frames, ch)
+                   for s in range(S)])
+    d_in = torch.from_numpy(xs).cuda()
+    d_out = torch.zeros((S, cap, ch), dtype=torch.float32, device="cuda")
+    b = speexhip.Batch(S, ch, i, o, q)
+    used, made = b.process_device(d_in.data_ptr(), frames * ch, frames, d_out.data_ptr(), cap * ch, cap,
+                                  torch.cuda.current_stream().cuda_stream, float_io=True)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for s in range(S):
+        want, wu = orc.Oracle(ch, i, o, q).process_float(xs[s], cap)
+        assert (used[s], made[s]) == (wu, want.shape[0])
+        assert np.abs(out[s, : made[s]] - want).max() <= 2e-6
+    b.close()

@@ -91,3 +91,22 @@ def test_oracle_on_the_reference_fixture_files(golden):
         assert out.shape[0] == r["out_frames"] and sha1(out) == r["sha1"], r["file"]
         # the reference test's only assertion (src/test.ts:40): durations agree within 10 ms
         assert abs(x.shape[0] / r["in_rate"] - out.shape[0] / r["out_rate"]) < 0.01
+
+
+def test_oracle_float_entry_point_matches_the_reference_goldens(golden):
+    """speex_resampler_process_interleaved_float (native reference; the WASM build does not export
+    it): bit-identical float32 bytes, counters and positions, incl. capacity-bound calls and the
+    8k->48k case where one 160-frame block emits more than 1024 outputs (float path only)."""
+    from make_golden import float_input
+    for c in golden["float_cases"]:
+        x = float_input(c["frames"], c["channels"], c["seed"])
+        o = orc.Oracle(c["channels"], c["in_rate"], c["out_rate"], c["quality"])
+        assert o.kind == c["kind"]
+        outs, off = [], 0
+        for (n, cap, used, made, pos, ph) in c["calls"]:
+            y, u = o.process_float(x[off: off + n], cap)
+            assert (u, y.shape[0]) + o.position() == (used, made, pos, ph), c["name"]
+            outs.append(y)
+            off += u
+        out = np.concatenate(outs)
+        assert out.shape[0] == c["out_frames"] and sha1(out) == c["out_sha1"], c["name"]
