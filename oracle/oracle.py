@@ -57,15 +57,20 @@ def tone_pcm(n_frames, channels, seed=7, amp=9000.0):
 
 
 class _Base:
-    def process(self, frames, out_capacity):
-        frames = np.ascontiguousarray(frames, dtype=np.int16)
-        if frames.ndim == 1:
-            frames = frames.reshape(-1, self.channels)
-        assert frames.shape[1] == self.channels
+    def process(self, frames, out_capacity, null_frames=0):
+        """frames=None: the reference's in == NULL case (null_frames frames of silence)."""
+        if frames is None:
+            ptr, n = None, int(null_frames)
+        else:
+            frames = np.ascontiguousarray(frames, dtype=np.int16)
+            if frames.ndim == 1:
+                frames = frames.reshape(-1, self.channels)
+            assert frames.shape[1] == self.channels
+            ptr, n = frames.ctypes.data_as(C.POINTER(C.c_int16)), frames.shape[0]
         out = np.zeros((max(int(out_capacity), 1), self.channels), np.int16)
-        il = C.c_uint32(frames.shape[0])
+        il = C.c_uint32(n)
         ol = C.c_uint32(int(out_capacity))
-        rc = self._process(frames.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(il),
+        rc = self._process(ptr, C.byref(il),
                            out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(ol))
         if rc != 0:
             raise RuntimeError("process failed: %d" % rc)
@@ -73,15 +78,19 @@ class _Base:
 
 
 class _FloatMixin:
-    def process_float(self, frames, out_capacity):
+    def process_float(self, frames, out_capacity, null_frames=0):
         """speex_resampler_process_interleaved_float: float32 frames in, float32 frames out."""
-        frames = np.ascontiguousarray(frames, dtype=np.float32)
-        if frames.ndim == 1:
-            frames = frames.reshape(-1, self.channels)
+        if frames is None:
+            ptr, n = None, int(null_frames)
+        else:
+            frames = np.ascontiguousarray(frames, dtype=np.float32)
+            if frames.ndim == 1:
+                frames = frames.reshape(-1, self.channels)
+            ptr, n = frames.ctypes.data_as(C.POINTER(C.c_float)), frames.shape[0]
         out = np.zeros((max(int(out_capacity), 1), self.channels), np.float32)
-        il = C.c_uint32(frames.shape[0])
+        il = C.c_uint32(n)
         ol = C.c_uint32(int(out_capacity))
-        rc = self._process_float(frames.ctypes.data_as(C.POINTER(C.c_float)), C.byref(il),
+        rc = self._process_float(ptr, C.byref(il),
                                  out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ol))
         if rc != 0:
             raise RuntimeError("process failed: %d" % rc)
@@ -117,22 +126,90 @@ class Oracle(_Base, _FloatMixin):
             L.orc_history.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
             L.orc_strerror.restype = C.c_char_p
             L.orc_strerror.argtypes = [C.c_int]
+            L.orc_new_frac.restype = C.c_void_p
+            L.orc_new_frac.argtypes = [C.c_uint32] * 5 + [C.c_int, C.POINTER(C.c_int)]
+            L.orc_set_rate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+            L.orc_set_rate_frac.argtypes = [C.c_void_p] + [C.c_uint32] * 4
+            L.orc_set_quality.argtypes = [C.c_void_p, C.c_int]
+            L.orc_get_rate.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+            L.orc_get_ratio.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+            for f in (L.orc_get_quality, L.orc_input_latency, L.orc_output_latency, L.orc_skip_zeros,
+                      L.orc_reset_mem, L.orc_block_in):
+                f.argtypes = [C.c_void_p]
+            L.orc_pending.restype = C.c_uint32
+            L.orc_pending.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
             cls._lib = L
         return cls._lib
 
-    def __init__(self, channels, in_rate, out_rate, quality=7):
+    def __init__(self, channels, in_rate, out_rate, quality=7, ratio=None):
         L = self.lib()
         err = C.c_int(0)
-        self._h = L.orc_new(channels, in_rate, out_rate, quality, C.byref(err))
+        if ratio is None:
+            self._h = L.orc_new(channels, in_rate, out_rate, quality, C.byref(err))
+        else:
+            self._h = L.orc_new_frac(channels, ratio[0], ratio[1], in_rate, out_rate, quality, C.byref(err))
         self.err = err.value
         if not self._h:
             raise ValueError(L.orc_strerror(err.value).decode())
         self.channels = channels
+        self.refresh()
+
+    def refresh(self):
         info = (C.c_uint32 * 8)()
-        L.orc_info(self._h, info)
+        self.lib().orc_info(self._h, info)
         (self.num, self.den, self.taps, self.oversample, kind, self.table_len,
          self.step_int, self.step_frac) = list(info)
         self.kind = KIND_NAMES[kind]
+
+    # ---- mid-stream control (reference resample.c:1084-1220) ----
+    def set_rate(self, in_rate, out_rate):
+        rc = self.lib().orc_set_rate(self._h, in_rate, out_rate)
+        self.refresh()
+        return rc
+
+    def set_rate_frac(self, num, den, in_rate, out_rate):
+        rc = self.lib().orc_set_rate_frac(self._h, num, den, in_rate, out_rate)
+        self.refresh()
+        return rc
+
+    def set_quality(self, quality):
+        rc = self.lib().orc_set_quality(self._h, quality)
+        self.refresh()
+        return rc
+
+    def rate(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self.lib().orc_get_rate(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def ratio(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self.lib().orc_get_ratio(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def quality(self):
+        return self.lib().orc_get_quality(self._h)
+
+    def input_latency(self):
+        return self.lib().orc_input_latency(self._h)
+
+    def output_latency(self):
+        return self.lib().orc_output_latency(self._h)
+
+    def skip_zeros(self):
+        return self.lib().orc_skip_zeros(self._h)
+
+    def reset_mem(self):
+        return self.lib().orc_reset_mem(self._h)
+
+    def pending(self, c=0):
+        n = self.lib().orc_pending(self._h, c, None)
+        buf = np.zeros(max(n, 1), np.float32)
+        self.lib().orc_pending(self._h, c, buf.ctypes.data_as(C.POINTER(C.c_float)))
+        return buf[:n]
+
+    def block_in(self):
+        return self.lib().orc_block_in(self._h)
 
     def _process(self, i, il, o, ol):
         return self.lib().orc_process_interleaved_int(self._h, i, il, o, ol)
@@ -199,24 +276,95 @@ class Reference(_Base, _FloatMixin):
                 C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
             L.speex_resampler_strerror.restype = C.c_char_p
             L.speex_resampler_strerror.argtypes = [C.c_int]
+            P = C.POINTER(_RefState)
+            L.speex_resampler_init_frac.restype = P
+            L.speex_resampler_init_frac.argtypes = [C.c_uint32] * 5 + [C.c_int, C.POINTER(C.c_int)]
+            L.speex_resampler_set_rate.argtypes = [P, C.c_uint32, C.c_uint32]
+            L.speex_resampler_set_rate_frac.argtypes = [P] + [C.c_uint32] * 4
+            L.speex_resampler_set_quality.argtypes = [P, C.c_int]
+            L.speex_resampler_get_rate.argtypes = [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+            L.speex_resampler_get_ratio.argtypes = [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+            L.speex_resampler_get_quality.argtypes = [P, C.POINTER(C.c_int)]
+            for f in (L.speex_resampler_get_input_latency, L.speex_resampler_get_output_latency,
+                      L.speex_resampler_skip_zeros, L.speex_resampler_reset_mem):
+                f.argtypes = [P]
             cls._lib = L
         return cls._lib
 
-    def __init__(self, channels, in_rate, out_rate, quality=7):
+    def __init__(self, channels, in_rate, out_rate, quality=7, ratio=None):
         L = self.lib()
         err = C.c_int(0)
-        self._h = L.speex_resampler_init(channels, in_rate, out_rate, quality, C.byref(err))
+        if ratio is None:
+            self._h = L.speex_resampler_init(channels, in_rate, out_rate, quality, C.byref(err))
+        else:
+            self._h = L.speex_resampler_init_frac(channels, ratio[0], ratio[1], in_rate, out_rate, quality,
+                                                  C.byref(err))
         self.err = err.value
         if not self._h:
             raise ValueError(L.speex_resampler_strerror(err.value).decode())
-        st = self._h.contents
         self.channels = channels
+        self.refresh()
+
+    def refresh(self):
+        st = self._h.contents
         self.num, self.den = st.num_rate, st.den_rate
         self.taps, self.oversample = st.filt_len, st.oversample
         self.step_int, self.step_frac = st.int_advance, st.frac_advance
         direct = st.filt_len * st.den_rate <= st.filt_len * st.oversample + 8
-        self.kind = KIND_NAMES[(0 if direct else 2) + (1 if quality > 8 else 0)]
+        self.kind = KIND_NAMES[(0 if direct else 2) + (1 if st.quality > 8 else 0)]
         self.table_len = st.filt_len * st.den_rate if direct else st.filt_len * st.oversample + 8
+
+    # ---- mid-stream control (deps/speex/resample.c:1084-1220) ----
+    def set_rate(self, in_rate, out_rate):
+        rc = self.lib().speex_resampler_set_rate(self._h, in_rate, out_rate)
+        self.refresh()
+        return rc
+
+    def set_rate_frac(self, num, den, in_rate, out_rate):
+        rc = self.lib().speex_resampler_set_rate_frac(self._h, num, den, in_rate, out_rate)
+        self.refresh()
+        return rc
+
+    def set_quality(self, quality):
+        rc = self.lib().speex_resampler_set_quality(self._h, quality)
+        self.refresh()
+        return rc
+
+    def rate(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self.lib().speex_resampler_get_rate(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def ratio(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self.lib().speex_resampler_get_ratio(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def quality(self):
+        q = C.c_int()
+        self.lib().speex_resampler_get_quality(self._h, C.byref(q))
+        return q.value
+
+    def input_latency(self):
+        return self.lib().speex_resampler_get_input_latency(self._h)
+
+    def output_latency(self):
+        return self.lib().speex_resampler_get_output_latency(self._h)
+
+    def skip_zeros(self):
+        return self.lib().speex_resampler_skip_zeros(self._h)
+
+    def reset_mem(self):
+        return self.lib().speex_resampler_reset_mem(self._h)
+
+    def pending(self, c=0):
+        st = self._h.contents
+        base = c * st.mem_alloc_size + st.filt_len - 1
+        return np.array([st.mem[base + j] for j in range(st.magic_samples[c])], np.float32)
+
+    def block_in(self):
+        st = self._h.contents
+        return st.mem_alloc_size - (st.filt_len - 1)
 
     def _process(self, i, il, o, ol):
         return self.lib().speex_resampler_process_interleaved_int(self._h, i, il, o, ol)

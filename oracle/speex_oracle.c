@@ -11,6 +11,9 @@
  *   - the four FIR kernels  deps/speex/resample.c:331-558
  *   - stream bookkeeping    deps/speex/resample.c:878-902, 968-1036, 1061-1082 (int16 entry)
  *                           and 927-963, 1038-1059 (float entry)
+ *   - mid-stream changes    deps/speex/resample.c:703-782 (history re-alignment, "magic"
+ *                           samples), 904-922, 1084-1220 (set_rate[_frac], set_quality,
+ *                           latencies, skip_zeros, reset_mem)
  *   - float build typedefs  deps/speex/arch.h:131-209 (FLOATING_POINT)
  * as built by scripts/build_emscripten.sh:18-19 (-D FLOATING_POINT -D OUTSIDE_SPEEX).
  *
@@ -30,6 +33,7 @@
 #define ORC_OK 0
 #define ORC_ERR_ALLOC 1
 #define ORC_ERR_INVALID 3
+#define ORC_ERR_OVERFLOW 5
 
 #define ORC_BLOCK_IN 160   /* st->buffer_size, resample.c:835 */
 #define ORC_BLOCK_OUT 1024 /* FIXED_STACK_ALLOC without VAR_ARRAYS, resample.c:108-112 */
@@ -98,12 +102,17 @@ typedef struct orc_state {
   int step_int, step_frac;
   float cutoff;
   int kind;
-  uint32_t table_len;
+  uint32_t table_len, table_cap; /* floats in use / allocated */
   float *table;
-  uint32_t line;     /* floats of history+staging per channel: taps-1+ORC_BLOCK_IN */
+  uint32_t line;     /* floats of history+staging per channel, grow-only ("mem_alloc_size"):
+                        at least taps-1+ORC_BLOCK_IN */
   float *lines;      /* channels x line */
   int32_t *pos;      /* per channel: resample.c "last_sample" */
   uint32_t *phase;   /* per channel: resample.c "samp_frac_num" */
+  uint32_t *pending; /* per channel: resample.c "magic_samples": already-buffered input frames
+                        (right after the history) left over from a filter-length change */
+  int started;       /* a block has been processed: filter changes must re-align the history */
+  int live;          /* construction finished (resample.c "initialised") */
 } orc_state;
 
 /* Window value at x in [0,1] by 4-point cubic interpolation of the table
@@ -147,17 +156,73 @@ static uint32_t gcd_u32(uint32_t a, uint32_t b) {
   return a;
 }
 
-/* Filter design for a fresh state (resample.c:605-702; the "started"/magic
- * branches at :727-782 are unreachable from src/index.ts and not restated). */
+/* History re-alignment after the filter length changed from old_taps (resample.c:703-782).
+ * A channel's line holds  history (taps-1 frames) ++ pending frames.  Restated per case:
+ *   not started : everything is silence;
+ *   longer      : put `pending` zeros in front (the reference's "remove the magic samples as
+ *                 if nothing had happened"), then either left-pad with zeros up to the new
+ *                 history length and move the position by half the padding, or -- if that
+ *                 augmented line is already long enough -- drop its first q frames and keep
+ *                 its last q frames as pending input, q = half the excess;
+ *   shorter     : drop the first d frames, the last d (plus the old pending ones) become
+ *                 pending input, d = half the difference. */
+static int fit_lines(orc_state *o, uint32_t old_taps) {
+  const uint32_t need = o->taps - 1 + ORC_BLOCK_IN;
+  if (need > o->line) {
+    float *fresh = (float *)calloc((size_t)o->channels * need, sizeof(float));
+    if (!fresh) return ORC_ERR_ALLOC;
+    for (uint32_t c = 0; c < o->channels && o->lines; c++)
+      memcpy(fresh + (size_t)c * need, o->lines + (size_t)c * o->line, sizeof(float) * o->line);
+    free(o->lines);
+    o->lines = fresh;
+    o->line = need;
+  }
+  if (!o->started) {
+    memset(o->lines, 0, sizeof(float) * (size_t)o->channels * o->line);
+    return ORC_OK;
+  }
+  if (o->taps == old_taps) return ORC_OK;
+  for (uint32_t c = 0; c < o->channels; c++) {
+    float *x = o->lines + (size_t)c * o->line;
+    const uint32_t p = o->pending[c];
+    if (o->taps > old_taps) {
+      const uint32_t have = old_taps - 1 + p; /* frames held */
+      const uint32_t aug = old_taps + 2 * p;  /* "olen", :741 */
+      float *b = (float *)calloc((size_t)aug + o->taps, sizeof(float));
+      if (!b) return ORC_ERR_ALLOC;
+      memcpy(b + p, x, sizeof(float) * have); /* b = p zeros ++ held frames: aug-1 frames */
+      o->pending[c] = 0;
+      if (o->taps > aug) { /* :748-758 */
+        const uint32_t lead = o->taps - aug;
+        memset(x, 0, sizeof(float) * lead);
+        memcpy(x + lead, b, sizeof(float) * (aug - 1));
+        o->pos[c] += lead / 2;
+      } else { /* :759-764 */
+        const uint32_t q = (aug - o->taps) / 2;
+        memcpy(x, b + q, sizeof(float) * (o->taps - 1 + q));
+        o->pending[c] = q;
+      }
+      free(b);
+    } else { /* :766-782 */
+      const uint32_t d = (old_taps - o->taps) / 2;
+      memmove(x, x + d, sizeof(float) * (o->taps - 1 + d + p));
+      o->pending[c] = d + p;
+    }
+  }
+  return ORC_OK;
+}
+
+/* Filter design (resample.c:605-702) followed by the history re-alignment (:703-782). */
 static int design(orc_state *o) {
   const orc_quality *q = &QUAL[o->quality];
+  const uint32_t old_taps = o->taps;
   o->step_int = o->num / o->den;
   o->step_frac = o->num % o->den;
   o->os = q->os;
   o->taps = q->taps;
   if (o->num > o->den) { /* decimating: stretch the filter, :618-635 */
     o->cutoff = q->bw_down * o->den / o->num;
-    if (scale_u32(&o->taps, o->taps, o->num, o->den)) return ORC_ERR_ALLOC;
+    if (scale_u32(&o->taps, o->taps, o->num, o->den)) goto fail;
     o->taps = ((o->taps - 1) & (~0x7u)) + 8;
     if (2 * o->den < o->num) o->os >>= 1;
     if (4 * o->den < o->num) o->os >>= 1;
@@ -170,14 +235,20 @@ static int design(orc_state *o) {
   /* smaller table wins, :647-648 (uint32 wrap-around arithmetic as in the reference) */
   int direct = (uint32_t)(o->taps * o->den) <= (uint32_t)(o->taps * o->os + 8) &&
                INT32_MAX / sizeof(float) / o->den >= o->taps;
+  uint32_t want;
   if (direct) {
-    o->table_len = o->taps * o->den;
+    want = o->taps * o->den;
   } else {
-    if ((INT32_MAX / sizeof(float) - 8) / o->os < o->taps) return ORC_ERR_ALLOC;
-    o->table_len = o->taps * o->os + 8;
+    if ((INT32_MAX / sizeof(float) - 8) / o->os < o->taps) goto fail;
+    want = o->taps * o->os + 8;
   }
-  o->table = (float *)malloc(sizeof(float) * o->table_len);
-  if (!o->table) return ORC_ERR_ALLOC;
+  if (want > o->table_cap) { /* grow-only allocation, :659-667 */
+    float *t = (float *)realloc(o->table, sizeof(float) * want);
+    if (!t) goto fail;
+    o->table = t;
+    o->table_cap = want;
+  }
+  o->table_len = want;
   if (direct) { /* one row of taps per output phase, :671-678 */
     for (uint32_t ph = 0; ph < o->den; ph++)
       for (int32_t j = 0; j < (int32_t)o->taps; j++)
@@ -190,9 +261,10 @@ static int design(orc_state *o) {
           tap_value(o->cutoff, (i / (float)o->os - o->taps / 2), o->taps, q->win);
     o->kind = o->quality > 8 ? K_INTERP_DOUBLE : K_INTERP_SINGLE;
   }
-  o->line = o->taps - 1 + ORC_BLOCK_IN;
-  o->lines = (float *)calloc((size_t)o->channels * o->line, sizeof(float));
-  return o->lines ? ORC_OK : ORC_ERR_ALLOC;
+  return fit_lines(o, old_taps);
+fail:
+  o->taps = old_taps; /* :785-791 */
+  return ORC_ERR_ALLOC;
 }
 
 void orc_free(orc_state *o) {
@@ -201,29 +273,70 @@ void orc_free(orc_state *o) {
   free(o->lines);
   free(o->pos);
   free(o->phase);
+  free(o->pending);
   free(o);
 }
 
-/* resample.c:794-866 */
-orc_state *orc_new(uint32_t channels, uint32_t in_rate, uint32_t out_rate, int quality,
-                   int *err) {
+/* resample.c:1107-1145: new ratio (reduced by the gcd), phase numerators rescaled to the
+ * new denominator, then the filter is redesigned if the state is live. */
+int orc_set_rate_frac(orc_state *o, uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate,
+                      uint32_t out_rate) {
+  if (ratio_num == 0 || ratio_den == 0) return ORC_ERR_INVALID;
+  if (o->in_rate == in_rate && o->out_rate == out_rate && o->num == ratio_num &&
+      o->den == ratio_den)
+    return ORC_OK;
+  const uint32_t old_den = o->den;
+  const uint32_t g = gcd_u32(ratio_num, ratio_den);
+  o->in_rate = in_rate;
+  o->out_rate = out_rate;
+  o->num = ratio_num / g;
+  o->den = ratio_den / g;
+  if (old_den > 0) {
+    for (uint32_t c = 0; c < o->channels; c++) {
+      if (scale_u32(&o->phase[c], o->phase[c], o->den, old_den)) return ORC_ERR_OVERFLOW;
+      if (o->phase[c] >= o->den) o->phase[c] = o->den - 1;
+    }
+  }
+  return o->live ? design(o) : ORC_OK;
+}
+
+/* resample.c:1084-1087 */
+int orc_set_rate(orc_state *o, uint32_t in_rate, uint32_t out_rate) {
+  return orc_set_rate_frac(o, in_rate, out_rate, in_rate, out_rate);
+}
+
+/* resample.c:1153-1163 */
+int orc_set_quality(orc_state *o, int quality) {
+  if (quality > 10 || quality < 0) return ORC_ERR_INVALID;
+  if (o->quality == quality) return ORC_OK;
+  o->quality = quality;
+  return o->live ? design(o) : ORC_OK;
+}
+
+/* resample.c:799-866 */
+orc_state *orc_new_frac(uint32_t channels, uint32_t ratio_num, uint32_t ratio_den,
+                        uint32_t in_rate, uint32_t out_rate, int quality, int *err) {
   int e = ORC_OK;
   orc_state *o = NULL;
-  if (channels == 0 || in_rate == 0 || out_rate == 0 || quality > 10 || quality < 0) {
+  if (channels == 0 || ratio_num == 0 || ratio_den == 0 || quality > 10 || quality < 0) {
     e = ORC_ERR_INVALID;
   } else if (!(o = (orc_state *)calloc(1, sizeof(*o)))) {
     e = ORC_ERR_ALLOC;
   } else {
-    uint32_t g = gcd_u32(in_rate, out_rate);
-    o->in_rate = in_rate;
-    o->out_rate = out_rate;
-    o->num = in_rate / g;
-    o->den = out_rate / g;
     o->channels = channels;
-    o->quality = quality;
+    o->quality = -1;
+    o->cutoff = 1.f;
     o->pos = (int32_t *)calloc(channels, sizeof(int32_t));
     o->phase = (uint32_t *)calloc(channels, sizeof(uint32_t));
-    e = (o->pos && o->phase) ? design(o) : ORC_ERR_ALLOC;
+    o->pending = (uint32_t *)calloc(channels, sizeof(uint32_t));
+    if (!(o->pos && o->phase && o->pending)) {
+      e = ORC_ERR_ALLOC;
+    } else {
+      orc_set_quality(o, quality);
+      orc_set_rate_frac(o, ratio_num, ratio_den, in_rate, out_rate);
+      e = design(o);
+      o->live = 1;
+    }
     if (e != ORC_OK) {
       orc_free(o);
       o = NULL;
@@ -231,6 +344,12 @@ orc_state *orc_new(uint32_t channels, uint32_t in_rate, uint32_t out_rate, int q
   }
   if (err) *err = e;
   return o;
+}
+
+/* resample.c:794-797 */
+orc_state *orc_new(uint32_t channels, uint32_t in_rate, uint32_t out_rate, int quality,
+                   int *err) {
+  return orc_new_frac(channels, in_rate, out_rate, in_rate, out_rate, quality, err);
 }
 
 /* float -> int16 with round-half-up in double and saturation (arch.h:208-209). */
@@ -307,41 +426,78 @@ static float fir_sample(const orc_state *o, const float *x, uint32_t phase) {
   }
 }
 
-/* One channel of one call: the <=160-in / <=1024-out block loop with history
- * shift (resample.c:968-1036 calling :878-902 calling the kernel loop shape
- * at :344-379).  Strided int16 in/out. */
+/* One run of the FIR over a channel line holding history ++ nin input frames, at most `cap`
+ * outputs, followed by the history shift (resample.c:878-902 around the kernel loop shape at
+ * :344-379).  Outputs go to `out` with `stride`: rounded to int16 (arch.h:208-209, as
+ * resample.c:1022 does from its stack buffer) or as they are (float entry).  Returns the
+ * number made; *used = input frames that entered the history. */
+static uint32_t run_block(orc_state *o, uint32_t c, uint32_t nin, uint32_t cap, void *out,
+                          uint32_t stride, int as_pcm, uint32_t *used_out) {
+  float *x = o->lines + (size_t)c * o->line;
+  int32_t pos = o->pos[c];
+  uint32_t phase = o->phase[c];
+  uint32_t made = 0;
+  o->started = 1;
+  while (!(pos >= (int32_t)nin || made >= cap)) {
+    const float v = fir_sample(o, x + pos, phase);
+    if (as_pcm)
+      ((int16_t *)out)[(size_t)made * stride] = to_pcm(v);
+    else
+      ((float *)out)[(size_t)made * stride] = v;
+    made++;
+    pos += o->step_int;
+    phase += o->step_frac;
+    if (phase >= o->den) {
+      phase -= o->den;
+      pos++;
+    }
+  }
+  uint32_t used = nin;
+  if (pos < (int32_t)nin) used = pos; /* output-bound: only `pos` frames count */
+  o->pos[c] = pos - (int32_t)used;
+  o->phase[c] = phase;
+  for (uint32_t j = 0; j + 1 < o->taps; j++) x[j] = x[j + used];
+  *used_out = used;
+  return made;
+}
+
+/* The pending ("magic") frames are input that is already in the line: run them as a block of
+ * their own and keep what was not consumed (resample.c:904-922). */
+static uint32_t drain_pending(orc_state *o, uint32_t c, uint32_t cap, void *out, uint32_t stride,
+                              int as_pcm) {
+  float *x = o->lines + (size_t)c * o->line;
+  uint32_t used = 0;
+  const uint32_t made = run_block(o, c, o->pending[c], cap, out, stride, as_pcm, &used);
+  o->pending[c] -= used;
+  for (uint32_t i = 0; i < o->pending[c]; i++) x[o->taps - 1 + i] = x[o->taps - 1 + i + used];
+  return made;
+}
+
+/* One channel of one call through the int16 entry point: blocks of at most (line - history)
+ * input frames -- 160 unless the filter has been shortened since -- and at most 1024 outputs,
+ * pending frames first (resample.c:968-1036).  Strided int16 in/out. */
 static void run_channel(orc_state *o, uint32_t c, const int16_t *in, uint32_t stride,
                         uint32_t *in_len, int16_t *out, uint32_t *out_len) {
   float *x = o->lines + (size_t)c * o->line;
   const uint32_t hist = o->taps - 1;
+  const uint32_t block_in = o->line - hist;
   uint32_t in_left = *in_len, out_left = *out_len;
   while (in_left && out_left) {
-    uint32_t nin = in_left > ORC_BLOCK_IN ? ORC_BLOCK_IN : in_left;
-    uint32_t nout_max = out_left > ORC_BLOCK_OUT ? ORC_BLOCK_OUT : out_left;
-    for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? (float)in[(size_t)j * stride] : 0.f;
-
-    int32_t pos = o->pos[c];
-    uint32_t phase = o->phase[c];
-    uint32_t made = 0;
-    while (!(pos >= (int32_t)nin || made >= nout_max)) {
-      out[(size_t)made * stride] = to_pcm(fir_sample(o, x + pos, phase));
-      made++;
-      pos += o->step_int;
-      phase += o->step_frac;
-      if (phase >= o->den) {
-        phase -= o->den;
-        pos++;
-      }
+    uint32_t room = out_left > ORC_BLOCK_OUT ? ORC_BLOCK_OUT : out_left;
+    uint32_t from_pending = 0, used = 0, made = 0;
+    if (o->pending[c]) {
+      from_pending = drain_pending(o, c, room, out, stride, 1);
+      room -= from_pending;
+      out_left -= from_pending;
     }
-    uint32_t used = nin;
-    if (pos < (int32_t)nin) used = pos; /* output-bound: only `pos` frames count */
-    o->pos[c] = pos - (int32_t)used;
-    o->phase[c] = phase;
-    for (uint32_t j = 0; j < hist; j++) x[j] = x[j + used];
-
+    if (!o->pending[c]) {
+      const uint32_t nin = in_left > block_in ? block_in : in_left;
+      for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? (float)in[(size_t)j * stride] : 0.f;
+      made = run_block(o, c, nin, room, out + (size_t)from_pending * stride, stride, 1, &used);
+    }
     in_left -= used;
     out_left -= made;
-    out += (size_t)made * stride;
+    out += (size_t)(from_pending + made) * stride;
     if (in) in += (size_t)used * stride;
   }
   *in_len -= in_left;
@@ -362,40 +518,30 @@ int orc_process_interleaved_int(orc_state *o, const int16_t *in, uint32_t *in_le
 
 /* One channel of one call through the FLOAT entry point (resample.c:927-963): input frames are
  * copied as they are, the FIR values are written unrounded, and -- unlike the int16 entry
- * point -- a block's output is limited only by the room left (resample.c:943), not by 1024. */
+ * point -- a block's output is limited only by the room left (resample.c:943), not by 1024;
+ * pending frames are drained once, up front, even when the call brings no input. */
 static void run_channel_float(orc_state *o, uint32_t c, const float *in, uint32_t stride,
                               uint32_t *in_len, float *out, uint32_t *out_len) {
   float *x = o->lines + (size_t)c * o->line;
   const uint32_t hist = o->taps - 1;
+  const uint32_t block_in = o->line - hist;
   uint32_t in_left = *in_len, out_left = *out_len;
-  while (in_left && out_left) {
-    uint32_t nin = in_left > ORC_BLOCK_IN ? ORC_BLOCK_IN : in_left;
-    uint32_t nout_max = out_left;
-    for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? in[(size_t)j * stride] : 0.f;
-
-    int32_t pos = o->pos[c];
-    uint32_t phase = o->phase[c];
-    uint32_t made = 0;
-    while (!(pos >= (int32_t)nin || made >= nout_max)) {
-      out[(size_t)made * stride] = fir_sample(o, x + pos, phase);
-      made++;
-      pos += o->step_int;
-      phase += o->step_frac;
-      if (phase >= o->den) {
-        phase -= o->den;
-        pos++;
-      }
+  if (o->pending[c]) {
+    const uint32_t m = drain_pending(o, c, out_left, out, stride, 0);
+    out_left -= m;
+    out += (size_t)m * stride;
+  }
+  if (!o->pending[c]) {
+    while (in_left && out_left) {
+      const uint32_t nin = in_left > block_in ? block_in : in_left;
+      uint32_t used = 0;
+      for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? in[(size_t)j * stride] : 0.f;
+      const uint32_t made = run_block(o, c, nin, out_left, out, stride, 0, &used);
+      in_left -= used;
+      out_left -= made;
+      out += (size_t)made * stride;
+      if (in) in += (size_t)used * stride;
     }
-    uint32_t used = nin;
-    if (pos < (int32_t)nin) used = pos;
-    o->pos[c] = pos - (int32_t)used;
-    o->phase[c] = phase;
-    for (uint32_t j = 0; j < hist; j++) x[j] = x[j + used];
-
-    in_left -= used;
-    out_left -= made;
-    out += (size_t)made * stride;
-    if (in) in += (size_t)used * stride;
   }
   *in_len -= in_left;
   *out_len -= out_left;
@@ -409,6 +555,46 @@ int orc_process_interleaved_float(orc_state *o, const float *in, uint32_t *in_le
     *in_len = want_in;
     *out_len = want_out;
     run_channel_float(o, c, in ? in + c : NULL, o->channels, in_len, out + c, out_len);
+  }
+  return ORC_OK;
+}
+
+/* resample.c:1089-1093, 1147-1151, 1165-1168 */
+void orc_get_rate(const orc_state *o, uint32_t *in_rate, uint32_t *out_rate) {
+  *in_rate = o->in_rate;
+  *out_rate = o->out_rate;
+}
+void orc_get_ratio(const orc_state *o, uint32_t *num, uint32_t *den) {
+  *num = o->num;
+  *den = o->den;
+}
+int orc_get_quality(const orc_state *o) { return o->quality; }
+
+/* resample.c:1190-1198 */
+int orc_input_latency(const orc_state *o) { return o->taps / 2; }
+int orc_output_latency(const orc_state *o) {
+  return ((o->taps / 2) * o->den + (o->num >> 1)) / o->num;
+}
+
+/* resample.c:1200-1206: start half a filter in, so the first output is not the filter's ramp-up */
+int orc_skip_zeros(orc_state *o) {
+  for (uint32_t c = 0; c < o->channels; c++) o->pos[c] = o->taps / 2;
+  return ORC_OK;
+}
+
+/* resample.c:1208-1220 */
+int orc_reset_mem(orc_state *o) {
+  for (uint32_t c = 0; c < o->channels; c++) {
+    o->pos[c] = 0;
+    o->pending[c] = 0;
+    o->phase[c] = 0;
+  }
+  /* the reference clears the first channels*(taps-1) floats of its buffer as one run; with a
+     per-channel stride that is only every channel's history when there is one channel.  The
+     frames it leaves behind in the other channels' histories are a quirk we restate. */
+  {
+    const size_t n = (size_t)o->channels * (o->taps - 1);
+    memset(o->lines, 0, sizeof(float) * n);
   }
   return ORC_OK;
 }
@@ -433,6 +619,13 @@ void orc_position(const orc_state *o, int32_t *pos, uint32_t *phase) {
 void orc_history(const orc_state *o, uint32_t c, float *dst) {
   memcpy(dst, o->lines + (size_t)c * o->line, sizeof(float) * (o->taps - 1));
 }
+/* Pending ("magic") frame count of channel 0 and, if dst, channel c's pending frames. */
+uint32_t orc_pending(const orc_state *o, uint32_t c, float *dst) {
+  if (dst)
+    memcpy(dst, o->lines + (size_t)c * o->line + (o->taps - 1), sizeof(float) * o->pending[c]);
+  return o->pending[c];
+}
+uint32_t orc_block_in(const orc_state *o) { return o->line - (o->taps - 1); }
 
 /* resample.c:1222-1239 */
 const char *orc_strerror(int err) {

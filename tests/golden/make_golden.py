@@ -206,6 +206,96 @@ def float_cases():
     return rows
 
 
+CONTROL_RATES = [8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000]
+
+
+def control_input(op, ch):
+    """Input block of a control-script processing op: LCG int16, or the same scaled to [-1, 1)."""
+    kind, frames, _cap, seed = op[:4]
+    if kind in ("int_null", "float_null"):
+        return None
+    pcm = orc.lcg_pcm(frames * ch, seed).reshape(frames, ch)
+    if kind == "int":
+        return pcm
+    return (pcm.astype(np.float32) / np.float32(32768.0)).reshape(frames, ch)
+
+
+def apply_op(eng, op, ch):
+    """Run one op of a control script on `eng` (Reference, Oracle or the HIP mirror: same method
+    names).  Returns (row, output-or-None); row = what the golden file stores for the op."""
+    kind = op[0]
+    out = None
+    if kind in ("int", "float", "int_null", "float_null"):
+        x = control_input(op, ch)
+        fn = eng.process if kind.startswith("int") else eng.process_float
+        if x is None:
+            out, used = fn(None, op[2], null_frames=op[1])
+        else:
+            out, used = fn(x, op[2])
+        res = [int(used), int(out.shape[0]), sha1(out)[:16]]
+    elif kind == "rate":
+        res = [eng.set_rate(op[1], op[2])]
+    elif kind == "ratefrac":
+        res = [eng.set_rate_frac(op[1], op[2], op[3], op[4])]
+    elif kind == "quality":
+        res = [eng.set_quality(op[1])]
+    elif kind == "skip":
+        res = [eng.skip_zeros()]
+    elif kind == "reset":
+        res = [eng.reset_mem()]
+    else:
+        raise ValueError(kind)
+    pos, ph = eng.position()
+    state = [int(pos), int(ph), int(len(eng.pending())), int(eng.taps), int(eng.input_latency()),
+             int(eng.output_latency())] + [int(v) for v in eng.rate()] + [int(v) for v in eng.ratio()]
+    return res + state, out
+
+
+def control_cases(n_scripts=40):
+    """Mid-stream control (reference deps/speex/resample.c:703-782, 904-922, 1084-1220): random
+    scripts of process / set_rate / set_rate_frac / set_quality / skip_zeros / reset_mem ops run
+    on the native reference.  Stored: the ops and, per op, return code or (used, produced,
+    digest) plus the visible state (position, phase, pending "magic" frames, filter length,
+    latencies, rates, ratio)."""
+    rows = []
+    for k in range(n_scripts):
+        r = np.random.RandomState(9000 + k)
+        ch = int(r.choice([1, 2, 2, 3, 8]))
+        i, o = int(r.choice(CONTROL_RATES)), int(r.choice(CONTROL_RATES))
+        q = int(r.randint(0, 11))
+        ref = orc.Reference(ch, i, o, q)
+        ops, results = [], []
+        for step in range(24):
+            pick = r.randint(0, 12)
+            if pick < 6 or step == 0:
+                frames = int(r.choice([0, 1, 7, 100, 160, 161, 500, 2000, 5000]))
+                full = int(np.ceil(frames * ref.den / ref.num)) + 2
+                cap = [full, full // 2, int(r.randint(0, full + 5)), 0][int(r.choice([0, 0, 1, 2, 2, 3]))]
+                kind = "int" if r.rand() < 0.6 else "float"
+                if r.rand() < 0.08:
+                    kind += "_null"
+                op = [kind, frames, int(cap), int(r.randint(1, 1 << 30))]
+            elif pick < 8:
+                op = ["rate", int(r.choice(CONTROL_RATES)), int(r.choice(CONTROL_RATES))]
+            elif pick == 8:
+                n, d = (160, 147) if r.rand() < 0.3 else (int(r.randint(1, 13)), int(r.randint(1, 13)))
+                op = ["ratefrac", n, d, n * 1000, d * 1000]
+            elif pick == 9:
+                op = ["quality", int(r.randint(0, 11))]
+            elif pick == 10:
+                op = ["skip"]
+            else:
+                op = ["reset"]
+            row, _ = apply_op(ref, op, ch)
+            ops.append(op)
+            results.append(row)
+        rows.append(dict(name="ctl_%02d" % k, channels=ch, in_rate=i, out_rate=o, quality=q, ops=ops,
+                         results=results))
+    n_pending = sum(1 for c in rows for res in c["results"] if res[-8] > 0)
+    print("control scripts: %d, ops with pending frames afterwards: %d" % (len(rows), n_pending))
+    return rows
+
+
 def resource_cases():
     """The reference's own fixtures (resources/*.pcm; read whole, header and all, like
     src/test.ts:29).  Only digests are stored; the test needs /root/reference to re-run them."""
@@ -260,7 +350,8 @@ def main():
         sources=["oracle/_ref/libspeexref.so (reference deps/speex/resample.c, -DFLOATING_POINT "
                  "-DOUTSIDE_SPEEX)", "reference app/speex_wasm.js via node"],
         lcg="s=s*1664525+1013904223 mod 2^32; sample=int16(s>>16); seed per case",
-        cases=cases, planner=planner_cases(), resources=resource_cases(), float_cases=float_cases())
+        cases=cases, planner=planner_cases(), resources=resource_cases(), float_cases=float_cases(),
+        control_cases=control_cases())
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     print("wrote golden.json: %d cases, %d planner sets, %d resource rows" %
