@@ -88,6 +88,42 @@ SPEEXHIP_API int speexhip_resampler_process_interleaved_float(SpeexHipResamplerS
 SPEEXHIP_API void speexhip_resampler_get_rate(SpeexHipResamplerState *st, uint32_t *in_rate,
                                               uint32_t *out_rate);
 
+/* ------------------------------------------------------------------------------------------
+ * The rest of the reference's C API around the path: mid-stream control.
+ * Not reachable from src/index.ts, but part of deps/speex/speex_resampler.h.  A change of the
+ * filter length keeps the stream continuous exactly as the reference does: the history is
+ * re-aligned and, when the filter gets shorter, the frames that no longer fit are kept as
+ * pending input ("magic samples", resample.c:727-782, 904-922).  These calls wait for the
+ * device (they touch the stream history) -- control plane, not hot path.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces speex_resampler_init_frac (speex_resampler.h:133-150, resample.c:799). */
+SPEEXHIP_API SpeexHipResamplerState *speexhip_resampler_init_frac(uint32_t nb_channels,
+                                                                  uint32_t ratio_num, uint32_t ratio_den,
+                                                                  uint32_t in_rate, uint32_t out_rate,
+                                                                  int quality, int *err);
+/* Replace speex_resampler_set_rate / set_rate_frac / get_ratio (speex_resampler.h:223-262,
+ * resample.c:1084-1151).  OVERFLOW when a phase numerator cannot be carried to the new
+ * denominator (the state is then left unchanged; the reference leaves it half-updated). */
+SPEEXHIP_API int speexhip_resampler_set_rate(SpeexHipResamplerState *st, uint32_t in_rate, uint32_t out_rate);
+SPEEXHIP_API int speexhip_resampler_set_rate_frac(SpeexHipResamplerState *st, uint32_t ratio_num,
+                                                  uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate);
+SPEEXHIP_API void speexhip_resampler_get_ratio(SpeexHipResamplerState *st, uint32_t *ratio_num,
+                                               uint32_t *ratio_den);
+/* Replace speex_resampler_set_quality / get_quality (speex_resampler.h:264-277, resample.c:1153-1168). */
+SPEEXHIP_API int speexhip_resampler_set_quality(SpeexHipResamplerState *st, int quality);
+SPEEXHIP_API void speexhip_resampler_get_quality(SpeexHipResamplerState *st, int *quality);
+/* Replace speex_resampler_get_input_latency / get_output_latency (speex_resampler.h:305-315,
+ * resample.c:1190-1198). */
+SPEEXHIP_API int speexhip_resampler_get_input_latency(SpeexHipResamplerState *st);
+SPEEXHIP_API int speexhip_resampler_get_output_latency(SpeexHipResamplerState *st);
+/* Replace speex_resampler_skip_zeros / reset_mem (speex_resampler.h:317-332,
+ * resample.c:1200-1220).  reset_mem restates the reference's multi-channel behaviour: its
+ * single memset run covers channels*(filt_len-1) floats of a buffer whose channel lines are
+ * mem_alloc_size apart, so only the first channel(s) are silenced. */
+SPEEXHIP_API int speexhip_resampler_skip_zeros(SpeexHipResamplerState *st);
+SPEEXHIP_API int speexhip_resampler_reset_mem(SpeexHipResamplerState *st);
+
 /* Replaces speex_resampler_strerror (speex_resampler.h:338, resample.c:1222-1239); same
  * strings for codes 0..4, the reference's "Unknown error..." text for 5 and out-of-range
  * codes, and a HIP message for SPEEXHIP_ERR_DEVICE. */
@@ -134,13 +170,15 @@ typedef struct SpeexHipInfo {
   int32_t last_sample;           /* stream position, resample.c:135 */
   uint32_t samp_frac_num;        /* stream phase, resample.c:136 */
   int32_t device;                /* HIP device ordinal the state lives on */
+  uint32_t magic_samples;        /* pending frames buffered after the history, resample.c:137 */
+  uint32_t block_in;             /* frames per block: mem_alloc_size-(filt_len-1), resample.c:935 */
 } SpeexHipInfo;
 
 SPEEXHIP_API int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info);
 
 /* Copies the last filt_len-1 consumed frames (interleaved float, the reference's `mem`: what
- * the next call's first outputs are computed from; resample.c:898-899) to the host.  dst holds
- * (filt_len-1)*ch floats. */
+ * the next call's first outputs are computed from; resample.c:898-899) followed by the
+ * magic_samples pending frames to the host.  dst holds (filt_len-1+magic_samples)*ch floats. */
 SPEEXHIP_API int speexhip_resampler_get_history(SpeexHipResamplerState *st, float *dst);
 
 /* Batched streams: n_streams independent resamplers with one shared (rates, quality,
@@ -162,6 +200,14 @@ SPEEXHIP_API int speexhip_batch_process_interleaved_float_device(
     SpeexHipBatch *b, const float *d_in, uint64_t in_stream_stride, uint32_t *in_len, float *d_out,
     uint64_t out_stream_stride, uint32_t *out_len, void *hip_stream);
 
+/* Mid-stream control for every stream of a batch (same semantics as the single-stream calls). */
+SPEEXHIP_API int speexhip_batch_set_rate_frac(SpeexHipBatch *b, uint32_t ratio_num, uint32_t ratio_den,
+                                              uint32_t in_rate, uint32_t out_rate);
+SPEEXHIP_API int speexhip_batch_set_quality(SpeexHipBatch *b, int quality);
+SPEEXHIP_API int speexhip_batch_skip_zeros(SpeexHipBatch *b);
+SPEEXHIP_API int speexhip_batch_reset_mem(SpeexHipBatch *b);
+SPEEXHIP_API int speexhip_batch_get_history(SpeexHipBatch *b, uint32_t stream, float *dst);
+
 /* ------------------------------------------------------------------------------------------
  * Host-only pieces of the path, callable without a GPU (used by the CPU test-suite).
  * ---------------------------------------------------------------------------------------- */
@@ -172,6 +218,11 @@ SPEEXHIP_API int speexhip_batch_process_interleaved_float_device(
 SPEEXHIP_API int speexhip_design_filter(uint32_t in_rate, uint32_t out_rate, int quality,
                                         SpeexHipInfo *info, float *table, uint32_t table_capacity);
 
+/* Same with the ratio given separately from the nominal rates (init_frac / set_rate_frac). */
+SPEEXHIP_API int speexhip_design_filter_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate,
+                                             uint32_t out_rate, int quality, SpeexHipInfo *info,
+                                             float *table, uint32_t table_capacity);
+
 /* One call of the stream bookkeeping (resample.c:878-902 inside the block loop :988-1030) in
  * closed form: given in_len frames, out_cap frames of room and the position (*last_sample,
  * *samp_frac_num), returns frames consumed / produced and advances the position. */
@@ -179,6 +230,24 @@ SPEEXHIP_API int speexhip_plan_call(uint32_t num_rate, uint32_t den_rate, uint32
                                     uint32_t out_cap, int32_t *last_sample,
                                     uint32_t *samp_frac_num, uint32_t *consumed,
                                     uint32_t *produced);
+
+/* The same for any entry point and state: float_entry selects the float call's rules
+ * (resample.c:927-963: no 1024-output cap, pending frames drained once up front) instead of
+ * the int16 call's (:968-1036); block_in = frames per block (160 unless a filter has been
+ * shortened mid-stream); *magic_samples = pending frames, consumed ahead of the input. */
+SPEEXHIP_API int speexhip_plan_call_ex(uint32_t num_rate, uint32_t den_rate, uint32_t in_len,
+                                       uint32_t out_cap, int float_entry, uint32_t block_in,
+                                       int32_t *last_sample, uint32_t *samp_frac_num,
+                                       uint32_t *magic_samples, uint32_t *consumed, uint32_t *produced);
+
+/* What a filter-length change does to a started stream (resample.c:727-782): afterwards the
+ * stream holds new_filt_len-1+*new_magic frames, frame j being old frame j+*shift where that
+ * exists (the old line has old_filt_len-1+magic frames) and silence elsewhere; last_sample
+ * moves by *last_delta.  *phase (may be NULL) is carried from old_den to new_den
+ * (resample.c:1130-1139); returns OVERFLOW if that is not representable. */
+SPEEXHIP_API int speexhip_plan_filter_change(uint32_t old_filt_len, uint32_t new_filt_len, uint32_t magic,
+                                             int64_t *shift, uint32_t *new_magic, int32_t *last_delta,
+                                             uint32_t *phase, uint32_t old_den, uint32_t new_den);
 
 /* Library build info: "speexhip <version> gfx950". */
 SPEEXHIP_API const char *speexhip_version(void);

@@ -28,6 +28,59 @@ SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channels, uint32_t i
   return st;
 }
 
+SpeexHipResamplerState *speexhip_resampler_init_frac(uint32_t nb_channels, uint32_t ratio_num,
+                                                     uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate,
+                                                     int quality, int *err) {
+  Batch *b = Batch::create_frac(1, nb_channels, ratio_num, ratio_den, in_rate, out_rate, quality, err);
+  if (b == nullptr) return nullptr;
+  SpeexHipResamplerState *st = new (std::nothrow) SpeexHipResamplerState_{b};
+  if (st == nullptr) {
+    delete b;
+    if (err) *err = SPEEXHIP_ERR_ALLOC_FAILED;
+  }
+  return st;
+}
+
+int speexhip_resampler_set_rate(SpeexHipResamplerState *st, uint32_t in_rate, uint32_t out_rate) {
+  return st ? st->batch->set_rate_frac(in_rate, out_rate, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG;
+}
+int speexhip_resampler_set_rate_frac(SpeexHipResamplerState *st, uint32_t ratio_num, uint32_t ratio_den,
+                                     uint32_t in_rate, uint32_t out_rate) {
+  return st ? st->batch->set_rate_frac(ratio_num, ratio_den, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG;
+}
+void speexhip_resampler_get_ratio(SpeexHipResamplerState *st, uint32_t *ratio_num, uint32_t *ratio_den) {
+  *ratio_num = st->batch->filter().num;
+  *ratio_den = st->batch->filter().den;
+}
+int speexhip_resampler_set_quality(SpeexHipResamplerState *st, int quality) {
+  return st ? st->batch->set_quality(quality) : SPEEXHIP_ERR_INVALID_ARG;
+}
+void speexhip_resampler_get_quality(SpeexHipResamplerState *st, int *quality) {
+  *quality = st->batch->filter().quality;
+}
+int speexhip_resampler_get_input_latency(SpeexHipResamplerState *st) { return st->batch->input_latency(); }
+int speexhip_resampler_get_output_latency(SpeexHipResamplerState *st) { return st->batch->output_latency(); }
+int speexhip_resampler_skip_zeros(SpeexHipResamplerState *st) {
+  return st ? st->batch->skip_zeros() : SPEEXHIP_ERR_INVALID_ARG;
+}
+int speexhip_resampler_reset_mem(SpeexHipResamplerState *st) {
+  return st ? st->batch->reset_mem() : SPEEXHIP_ERR_INVALID_ARG;
+}
+
+int speexhip_batch_set_rate_frac(SpeexHipBatch *b, uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate,
+                                 uint32_t out_rate) {
+  return b ? b->batch->set_rate_frac(ratio_num, ratio_den, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG;
+}
+int speexhip_batch_set_quality(SpeexHipBatch *b, int quality) {
+  return b ? b->batch->set_quality(quality) : SPEEXHIP_ERR_INVALID_ARG;
+}
+int speexhip_batch_skip_zeros(SpeexHipBatch *b) { return b ? b->batch->skip_zeros() : SPEEXHIP_ERR_INVALID_ARG; }
+int speexhip_batch_reset_mem(SpeexHipBatch *b) { return b ? b->batch->reset_mem() : SPEEXHIP_ERR_INVALID_ARG; }
+int speexhip_batch_get_history(SpeexHipBatch *b, uint32_t stream, float *dst) {
+  if (b == nullptr || dst == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return b->batch->history(stream, dst);
+}
+
 void speexhip_resampler_destroy(SpeexHipResamplerState *st) {
   if (st == nullptr) return;
   delete st->batch;
@@ -144,8 +197,15 @@ int speexhip_batch_process_interleaved_int_device(SpeexHipBatch *b, const int16_
 
 int speexhip_design_filter(uint32_t in_rate, uint32_t out_rate, int quality, SpeexHipInfo *info,
                            float *table, uint32_t table_capacity) {
+  if (in_rate == 0 || out_rate == 0) return SPEEXHIP_ERR_INVALID_ARG;
+  return speexhip_design_filter_frac(in_rate, out_rate, in_rate, out_rate, quality, info, table, table_capacity);
+}
+
+int speexhip_design_filter_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate,
+                                int quality, SpeexHipInfo *info, float *table, uint32_t table_capacity) {
   speexhip::FilterSpec f;
-  const int rc = speexhip::design_filter(in_rate, out_rate, quality, &f, table != nullptr);
+  const int rc = speexhip::design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality, &f,
+                                              table != nullptr);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   if (info != nullptr) {
     std::memset(info, 0, sizeof(*info));
@@ -183,6 +243,45 @@ int speexhip_plan_call(uint32_t num_rate, uint32_t den_rate, uint32_t in_len, ui
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-const char *speexhip_version(void) { return "speexhip 0.1.0 gfx950"; }
+int speexhip_plan_call_ex(uint32_t num_rate, uint32_t den_rate, uint32_t in_len, uint32_t out_cap,
+                          int float_entry, uint32_t block_in, int32_t *last_sample, uint32_t *samp_frac_num,
+                          uint32_t *magic_samples, uint32_t *consumed, uint32_t *produced) {
+  if (num_rate == 0 || den_rate == 0 || block_in == 0 || last_sample == nullptr ||
+      samp_frac_num == nullptr || magic_samples == nullptr)
+    return SPEEXHIP_ERR_INVALID_ARG;
+  speexhip::StreamPos p;
+  p.last = *last_sample;
+  p.frac = *samp_frac_num;
+  p.magic = *magic_samples;
+  speexhip::EntryRules rules;
+  rules.block_in = block_in;
+  rules.float_entry = float_entry != 0;
+  const speexhip::CallPlan plan = speexhip::plan_call(num_rate, den_rate, in_len, out_cap, p, rules);
+  *last_sample = plan.end.last;
+  *samp_frac_num = plan.end.frac;
+  *magic_samples = plan.end.magic;
+  if (consumed) *consumed = plan.consumed;
+  if (produced) *produced = plan.produced;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int speexhip_plan_filter_change(uint32_t old_filt_len, uint32_t new_filt_len, uint32_t magic, int64_t *shift,
+                                uint32_t *new_magic, int32_t *last_delta, uint32_t *phase, uint32_t old_den,
+                                uint32_t new_den) {
+  if (old_filt_len == 0 || new_filt_len == 0 || shift == nullptr || new_magic == nullptr ||
+      last_delta == nullptr)
+    return SPEEXHIP_ERR_INVALID_ARG;
+  if (phase != nullptr) {
+    if (old_den == 0 || new_den == 0) return SPEEXHIP_ERR_INVALID_ARG;
+    if (!speexhip::scale_phase(phase, new_den, old_den)) return SPEEXHIP_ERR_OVERFLOW;
+  }
+  const speexhip::Realign r = speexhip::realign_history(old_filt_len, new_filt_len, magic);
+  *shift = r.shift;
+  *new_magic = r.new_magic;
+  *last_delta = r.last_delta;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+const char *speexhip_version(void) { return "speexhip 0.2.0 gfx950"; }
 
 }  // extern "C"

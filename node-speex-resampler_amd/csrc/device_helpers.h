@@ -38,12 +38,13 @@ struct PerLoad {
   static constexpr int value = 16 / sizeof(T);
 };
 
-// The next call's history: the last taps-1 frames of (history ++ input[0..consumed)), i.e.
-// reference resample.c:898-899 applied once over the whole call.
+// The next call's history: hist_keep frames of (history ++ input) starting `consumed` frames in,
+// i.e. reference resample.c:898-899 (and :914-919 for pending frames) applied once over the
+// whole call.
 template <typename T>
-__device__ __forceinline__ void roll_history(uint32_t taps, uint32_t channels, const StreamDesc &d) {
-  const uint32_t hist_frames = taps - 1;
-  const uint32_t total = hist_frames * channels;
+__device__ __forceinline__ void roll_history(uint32_t channels, const StreamDesc &d) {
+  const uint32_t hist_frames = d.hist_frames;
+  const uint32_t total = d.hist_keep * channels;
   for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
     const uint32_t h = i / channels, c = i - h * channels;
     const int64_t v = static_cast<int64_t>(d.consumed) + h;
@@ -87,14 +88,14 @@ struct WindowGeom {
 };
 
 template <typename T>
-__device__ __forceinline__ WindowGeom window_geom(const StreamDesc &d, uint32_t taps, uint32_t channels,
+__device__ __forceinline__ WindowGeom window_geom(const StreamDesc &d, uint32_t channels,
                                                   uint32_t num, uint32_t tail_frames, uint32_t m_lo,
                                                   uint32_t m_cnt, uint32_t pad = 0) {
   constexpr int GS = PerLoad<T>::value;
   WindowGeom w;
   w.pad = pad;
   w.period_elems = num * channels;
-  w.hist_elems = static_cast<int64_t>(taps - 1) * channels;
+  w.hist_elems = static_cast<int64_t>(d.hist_frames) * channels;
   w.in_elems = static_cast<int64_t>(d.in_frames) * channels;
   const int64_t q_lo =
       (static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * num) * channels - w.hist_elems;

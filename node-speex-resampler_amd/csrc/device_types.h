@@ -6,11 +6,12 @@ namespace speexhip {
 
 // One stream's share of one processing call.  V = history ++ input is the virtual frame
 // sequence the FIR windows index (history = the last taps-1 consumed frames, zeros at start:
-// reference resample.c:721-725, 898-899).
+// reference resample.c:721-725, 898-899; `consumed` counts frames of V past the history, so it
+// includes pending frames drained by this call).
 struct StreamDesc {
   const void *in;       // interleaved s16 or f32 (the call's sample type), in_frames frames
                         // (device); NULL = silence
-  const float *hist;    // (taps-1) frames, interleaved, always float like the reference's `mem`
+  const float *hist;    // hist_frames frames, interleaved, always float like the reference's `mem`
   void *out;            // interleaved s16 or f32, room for n_out frames (device)
   float *hist_next;     // where this call leaves the next call's history
   uint32_t in_frames;
@@ -21,6 +22,10 @@ struct StreamDesc {
   uint32_t k_shift;     // phase_index_of(frac0): canonical phase index of output 0
   int32_t base_shift;   // last0 - (k_shift*num) div den  (tiled kernel's period origin)
   uint32_t tile_begin;  // first tile of this stream in the launch's flat tile list
+  uint32_t hist_frames; // frames in `hist`: taps-1, plus the pending ("magic") frames a filter
+                        // change left buffered (reference resample.c:727-782) -- they are input
+                        // that is already in the line, so V simply starts with a longer history
+  uint32_t hist_keep;   // frames this call leaves in hist_next: taps-1 + pending frames remaining
 };
 
 static const int kMaxPackedStreams = 8;

@@ -26,10 +26,15 @@ const char *last_device_error() { return g_last_error.c_str(); }
 
 Batch *Batch::create(uint32_t n_streams, uint32_t channels, uint32_t in_rate, uint32_t out_rate,
                      int quality, int *err) {
+  return create_frac(n_streams, channels, in_rate, out_rate, in_rate, out_rate, quality, err);
+}
+
+Batch *Batch::create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_num, uint32_t ratio_den,
+                          uint32_t in_rate, uint32_t out_rate, int quality, int *err) {
   int e = SPEEXHIP_ERR_SUCCESS;
   Batch *b = nullptr;
   // argument checks first, like the reference (resample.c:804-809)
-  if (n_streams == 0 || channels == 0 || in_rate == 0 || out_rate == 0 || quality > 10 ||
+  if (n_streams == 0 || channels == 0 || ratio_num == 0 || ratio_den == 0 || quality > 10 ||
       quality < 0) {
     e = SPEEXHIP_ERR_INVALID_ARG;
   } else {
@@ -39,7 +44,7 @@ Batch *Batch::create(uint32_t n_streams, uint32_t channels, uint32_t in_rate, ui
     } else {
       b->n_streams_ = n_streams;
       b->channels_ = channels;
-      e = design_filter(in_rate, out_rate, quality, &b->filter_);
+      e = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality, &b->filter_);
       if (e == SPEEXHIP_ERR_SUCCESS) e = b->setup();
       if (e != SPEEXHIP_ERR_SUCCESS) {
         delete b;
@@ -68,15 +73,43 @@ int Batch::setup() {
   if (m != nullptr && std::strcmp(m, "exact") == 0) mode_ = SPEEXHIP_MODE_EXACT;
 
   pos_.assign(n_streams_, StreamPos());
+  started_.assign(n_streams_, 0);
+  int rc = install_filter(std::vector<float>(), filter_.taps - 1);  // resample.c:721-725: silence
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  if (n_streams_ > static_cast<uint32_t>(kMaxPackedStreams)) {
+    const size_t ring_bytes = sizeof(StreamDesc) * n_streams_ * kRing;
+    HIP_TRY(hipHostMalloc(&h_ring_, ring_bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&d_ring_, ring_bytes));
+    for (int i = 0; i < kRing; i++) HIP_TRY(hipEventCreateWithFlags(&ring_done_[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+// (Re)build everything on the device that depends on filter_: the sinc table, the fast
+// kernels' tap rows and the history buffers (hist = all streams' lines, hist_frames_cap frames
+// each, interleaved; empty = silence).
+int Batch::install_filter(const std::vector<float> &hist, uint32_t hist_frames_cap) {
+  (void)hipFree(d_table_);
+  (void)hipFree(d_hist_[0]);
+  (void)hipFree(d_hist_[1]);
+  (void)hipFree(d_period_rows_);
+  (void)hipFree(d_slide_rows_);
+  d_table_ = d_hist_[0] = d_hist_[1] = d_period_rows_ = d_slide_rows_ = nullptr;
+  line_ = std::max(line_, filter_.taps - 1 + kBlockIn);  // grow-only, resample.c:709-720
+
   HIP_TRY(hipMalloc(&d_table_, sizeof(float) * filter_.table_len));
   HIP_TRY(hipMemcpy(d_table_, filter_.table.data(), sizeof(float) * filter_.table_len,
                     hipMemcpyHostToDevice));
-  hist_elems_ = static_cast<size_t>(filter_.taps - 1) * channels_;
+  hist_elems_ = static_cast<size_t>(hist_frames_cap) * channels_;
   const size_t hist_bytes = std::max<size_t>(hist_elems_ * n_streams_ * sizeof(float), 16);
   for (int i = 0; i < 2; i++) {
     HIP_TRY(hipMalloc(&d_hist_[i], hist_bytes));
-    HIP_TRY(hipMemset(d_hist_[i], 0, hist_bytes));  // resample.c:721-725: history starts silent
+    HIP_TRY(hipMemset(d_hist_[i], 0, hist_bytes));
   }
+  hist_cur_ = 0;
+  if (!hist.empty())
+    HIP_TRY(hipMemcpy(d_hist_[0], hist.data(), hist_elems_ * n_streams_ * sizeof(float), hipMemcpyHostToDevice));
   exact_geo_ = exact_geometry(filter_, channels_, kLdsBudget);
   period_ = plan_period(filter_, channels_, kLdsBudget);
   if (period_.usable) {
@@ -94,13 +127,107 @@ int Batch::setup() {
   } else {
     slide_.usable = false;
   }
-  if (n_streams_ > static_cast<uint32_t>(kMaxPackedStreams)) {
-    const size_t ring_bytes = sizeof(StreamDesc) * n_streams_ * kRing;
-    HIP_TRY(hipHostMalloc(&h_ring_, ring_bytes, hipHostMallocDefault));
-    HIP_TRY(hipMalloc(&d_ring_, ring_bytes));
-    for (int i = 0; i < kRing; i++) HIP_TRY(hipEventCreateWithFlags(&ring_done_[i], hipEventDisableTiming));
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int Batch::fetch_history(std::vector<float> *host) {
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(hipDeviceSynchronize());  // every enqueued call has left its history
+  host->assign(hist_elems_ * n_streams_, 0.f);
+  if (!host->empty())
+    HIP_TRY(hipMemcpy(host->data(), d_hist_[hist_cur_], host->size() * sizeof(float), hipMemcpyDeviceToHost));
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+// Switch every stream to the filter `next` (already designed): the tail of update_filter(),
+// resample.c:703-782, per stream, on the host -- this is rare control-plane work.
+int Batch::adopt_filter(const FilterSpec &next) {
+  std::vector<float> old;
+  int rc = fetch_history(&old);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  const uint32_t old_taps = filter_.taps, new_taps = next.taps;
+  const size_t old_stride = hist_elems_;
+  std::vector<Realign> moves(n_streams_);
+  uint32_t cap_frames = new_taps - 1;
+  for (uint32_t s = 0; s < n_streams_; s++) {
+    if (started_[s]) moves[s] = realign_history(old_taps, new_taps, pos_[s].magic);
+    cap_frames = std::max(cap_frames, new_taps - 1 + (started_[s] ? moves[s].new_magic : pos_[s].magic));
   }
-  HIP_TRY(hipDeviceSynchronize());
+  std::vector<float> fresh(static_cast<size_t>(cap_frames) * channels_ * n_streams_, 0.f);
+  for (uint32_t s = 0; s < n_streams_; s++) {
+    if (!started_[s]) continue;  // resample.c:721-726: nothing processed yet -> silence
+    const int64_t have = static_cast<int64_t>(old_taps - 1) + pos_[s].magic;
+    const uint32_t keep = new_taps - 1 + moves[s].new_magic;
+    const float *src = old.data() + s * old_stride;
+    float *dst = fresh.data() + static_cast<size_t>(s) * cap_frames * channels_;
+    for (uint32_t j = 0; j < keep; j++) {
+      const int64_t from = static_cast<int64_t>(j) + moves[s].shift;
+      if (from < 0 || from >= have) continue;
+      std::memcpy(dst + static_cast<size_t>(j) * channels_, src + from * channels_, sizeof(float) * channels_);
+    }
+    pos_[s].magic = moves[s].new_magic;
+    pos_[s].last += moves[s].last_delta;
+  }
+  filter_ = next;
+  return install_filter(fresh, cap_frames);
+}
+
+int Batch::set_rate_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate) {
+  if (ratio_num == 0 || ratio_den == 0) return SPEEXHIP_ERR_INVALID_ARG;
+  // resample.c:1116-1117 (compares the given ratio with the REDUCED one it stores, as there)
+  if (filter_.in_rate == in_rate && filter_.out_rate == out_rate && filter_.num == ratio_num &&
+      filter_.den == ratio_den)
+    return SPEEXHIP_ERR_SUCCESS;
+  FilterSpec next;
+  int rc = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, filter_.quality, &next);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  // phase numerators move to the new denominator (resample.c:1130-1139).  On overflow the
+  // reference returns with its state half-updated; here nothing has been touched yet.
+  std::vector<uint32_t> frac(n_streams_);
+  for (uint32_t s = 0; s < n_streams_; s++) {
+    frac[s] = pos_[s].frac;
+    if (!scale_phase(&frac[s], next.den, filter_.den)) return SPEEXHIP_ERR_OVERFLOW;
+  }
+  rc = adopt_filter(next);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  for (uint32_t s = 0; s < n_streams_; s++) pos_[s].frac = frac[s];
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int Batch::set_quality(int quality) {
+  if (quality > 10 || quality < 0) return SPEEXHIP_ERR_INVALID_ARG;
+  if (quality == filter_.quality) return SPEEXHIP_ERR_SUCCESS;  // resample.c:1157-1158
+  FilterSpec next;
+  // the stored ratio is already reduced, so designing from it reproduces num/den
+  const int rc = design_filter_frac(filter_.num, filter_.den, filter_.in_rate, filter_.out_rate, quality, &next);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  return adopt_filter(next);
+}
+
+int Batch::skip_zeros() {  // resample.c:1200-1206
+  for (uint32_t s = 0; s < n_streams_; s++) pos_[s].last = static_cast<int32_t>(filter_.taps / 2);
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int Batch::reset_mem() {  // resample.c:1208-1220
+  std::vector<float> h;
+  int rc = fetch_history(&h);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  // The reference clears the first channels*(taps-1) floats of its buffer as ONE run, but its
+  // channel lines are line_ floats apart: only the lines (or parts of lines) that fall inside
+  // that run are silenced, later channels keep their history.  Restated, not "fixed": the
+  // outputs after a reset must be the reference's.
+  const uint64_t run = static_cast<uint64_t>(channels_) * (filter_.taps - 1);
+  for (uint32_t s = 0; s < n_streams_; s++) {
+    float *line = h.data() + s * hist_elems_;
+    for (uint32_t c = 0; c < channels_; c++) {
+      const uint64_t first = static_cast<uint64_t>(c) * line_;
+      for (uint32_t j = 0; j + 1 < filter_.taps && first + j < run; j++) line[static_cast<size_t>(j) * channels_ + c] = 0.f;
+    }
+    pos_[s] = StreamPos();
+  }
+  if (!h.empty())
+    HIP_TRY(hipMemcpy(d_hist_[hist_cur_], h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -145,16 +272,18 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
   if (s < n_streams_) {
     o->last_sample = pos_[s].last;
     o->samp_frac_num = pos_[s].frac;
+    o->magic_samples = pos_[s].magic;
   }
+  o->block_in = block_in();
   o->device = device_;
 }
 
 int Batch::history(uint32_t s, float *dst) {
   if (s >= n_streams_) return SPEEXHIP_ERR_INVALID_ARG;
   HIP_TRY(hipDeviceSynchronize());
-  if (hist_elems_)
-    HIP_TRY(hipMemcpy(dst, d_hist_[hist_cur_] + s * hist_elems_, hist_elems_ * sizeof(float),
-                      hipMemcpyDeviceToHost));
+  const size_t n = static_cast<size_t>(filter_.taps - 1 + pos_[s].magic) * channels_;
+  if (n)
+    HIP_TRY(hipMemcpy(dst, d_hist_[hist_cur_] + s * hist_elems_, n * sizeof(float), hipMemcpyDeviceToHost));
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -163,7 +292,9 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
   const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
   // the int16 entry point emits at most 1024 outputs per 160-frame block (its stack buffer,
   // resample.c:982-991); the float entry point has no such cap (resample.c:943)
-  const uint32_t block_out = float_io ? 0xffffffffu : kBlockOut;
+  EntryRules rules;
+  rules.block_in = block_in();
+  rules.float_entry = float_io;
   const bool packed = n_streams_ <= static_cast<uint32_t>(kMaxPackedStreams);
   DescPack pack;
   StreamDesc *descs = pack.d;
@@ -184,7 +315,7 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
   bool any_work = false;
   std::vector<CallPlan> plans(n_streams_);
   for (uint32_t s = 0; s < n_streams_; s++) {
-    const CallPlan plan = plan_call(filter_.num, filter_.den, in_len[s], out_len[s], pos_[s], block_out);
+    const CallPlan plan = plan_call(filter_.num, filter_.den, in_len[s], out_len[s], pos_[s], rules);
     plans[s] = plan;
     StreamDesc &d = descs[s];
     d.in = d_in ? static_cast<const char *>(d_in) + s * in_stride * es : nullptr;
@@ -193,7 +324,9 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
     d.hist_next = d_hist_[hist_cur_ ^ 1] + s * hist_elems_;
     d.in_frames = in_len[s];
     d.n_out = plan.produced;
-    d.consumed = plan.consumed;
+    d.consumed = plan.magic_used + plan.consumed;  // frames of V past the history
+    d.hist_frames = filter_.taps - 1 + plan.begin.magic;
+    d.hist_keep = filter_.taps - 1 + plan.end.magic;
     d.last0 = plan.begin.last;
     d.frac0 = plan.begin.frac;
     d.k_shift = phase_index_of(filter_.num, filter_.den, plan.begin.frac);
@@ -201,7 +334,9 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
                    static_cast<int32_t>((static_cast<uint64_t>(d.k_shift) * filter_.num) / filter_.den);
     d.tile_begin = 0;
     max_out = std::max(max_out, plan.produced);
-    any_work = any_work || plan.produced != 0 || plan.consumed != 0;
+    any_work = any_work || plan.produced != 0 || d.consumed != 0;
+    // resample.c:886: any block run marks the state as started
+    if (plan.produced != 0 || d.consumed != 0 || (in_len[s] != 0 && out_len[s] != 0)) started_[s] = 1;
   }
 
   if (any_work) {

@@ -22,6 +22,9 @@ class Batch {
   // Returns nullptr and sets *err on failure.  Uses the calling thread's current HIP device.
   static Batch *create(uint32_t n_streams, uint32_t channels, uint32_t in_rate, uint32_t out_rate,
                        int quality, int *err);
+  // speex_resampler_init_frac (resample.c:799): ratio given separately from the nominal rates.
+  static Batch *create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_num, uint32_t ratio_den,
+                            uint32_t in_rate, uint32_t out_rate, int quality, int *err);
   ~Batch();
 
   // Device-resident call for all streams; asynchronous on `stream`.
@@ -32,6 +35,18 @@ class Batch {
   // Host-buffer call for a single-stream batch; synchronous (H2D, kernels, D2H).
   int process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io);
 
+  // Mid-stream control (reference resample.c:1084-1220).  These wait for the
+  // device, re-align every stream's history on the host (resample.c:727-782) and rebuild the
+  // filter tables; they apply to all streams of the batch.
+  int set_rate_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate);
+  int set_quality(int quality);
+  int skip_zeros();
+  int reset_mem();
+  int input_latency() const { return static_cast<int>(filter_.taps / 2); }
+  int output_latency() const {
+    return static_cast<int>(((filter_.taps / 2) * filter_.den + (filter_.num >> 1)) / filter_.num);
+  }
+
   int set_mode(int mode);
   void info(uint32_t stream, SpeexHipInfo *out) const;
   int history(uint32_t stream, float *dst);
@@ -41,6 +56,10 @@ class Batch {
  private:
   Batch() = default;
   int setup();
+  int install_filter(const std::vector<float> &hist, uint32_t hist_frames_cap);
+  int adopt_filter(const FilterSpec &next);
+  int fetch_history(std::vector<float> *host);
+  uint32_t block_in() const { return line_ - (filter_.taps - 1); }
   int ensure_stage(size_t in_bytes, size_t out_bytes);
 
   FilterSpec filter_;
@@ -48,10 +67,14 @@ class Batch {
   int device_ = 0;
   int mode_ = SPEEXHIP_MODE_FAST;
   std::vector<StreamPos> pos_;
+  std::vector<uint8_t> started_;  // per stream: a block has run (resample.c:886), so a filter
+                                  // change must re-align the history instead of clearing it
+  uint32_t line_ = 0;             // frames per channel line, grow-only (resample.c
+                                  // "mem_alloc_size", :709-720): block size = line_-(taps-1)
 
   float *d_table_ = nullptr;
   float *d_hist_[2] = {nullptr, nullptr};  // float, like the reference's `mem`
-  size_t hist_elems_ = 0;  // per stream: (taps-1)*channels
+  size_t hist_elems_ = 0;  // per stream: (taps-1 + room for pending frames)*channels
   int hist_cur_ = 0;
 
   ExactGeometry exact_geo_;

@@ -102,13 +102,25 @@ bool mul_ratio(uint32_t *dst, uint32_t v, uint32_t num, uint32_t den) {
 }  // namespace
 
 int design_filter(uint32_t in_rate, uint32_t out_rate, int quality, FilterSpec *f, bool fill_table) {
-  if (in_rate == 0 || out_rate == 0 || quality > 10 || quality < 0) return SPEEXHIP_ERR_INVALID_ARG;
+  if (in_rate == 0 || out_rate == 0) return SPEEXHIP_ERR_INVALID_ARG;
+  return design_filter_frac(in_rate, out_rate, in_rate, out_rate, quality, f, fill_table);
+}
+
+bool scale_phase(uint32_t *frac, uint32_t new_den, uint32_t old_den) {
+  if (!mul_ratio(frac, *frac, new_den, old_den)) return false;
+  if (*frac >= new_den) *frac = new_den - 1;  // "safety net", resample.c:1136-1138
+  return true;
+}
+
+int design_filter_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate,
+                       int quality, FilterSpec *f, bool fill_table) {
+  if (ratio_num == 0 || ratio_den == 0 || quality > 10 || quality < 0) return SPEEXHIP_ERR_INVALID_ARG;
   const Grade &g = kGrades[quality];
-  const uint32_t common = gcd(in_rate, out_rate);
+  const uint32_t common = gcd(ratio_num, ratio_den);
   f->in_rate = in_rate;
   f->out_rate = out_rate;
-  f->num = in_rate / common;
-  f->den = out_rate / common;
+  f->num = ratio_num / common;
+  f->den = ratio_den / common;
   f->quality = quality;
   f->int_advance = static_cast<int>(f->num / f->den);
   f->frac_advance = static_cast<int>(f->num % f->den);

@@ -35,6 +35,16 @@ struct FilterSpec {
 int design_filter(uint32_t in_rate, uint32_t out_rate, int quality, FilterSpec *spec,
                   bool fill_table = true);
 
+// Same with the ratio given separately from the nominal rates (speex_resampler_init_frac /
+// set_rate_frac, resample.c:799, 1107): num/den = ratio reduced by its gcd, the rates are
+// only reported back.
+int design_filter_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate,
+                       int quality, FilterSpec *spec, bool fill_table = true);
+
+// Phase numerator carried over to a new denominator (resample.c:1130-1139): frac*new/old
+// without 32-bit overflow, clamped below new_den.  false = overflow (RESAMPLER_ERR_OVERFLOW).
+bool scale_phase(uint32_t *frac, uint32_t new_den, uint32_t old_den);
+
 // Cubic blend weights of the interpolated kernels for one output phase
 // (resample.c:454-458 + cubic_coef :318-328), bit-exact float arithmetic.
 void phase_blend(const FilterSpec &f, uint32_t phase, int *offset, float w[4]);

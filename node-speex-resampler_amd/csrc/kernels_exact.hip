@@ -63,10 +63,10 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   const uint32_t C = p.channels;
-  const uint32_t hist_frames = p.taps - 1;
+  const uint32_t hist_frames = d.hist_frames;
 
   if (blockIdx.x == gridDim.x - 1) {  // one extra workgroup per stream rolls the history
-    if (blockIdx.z == 0) roll_history<T>(p.taps, p.channels, d);
+    if (blockIdx.z == 0) roll_history<T>(p.channels, d);
     return;
   }
   const uint32_t k_first = blockIdx.x * p.outs_per_block;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == p.history_block) {
-    if (blockIdx.z == 0) roll_history<T>(p.taps, p.channels, d);
+    if (blockIdx.z == 0) roll_history<T>(p.channels, d);
     return;
   }
   if (d.n_out == 0 || blockIdx.x > p.history_block) return;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   if (m_lo >= m_total) return;
   const uint32_t m_cnt = min(p.lane_periods, m_total - m_lo);
 
-  const WindowGeom wg = window_geom<T>(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
+  const WindowGeom wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
   if (!(p.skip & 2u)) {
     u32x4 w[3];
     window_fetch<3, T>(wg, w);
@@ -246,7 +246,7 @@ __device__ __forceinline__ void persistent_body(const PeriodParams &p, const flo
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t s = blockIdx.x; s < n_streams; s += gridDim.x)  // history rolls ride along
-    roll_history<T>(p.taps, p.channels, PACKED ? pack.d[s] : streams[s]);
+    roll_history<T>(p.channels, PACKED ? pack.d[s] : streams[s]);
 
   const uint32_t total = n_streams * tiles_per_stream;
   uint32_t tile = blockIdx.x;
@@ -261,7 +261,7 @@ __device__ __forceinline__ void persistent_body(const PeriodParams &p, const flo
     m_lo = (t - s * tiles_per_stream) * p.lane_periods;
     m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 0;
     if (m_cnt) {
-      wg = window_geom<T>(d, p.taps, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
+      wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
       window_fetch<3, T>(wg, w);
     }
   };

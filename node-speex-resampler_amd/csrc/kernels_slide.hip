@@ -58,7 +58,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
-    roll_history<T>(p.taps, p.channels, d);
+    roll_history<T>(p.channels, d);
     return;
   }
   if (d.n_out == 0) return;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
 
   // ---- stage: frames [f0, f0 + m_cnt*num + row_len) of V; frame f -> row f / (P*NUM), column ... ----
   {
-    const int64_t hist_elems = static_cast<int64_t>(p.taps - 1) * C;
+    const int64_t hist_elems = static_cast<int64_t>(d.hist_frames) * C;
     const int64_t in_elems = static_cast<int64_t>(d.in_frames) * C;
     const int64_t q0 = (static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * NUM) * C - hist_elems;
     const uint32_t frames = m_cnt * NUM + p.row_len + P * NUM;  // + one row of slack for the last iteration

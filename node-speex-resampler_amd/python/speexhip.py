@@ -27,6 +27,14 @@ EXPORTS = [
     "speexhip_batch_init", "speexhip_batch_destroy", "speexhip_batch_set_mode",
     "speexhip_batch_get_info", "speexhip_batch_process_interleaved_int_device",
     "speexhip_design_filter", "speexhip_plan_call", "speexhip_version",
+    # mid-stream control
+    "speexhip_resampler_init_frac", "speexhip_resampler_set_rate", "speexhip_resampler_set_rate_frac",
+    "speexhip_resampler_get_ratio", "speexhip_resampler_set_quality", "speexhip_resampler_get_quality",
+    "speexhip_resampler_get_input_latency", "speexhip_resampler_get_output_latency",
+    "speexhip_resampler_skip_zeros", "speexhip_resampler_reset_mem",
+    "speexhip_batch_set_rate_frac", "speexhip_batch_set_quality", "speexhip_batch_skip_zeros",
+    "speexhip_batch_reset_mem", "speexhip_batch_get_history",
+    "speexhip_design_filter_frac", "speexhip_plan_call_ex", "speexhip_plan_filter_change",
 ]
 
 
@@ -36,7 +44,7 @@ class Info(C.Structure):
                 ("filt_len", C.c_uint32), ("oversample", C.c_uint32),
                 ("sinc_table_length", C.c_uint32), ("kernel", C.c_int32), ("mode", C.c_int32),
                 ("fast_path", C.c_int32), ("last_sample", C.c_int32), ("samp_frac_num", C.c_uint32),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("magic_samples", C.c_uint32), ("block_in", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -101,6 +109,29 @@ def lib():
         L.speexhip_plan_call.restype = i32
         L.speexhip_plan_call.argtypes = [u32, u32, u32, u32, C.POINTER(C.c_int32), pu32, pu32, pu32]
         L.speexhip_version.restype = C.c_char_p
+        pi32 = C.POINTER(C.c_int32)
+        L.speexhip_resampler_init_frac.restype = p
+        L.speexhip_resampler_init_frac.argtypes = [u32, u32, u32, u32, u32, i32, C.POINTER(C.c_int)]
+        L.speexhip_resampler_set_rate.argtypes = [p, u32, u32]
+        L.speexhip_resampler_set_rate_frac.argtypes = [p, u32, u32, u32, u32]
+        L.speexhip_resampler_get_ratio.argtypes = [p, pu32, pu32]
+        L.speexhip_resampler_set_quality.argtypes = [p, i32]
+        L.speexhip_resampler_get_quality.argtypes = [p, C.POINTER(C.c_int)]
+        for f in (L.speexhip_resampler_get_input_latency, L.speexhip_resampler_get_output_latency,
+                  L.speexhip_resampler_skip_zeros, L.speexhip_resampler_reset_mem,
+                  L.speexhip_batch_skip_zeros, L.speexhip_batch_reset_mem):
+            f.restype = i32
+            f.argtypes = [p]
+        L.speexhip_batch_set_rate_frac.argtypes = [p, u32, u32, u32, u32]
+        L.speexhip_batch_set_quality.argtypes = [p, i32]
+        L.speexhip_batch_get_history.argtypes = [p, u32, C.POINTER(C.c_float)]
+        L.speexhip_design_filter_frac.restype = i32
+        L.speexhip_design_filter_frac.argtypes = [u32, u32, u32, u32, i32, C.POINTER(Info),
+                                                  C.POINTER(C.c_float), u32]
+        L.speexhip_plan_call_ex.restype = i32
+        L.speexhip_plan_call_ex.argtypes = [u32, u32, u32, u32, i32, u32, pi32, pu32, pu32, pu32, pu32]
+        L.speexhip_plan_filter_change.restype = i32
+        L.speexhip_plan_filter_change.argtypes = [u32, u32, u32, C.POINTER(C.c_int64), pu32, pi32, pu32, u32, u32]
         _lib = L
     return _lib
 
@@ -134,22 +165,114 @@ def plan_call(num, den, in_len, out_cap, last, frac):
     return c.value, p.value, l.value, f.value
 
 
+def design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality):
+    """Host-only filter geometry for a ratio given separately from the rates; info dict."""
+    info = Info()
+    rc = lib().speexhip_design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality,
+                                           C.byref(info), None, 0)
+    if rc != 0:
+        raise ValueError(strerror(rc))
+    return info.as_dict()
+
+
+def plan_call_ex(num, den, in_len, out_cap, float_entry, block_in, last, frac, magic):
+    """Host-only bookkeeping of one call for any entry point / state;
+    returns (consumed, produced, last', frac', magic')."""
+    l, f, m, c, p = C.c_int32(last), C.c_uint32(frac), C.c_uint32(magic), C.c_uint32(), C.c_uint32()
+    rc = lib().speexhip_plan_call_ex(num, den, in_len, out_cap, int(float_entry), block_in, C.byref(l),
+                                     C.byref(f), C.byref(m), C.byref(c), C.byref(p))
+    if rc != 0:
+        raise ValueError(strerror(rc))
+    return c.value, p.value, l.value, f.value, m.value
+
+
+def plan_filter_change(old_taps, new_taps, magic, phase=None, old_den=1, new_den=1):
+    """Host-only: (rc, shift, new_magic, last_delta, phase')."""
+    sh, nm, ld = C.c_int64(), C.c_uint32(), C.c_int32()
+    ph = C.c_uint32(phase or 0)
+    rc = lib().speexhip_plan_filter_change(old_taps, new_taps, magic, C.byref(sh), C.byref(nm), C.byref(ld),
+                                           C.byref(ph) if phase is not None else None, old_den, new_den)
+    return rc, sh.value, nm.value, ld.value, ph.value
+
+
 class Resampler:
     """Thin object over the C ABI state: host-buffer ``process`` and device-pointer
     ``process_device`` (same signature as oracle.Oracle.process for the shared test driver)."""
 
-    def __init__(self, channels, in_rate, out_rate, quality=7, mode=None):
+    def __init__(self, channels, in_rate, out_rate, quality=7, mode=None, ratio=None):
         err = C.c_int(0)
-        self._h = lib().speexhip_resampler_init(channels, in_rate, out_rate, quality, C.byref(err))
+        if ratio is None:
+            self._h = lib().speexhip_resampler_init(channels, in_rate, out_rate, quality, C.byref(err))
+        else:
+            self._h = lib().speexhip_resampler_init_frac(channels, ratio[0], ratio[1], in_rate, out_rate,
+                                                         quality, C.byref(err))
         if not self._h:
             raise (RuntimeError if err.value == ERR_DEVICE else ValueError)(strerror(err.value))
         self.channels = channels
         if mode is not None:
             self.set_mode(mode)
+        self.refresh()
+
+    def refresh(self):
         i = self.info()
         self.num, self.den, self.taps = i["num_rate"], i["den_rate"], i["filt_len"]
         self.oversample, self.kind = i["oversample"], KERNEL_NAMES[i["kernel"]]
         self.table_len = i["sinc_table_length"]
+
+    # ---- mid-stream control: same method names as oracle.Oracle / oracle.Reference ----
+    def set_rate(self, in_rate, out_rate):
+        rc = lib().speexhip_resampler_set_rate(self._h, in_rate, out_rate)
+        self.refresh()
+        return rc
+
+    def set_rate_frac(self, num, den, in_rate, out_rate):
+        rc = lib().speexhip_resampler_set_rate_frac(self._h, num, den, in_rate, out_rate)
+        self.refresh()
+        return rc
+
+    def set_quality(self, quality):
+        rc = lib().speexhip_resampler_set_quality(self._h, quality)
+        self.refresh()
+        return rc
+
+    def rate(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        lib().speexhip_resampler_get_rate(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def ratio(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        lib().speexhip_resampler_get_ratio(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def quality(self):
+        q = C.c_int()
+        lib().speexhip_resampler_get_quality(self._h, C.byref(q))
+        return q.value
+
+    def input_latency(self):
+        return lib().speexhip_resampler_get_input_latency(self._h)
+
+    def output_latency(self):
+        return lib().speexhip_resampler_get_output_latency(self._h)
+
+    def skip_zeros(self):
+        return lib().speexhip_resampler_skip_zeros(self._h)
+
+    def reset_mem(self):
+        return lib().speexhip_resampler_reset_mem(self._h)
+
+    def pending(self, c=0):
+        """channel c of the pending ("magic") frames"""
+        return self._lines()[self.taps - 1:, c].copy()
+
+    def _lines(self):
+        n = self.taps - 1 + self.info()["magic_samples"]
+        buf = np.zeros((max(n, 1), self.channels), np.float32)
+        rc = lib().speexhip_resampler_get_history(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return buf[:n]
 
     def set_mode(self, mode):
         rc = lib().speexhip_resampler_set_mode(self._h, mode)
@@ -167,34 +290,39 @@ class Resampler:
 
     def history(self):
         """(taps-1, channels) float32: the reference's `mem` after the last call"""
-        buf = np.zeros(((self.taps - 1), self.channels), np.float32)
-        rc = lib().speexhip_resampler_get_history(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)))
-        if rc:
-            raise RuntimeError(strerror(rc))
-        return buf
+        return self._lines()[: self.taps - 1].copy()
 
-    def process(self, frames, out_capacity):
-        frames = np.ascontiguousarray(frames, dtype=np.int16)
-        if frames.ndim == 1:
-            frames = frames.reshape(-1, self.channels)
+    def process(self, frames, out_capacity, null_frames=0):
+        """frames=None: the reference's in == NULL case (null_frames frames of silence)."""
+        if frames is None:
+            ptr, n = None, int(null_frames)
+        else:
+            frames = np.ascontiguousarray(frames, dtype=np.int16)
+            if frames.ndim == 1:
+                frames = frames.reshape(-1, self.channels)
+            ptr, n = frames.ctypes.data_as(C.POINTER(C.c_int16)), frames.shape[0]
         out = np.zeros((max(int(out_capacity), 1), self.channels), np.int16)
-        il, ol = C.c_uint32(frames.shape[0]), C.c_uint32(int(out_capacity))
+        il, ol = C.c_uint32(n), C.c_uint32(int(out_capacity))
         rc = lib().speexhip_resampler_process_interleaved_int(
-            self._h, frames.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(il),
+            self._h, ptr, C.byref(il),
             out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(ol))
         if rc:
             raise RuntimeError(strerror(rc))
         return out[: ol.value].copy(), il.value
 
-    def process_float(self, frames, out_capacity):
+    def process_float(self, frames, out_capacity, null_frames=0):
         """speexhip_resampler_process_interleaved_float with host buffers (float32 in / out)."""
-        frames = np.ascontiguousarray(frames, dtype=np.float32)
-        if frames.ndim == 1:
-            frames = frames.reshape(-1, self.channels)
+        if frames is None:
+            ptr, n = None, int(null_frames)
+        else:
+            frames = np.ascontiguousarray(frames, dtype=np.float32)
+            if frames.ndim == 1:
+                frames = frames.reshape(-1, self.channels)
+            ptr, n = frames.ctypes.data_as(C.POINTER(C.c_float)), frames.shape[0]
         out = np.zeros((max(int(out_capacity), 1), self.channels), np.float32)
-        il, ol = C.c_uint32(frames.shape[0]), C.c_uint32(int(out_capacity))
+        il, ol = C.c_uint32(n), C.c_uint32(int(out_capacity))
         rc = lib().speexhip_resampler_process_interleaved_float(
-            self._h, frames.ctypes.data_as(C.POINTER(C.c_float)), C.byref(il),
+            self._h, ptr, C.byref(il),
             out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ol))
         if rc:
             raise RuntimeError(strerror(rc))
@@ -236,6 +364,28 @@ class Batch:
         i = Info()
         lib().speexhip_batch_get_info(self._h, stream, C.byref(i))
         return i.as_dict()
+
+    def set_rate_frac(self, num, den, in_rate, out_rate):
+        return lib().speexhip_batch_set_rate_frac(self._h, num, den, in_rate, out_rate)
+
+    def set_quality(self, quality):
+        return lib().speexhip_batch_set_quality(self._h, quality)
+
+    def skip_zeros(self):
+        return lib().speexhip_batch_skip_zeros(self._h)
+
+    def reset_mem(self):
+        return lib().speexhip_batch_reset_mem(self._h)
+
+    def lines(self, stream):
+        """(taps-1+pending, channels) float32 of one stream: history then pending frames"""
+        i = self.info(stream)
+        n = i["filt_len"] - 1 + i["magic_samples"]
+        buf = np.zeros((max(n, 1), self.channels), np.float32)
+        rc = lib().speexhip_batch_get_history(self._h, stream, buf.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return buf[:n]
 
     def process_device(self, d_in_ptr, in_stride, in_frames, d_out_ptr, out_stride, out_capacity,
                        stream_ptr=0, float_io=False):

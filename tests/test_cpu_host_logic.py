@@ -162,3 +162,81 @@ R.default.initPromise.then(() => {
     assert out["q11"] == "Invalid argument." and out["rate0"] == "Invalid argument."
     assert out["fields"] == [2, 44100, 48000, 7]
     assert out["exports"] == ["function", "function", "function"]
+
+
+class _BookkeepingModel:
+    """The integer side of a stream, driven ONLY through the library's host-only entry points
+    (design_filter_frac, plan_call_ex, plan_filter_change) -- i.e. the product's planner and
+    re-alignment rules without a GPU.  Mirrors what engine.cpp keeps per stream."""
+
+    def __init__(self, in_rate, out_rate, quality):
+        self.quality = quality
+        self.last = self.frac = self.magic = 0
+        self.started = False
+        self.line = 0
+        self._adopt(speexhip.design_filter_frac(in_rate, out_rate, in_rate, out_rate, quality))
+
+    def _adopt(self, info):
+        self.info = info
+        self.num, self.den, self.taps = info["num_rate"], info["den_rate"], info["filt_len"]
+        self.line = max(self.line, self.taps - 1 + 160)
+
+    def _change(self, info, rescale):
+        frac = self.frac
+        if rescale:
+            rc, _, _, _, frac = speexhip.plan_filter_change(self.taps, info["filt_len"], self.magic, self.frac,
+                                                            self.den, info["den_rate"])
+            if rc:
+                return rc
+        if self.started:
+            rc, _shift, magic, delta, _ = speexhip.plan_filter_change(self.taps, info["filt_len"], self.magic)
+            assert rc == 0
+            self.magic, self.last = magic, self.last + delta
+        self.frac = frac
+        self._adopt(info)
+        return 0
+
+    def op(self, op):
+        kind = op[0]
+        if kind in ("int", "float", "int_null", "float_null"):
+            used, made, self.last, self.frac, self.magic = speexhip.plan_call_ex(
+                self.num, self.den, op[1], op[2], kind.startswith("float"), self.line - (self.taps - 1),
+                self.last, self.frac, self.magic)
+            self.started = self.started or (op[1] > 0 and op[2] > 0)
+            res = [used, made]
+        elif kind in ("rate", "ratefrac"):
+            n, d, i, o = (op[1], op[2], op[1], op[2]) if kind == "rate" else op[1:5]
+            if (self.info["in_rate"], self.info["out_rate"], self.num, self.den) == (i, o, n, d):
+                res = [0]
+            else:
+                res = [self._change(speexhip.design_filter_frac(n, d, i, o, self.quality), True)]
+        elif kind == "quality":
+            if op[1] != self.quality:
+                self.quality = op[1]
+                self._change(speexhip.design_filter_frac(self.num, self.den, self.info["in_rate"],
+                                                         self.info["out_rate"], op[1]), False)
+            res = [0]
+        elif kind == "skip":
+            self.last = self.taps // 2
+            res = [0]
+        else:
+            self.last = self.frac = self.magic = 0
+            res = [0]
+        return res + [self.last, self.frac, self.magic, self.taps, self.taps // 2,
+                      ((self.taps // 2) * self.den + (self.num >> 1)) // self.num,
+                      self.info["in_rate"], self.info["out_rate"], self.num, self.den]
+
+
+def test_planner_and_realignment_match_the_reference_control_scripts(golden):
+    """SURVEY 8(f) row N3 on the CPU: the product's host logic (planner with pending frames and
+    either entry point's block rules, filter-change re-alignment, phase rescaling) reproduces the
+    reference's counters and state over the 40 recorded control scripts (960 ops)."""
+    checked = 0
+    for c in golden["control_cases"]:
+        m = _BookkeepingModel(c["in_rate"], c["out_rate"], c["quality"])
+        for k, (op, want) in enumerate(zip(c["ops"], c["results"])):
+            got = m.op(op)
+            want = [w for w in want if not isinstance(w, str)]  # digests need the GPU
+            assert got == want, (c["name"], k, op, got, want)
+            checked += 1
+    assert checked == 960

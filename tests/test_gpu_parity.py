@@ -406,3 +406,97 @@ def test_float_batched_device_pointers():
         assert (used[s], made[s]) == (wu, want.shape[0])
         assert np.abs(out[s, : made[s]] - want).max() <= 2e-6
     b.close()
+
+
+def test_mid_stream_control_scripts_exact_mode(golden):
+    """set_rate / set_rate_frac / set_quality / skip_zeros / reset_mem between
+    processing calls, incl. the pending ("magic") frames a filter change leaves buffered
+    (reference resample.c:703-782, 904-922, 1084-1220).  EXACT mode must reproduce every
+    recorded row of the reference: return codes, counters, output digests, state."""
+    from make_golden import apply_op
+    for c in golden["control_cases"]:
+        r = speexhip.Resampler(c["channels"], c["in_rate"], c["out_rate"], c["quality"], mode=speexhip.MODE_EXACT)
+        for k, (op, want) in enumerate(zip(c["ops"], c["results"])):
+            row, _ = apply_op(r, op, c["channels"])
+            assert row == want, (c["name"], k, op)
+        r.close()
+
+
+def test_mid_stream_control_scripts_fast_mode(golden):
+    """Same scripts in FAST mode against the oracle running alongside: identical bookkeeping,
+    int16 outputs within +-1 LSB, float outputs within 2e-6 of the window's scale, and the stream lines
+    (history ++ pending frames) equal after every op."""
+    from make_golden import apply_op
+    for c in golden["control_cases"]:
+        ch = c["channels"]
+        r = speexhip.Resampler(ch, c["in_rate"], c["out_rate"], c["quality"], mode=speexhip.MODE_FAST)
+        ref = orc.Oracle(ch, c["in_rate"], c["out_rate"], c["quality"])
+        for k, (op, want) in enumerate(zip(c["ops"], c["results"])):
+            # int16 and float calls alternate on one state, so a float call may see int16-scale
+            # history: the float tolerance is relative to the largest sample in its window
+            scale = max([1.0] + [float(np.abs(ref.history(cc)).max(initial=0.0)) for cc in range(ch)] +
+                        [float(np.abs(ref.pending(cc)).max(initial=0.0)) for cc in range(ch)])
+            row, got = apply_op(r, op, ch)
+            wrow, wout = apply_op(ref, op, ch)
+            tag = (c["name"], k, op)
+            assert [v for v in row if not isinstance(v, str)] == [v for v in want if not isinstance(v, str)], tag
+            if got is not None:
+                assert got.shape == wout.shape, tag
+                if got.dtype == np.int16:
+                    assert_close(got, wout, str(tag), rate=1.0 if got.size < 20000 else MISMATCH_RATE)
+                else:
+                    assert np.abs(got - wout).max(initial=0.0) <= 2e-6 * scale, tag
+            for cc in range(ch):
+                assert np.array_equal(r.history()[:, cc], ref.history(cc)), tag
+                assert np.array_equal(r.pending(cc), ref.pending(cc)), tag
+        r.close()
+
+
+def test_batch_mid_stream_quality_change_with_ragged_streams():
+    """speexhip_batch_set_quality / set_rate_frac / reset_mem / skip_zeros: every stream of a batch is
+    re-aligned on its own (streams that were capacity-bound hold different pending counts)."""
+    import torch
+    ch, i, o, S, frames = 2, 44100, 48000, 4, 6000
+    xs = np.stack([orc.lcg_pcm(frames * ch, 700 + s).reshape(frames, ch) for s in range(S)])
+    d_in = torch.from_numpy(xs).cuda()
+    cap = 8000
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    b = speexhip.Batch(S, ch, i, o, 8, mode=speexhip.MODE_EXACT)
+    refs = [orc.Oracle(ch, i, o, 8) for _ in range(S)]
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def step(in_frames, caps):
+        used, made = b.process_device(d_in.data_ptr(), frames * ch, in_frames, d_out.data_ptr(), cap * ch, caps, sp)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        for s in range(S):
+            want, wu = refs[s].process(xs[s, : in_frames[s]], caps[s])
+            assert (used[s], made[s]) == (wu, want.shape[0]), s
+            assert np.array_equal(out[s, : made[s]], want), s
+            assert (b.info(s)["last_sample"], b.info(s)["samp_frac_num"]) == refs[s].position()
+            assert b.info(s)["magic_samples"] == len(refs[s].pending())
+            lines = b.lines(s)
+            for c in range(ch):
+                assert np.array_equal(lines[: refs[s].taps - 1, c], refs[s].history(c))
+                assert np.array_equal(lines[refs[s].taps - 1:, c], refs[s].pending(c))
+
+    step([6000, 5000, 300, 0], [8000, 100, 8000, 8000])
+    assert b.set_quality(3) == 0
+    for r_ in refs:
+        assert r_.set_quality(3) == 0
+    step([40, 40, 40, 40], [3, 0, 50, 50])      # pending frames only partly drained on some streams
+    step([2000, 2000, 2000, 2000], [8000, 8000, 8000, 8000])
+    assert b.set_quality(10) == 0               # longer again: re-padding with silence / position shift
+    for r_ in refs:
+        r_.set_quality(10)
+    step([3000, 10, 3000, 1], [8000, 8000, 8000, 8000])
+    assert b.set_rate_frac(3, 2, 48000, 32000) == 0
+    for r_ in refs:
+        assert r_.set_rate_frac(3, 2, 48000, 32000) == 0
+    step([3000, 3000, 3000, 3000], [8000, 8000, 5, 8000])
+    assert b.skip_zeros() == 0 and b.reset_mem() == 0 and b.skip_zeros() == 0
+    for r_ in refs:
+        r_.skip_zeros(), r_.reset_mem(), r_.skip_zeros()
+    step([3000, 3000, 3000, 3000], [8000, 8000, 8000, 8000])
+    assert b.set_quality(11) == 3 and b.set_rate_frac(0, 1, 1, 1) == 3
+    b.close()
