@@ -150,6 +150,21 @@ SPEEXHIP_API int speexhip_resampler_process_interleaved_float_device(SpeexHipRes
                                                                      uint32_t *out_len,
                                                                      void *hip_stream);
 
+/* Chunk coalescing: n_chunks CONSECUTIVE host-buffer calls on one stream as
+ * ONE transfer + ONE launch.  in[i] / in_len[i] / out_len[i] are what call i of
+ * speexhip_resampler_process_interleaved_int would be given (in[i] may be NULL = silence); on
+ * return in_len[i] / out_len[i] hold what call i consumed / wrote, and `out` holds the calls'
+ * outputs back to back (so it needs room for the sum of the capacities).  Bytes and counters
+ * are exactly those of the n_chunks separate calls, including frames a capacity-bound call
+ * leaves unconsumed: the host plans every call in integer arithmetic first and only the frames
+ * really consumed travel to the GPU. */
+SPEEXHIP_API int speexhip_resampler_process_chunks_int(SpeexHipResamplerState *st, uint32_t n_chunks,
+                                                       const int16_t *const *in, uint32_t *in_len,
+                                                       int16_t *out, uint32_t *out_len);
+SPEEXHIP_API int speexhip_resampler_process_chunks_float(SpeexHipResamplerState *st, uint32_t n_chunks,
+                                                         const float *const *in, uint32_t *in_len,
+                                                         float *out, uint32_t *out_len);
+
 /* SPEEXHIP_MODE_FAST (default; +-1 LSB) or SPEEXHIP_MODE_EXACT (bit-identical arithmetic
  * order, slower).  The environment variable SPEEXHIP_MODE=exact|fast sets the initial mode. */
 SPEEXHIP_API int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode);

@@ -126,6 +126,22 @@ int speexhip_batch_process_interleaved_float_device(SpeexHipBatch *b, const floa
                                   static_cast<hipStream_t>(hip_stream));
 }
 
+int speexhip_resampler_process_chunks_int(SpeexHipResamplerState *st, uint32_t n_chunks,
+                                          const int16_t *const *in, uint32_t *in_len, int16_t *out,
+                                          uint32_t *out_len) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->process_host_chunks(n_chunks, reinterpret_cast<const void *const *>(in), in_len, out,
+                                        out_len, false);
+}
+
+int speexhip_resampler_process_chunks_float(SpeexHipResamplerState *st, uint32_t n_chunks,
+                                            const float *const *in, uint32_t *in_len, float *out,
+                                            uint32_t *out_len) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->process_host_chunks(n_chunks, reinterpret_cast<const void *const *>(in), in_len, out,
+                                        out_len, true);
+}
+
 void speexhip_resampler_get_rate(SpeexHipResamplerState *st, uint32_t *in_rate, uint32_t *out_rate) {
   *in_rate = st->batch->filter().in_rate;
   *out_rate = st->batch->filter().out_rate;

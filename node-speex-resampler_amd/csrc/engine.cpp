@@ -289,12 +289,31 @@ int Batch::history(uint32_t s, float *dst) {
 
 int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len, void *d_out,
                           uint64_t out_stride, uint32_t *out_len, bool float_io, hipStream_t stream) {
-  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
   // the int16 entry point emits at most 1024 outputs per 160-frame block (its stack buffer,
   // resample.c:982-991); the float entry point has no such cap (resample.c:943)
   EntryRules rules;
   rules.block_in = block_in();
   rules.float_entry = float_io;
+  std::vector<CallPlan> plans(n_streams_);
+  for (uint32_t s = 0; s < n_streams_; s++) {
+    plans[s] = plan_call(filter_.num, filter_.den, in_len[s], out_len[s], pos_[s], rules);
+    // resample.c:886: any block run marks the state as started
+    if (in_len[s] != 0 && out_len[s] != 0) started_[s] = 1;
+  }
+  const int rc = run_plans(d_in, in_stride, in_len, d_out, out_stride, plans.data(), float_io, stream);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  for (uint32_t s = 0; s < n_streams_; s++) {
+    in_len[s] = plans[s].consumed;
+    out_len[s] = plans[s].produced;
+  }
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+// One launch that carries every stream from plans[s].begin to plans[s].end.  in_frames[s] =
+// frames readable at the stream's input pointer.
+int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_frames, void *d_out,
+                     uint64_t out_stride, const CallPlan *plans, bool float_io, hipStream_t stream) {
+  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
   const bool packed = n_streams_ <= static_cast<uint32_t>(kMaxPackedStreams);
   DescPack pack;
   StreamDesc *descs = pack.d;
@@ -313,16 +332,14 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
 
   uint32_t max_out = 0;
   bool any_work = false;
-  std::vector<CallPlan> plans(n_streams_);
   for (uint32_t s = 0; s < n_streams_; s++) {
-    const CallPlan plan = plan_call(filter_.num, filter_.den, in_len[s], out_len[s], pos_[s], rules);
-    plans[s] = plan;
+    const CallPlan &plan = plans[s];
     StreamDesc &d = descs[s];
     d.in = d_in ? static_cast<const char *>(d_in) + s * in_stride * es : nullptr;
     d.hist = d_hist_[hist_cur_] + s * hist_elems_;
     d.out = static_cast<char *>(d_out) + s * out_stride * es;
     d.hist_next = d_hist_[hist_cur_ ^ 1] + s * hist_elems_;
-    d.in_frames = in_len[s];
+    d.in_frames = in_frames[s];
     d.n_out = plan.produced;
     d.consumed = plan.magic_used + plan.consumed;  // frames of V past the history
     d.hist_frames = filter_.taps - 1 + plan.begin.magic;
@@ -335,8 +352,6 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
     d.tile_begin = 0;
     max_out = std::max(max_out, plan.produced);
     any_work = any_work || plan.produced != 0 || d.consumed != 0;
-    // resample.c:886: any block run marks the state as started
-    if (plan.produced != 0 || d.consumed != 0 || (in_len[s] != 0 && out_len[s] != 0)) started_[s] = 1;
   }
 
   if (any_work) {
@@ -363,11 +378,7 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
     }
     hist_cur_ ^= 1;
   }
-  for (uint32_t s = 0; s < n_streams_; s++) {
-    pos_[s] = plans[s].end;
-    in_len[s] = plans[s].consumed;
-    out_len[s] = plans[s].produced;
-  }
+  for (uint32_t s = 0; s < n_streams_; s++) pos_[s] = plans[s].end;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -422,6 +433,87 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, made, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
   if (made != 0) std::memcpy(out, h_pin_out_, made);
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+// A sequence of calls on one stream as one transfer and (normally) one launch.  Every output
+// is a function of (history ++ the frames consumed so far) and its own index; call boundaries
+// only decide the counters.  So: plan the calls one after the other on the host (integers),
+// pack the frames each call really consumes back to back, and run the stream from the first
+// call's begin state to the last call's end state.  One exception: a capacity-bound call that
+// leaves input unconsumed -- its last outputs may still have read the first frame it then drops
+// (up-sampling: several outputs share one newest frame), while the next call sees its own first
+// frame in that slot.  Such a call closes a launch group: it keeps that one extra frame
+// readable, and the calls after it start a new launch on the same stream.
+int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_t *in_len, void *out,
+                               uint32_t *out_len, bool float_io) {
+  if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
+  HIP_TRY(hipSetDevice(device_));
+  const size_t fb = (float_io ? sizeof(float) : sizeof(int16_t)) * channels_;  // bytes per frame
+  EntryRules rules;
+  rules.block_in = block_in();
+  rules.float_entry = float_io;
+  struct Group {
+    CallPlan fused;
+    uint64_t in_off = 0, out_off = 0;  // frames into the staging buffers
+    uint32_t readable = 0;             // frames at in_off the launch may read
+  };
+  std::vector<CallPlan> plans(n_chunks);
+  std::vector<Group> groups;
+  StreamPos pos = pos_[0];
+  uint64_t frames = 0, made = 0;
+  bool open = false;
+  for (uint32_t i = 0; i < n_chunks; i++) {
+    plans[i] = plan_call(filter_.num, filter_.den, in_len[i], out_len[i], pos, rules);
+    pos = plans[i].end;
+    if (in_len[i] != 0 && out_len[i] != 0) started_[0] = 1;
+    if (!open) {
+      Group g;
+      g.fused.begin = plans[i].begin;
+      g.in_off = frames;
+      g.out_off = made;
+      groups.push_back(g);
+      open = true;
+    }
+    Group &g = groups.back();
+    g.fused.end = plans[i].end;
+    g.fused.magic_used += plans[i].magic_used;
+    g.fused.consumed += plans[i].consumed;
+    g.fused.produced += plans[i].produced;
+    g.readable += plans[i].consumed;
+    frames += plans[i].consumed;
+    made += plans[i].produced;
+    if (plans[i].consumed < in_len[i]) {  // dropped input: one more frame stays readable
+      g.readable += 1;
+      frames += 1;
+      open = false;
+    }
+    if (frames > 0x7fffffffull || made > 0x7fffffffull) return SPEEXHIP_ERR_OVERFLOW;
+  }
+  int rc = ensure_stage(frames * fb, made * fb);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  size_t off = 0;
+  for (uint32_t i = 0; i < n_chunks; i++) {  // frames a call drops never reach the GPU
+    const size_t bytes = (plans[i].consumed + (plans[i].consumed < in_len[i] ? 1u : 0u)) * fb;
+    if (in != nullptr && in[i] != nullptr)
+      std::memcpy(h_pin_in_ + off, in[i], bytes);
+    else
+      std::memset(h_pin_in_ + off, 0, bytes);
+    off += bytes;
+  }
+  if (off != 0) HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, off, hipMemcpyHostToDevice, own_stream_));
+  for (const Group &g : groups) {
+    rc = run_plans(d_stage_in_ + g.in_off * fb, 0, &g.readable, d_stage_out_ + g.out_off * fb, 0, &g.fused,
+                   float_io, own_stream_);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  }
+  if (made != 0) HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, made * fb, hipMemcpyDeviceToHost, own_stream_));
+  HIP_TRY(hipStreamSynchronize(own_stream_));
+  if (made != 0) std::memcpy(out, h_pin_out_, made * fb);
+  for (uint32_t i = 0; i < n_chunks; i++) {
+    in_len[i] = plans[i].consumed;
+    out_len[i] = plans[i].produced;
+  }
   return SPEEXHIP_ERR_SUCCESS;
 }
 

@@ -34,6 +34,10 @@ class Batch {
                      uint64_t out_stride, uint32_t *out_len, bool float_io, hipStream_t stream);
   // Host-buffer call for a single-stream batch; synchronous (H2D, kernels, D2H).
   int process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io);
+  // n_chunks consecutive host-buffer calls of a single-stream batch as one launch; outputs are
+  // written back to back into `out` (room for the sum of the capacities).
+  int process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_t *in_len, void *out,
+                          uint32_t *out_len, bool float_io);
 
   // Mid-stream control (reference resample.c:1084-1220).  These wait for the
   // device, re-align every stream's history on the host (resample.c:727-782) and rebuild the
@@ -61,6 +65,8 @@ class Batch {
   int fetch_history(std::vector<float> *host);
   uint32_t block_in() const { return line_ - (filter_.taps - 1); }
   int ensure_stage(size_t in_bytes, size_t out_bytes);
+  int run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_frames, void *d_out,
+                uint64_t out_stride, const CallPlan *plans, bool float_io, hipStream_t stream);
 
   FilterSpec filter_;
   uint32_t n_streams_ = 0, channels_ = 0;

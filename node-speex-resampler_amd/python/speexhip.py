@@ -35,6 +35,8 @@ EXPORTS = [
     "speexhip_batch_set_rate_frac", "speexhip_batch_set_quality", "speexhip_batch_skip_zeros",
     "speexhip_batch_reset_mem", "speexhip_batch_get_history",
     "speexhip_design_filter_frac", "speexhip_plan_call_ex", "speexhip_plan_filter_change",
+    # chunk coalescing
+    "speexhip_resampler_process_chunks_int", "speexhip_resampler_process_chunks_float",
 ]
 
 
@@ -132,6 +134,9 @@ def lib():
         L.speexhip_plan_call_ex.argtypes = [u32, u32, u32, u32, i32, u32, pi32, pu32, pu32, pu32, pu32]
         L.speexhip_plan_filter_change.restype = i32
         L.speexhip_plan_filter_change.argtypes = [u32, u32, u32, C.POINTER(C.c_int64), pu32, pi32, pu32, u32, u32]
+        for f in (L.speexhip_resampler_process_chunks_int, L.speexhip_resampler_process_chunks_float):
+            f.restype = i32
+            f.argtypes = [p, u32, C.POINTER(C.c_void_p), pu32, p, pu32]
         _lib = L
     return _lib
 
@@ -327,6 +332,31 @@ class Resampler:
         if rc:
             raise RuntimeError(strerror(rc))
         return out[: ol.value].copy(), il.value
+
+    def process_chunks(self, chunks, capacities, dtype=np.int16):
+        """n consecutive calls as one launch (speexhip_resampler_process_chunks_int / _float).
+        chunks: arrays of frames (or None with capacities[i] = (null_frames, capacity)).
+        Returns (list of per-call outputs, list of frames consumed)."""
+        n = len(chunks)
+        keep, ptrs, lens, caps = [], (C.c_void_p * n)(), (C.c_uint32 * n)(), (C.c_uint32 * n)()
+        for i, ch_ in enumerate(chunks):
+            if ch_ is None:
+                ptrs[i], lens[i], caps[i] = None, capacities[i][0], capacities[i][1]
+            else:
+                a = np.ascontiguousarray(ch_, dtype=dtype).reshape(-1, self.channels)
+                keep.append(a)
+                ptrs[i], lens[i], caps[i] = a.ctypes.data, a.shape[0], capacities[i]
+        out = np.zeros((max(sum(caps), 1), self.channels), dtype)
+        fn = (lib().speexhip_resampler_process_chunks_int if dtype == np.int16
+              else lib().speexhip_resampler_process_chunks_float)
+        rc = fn(self._h, n, ptrs, lens, C.c_void_p(out.ctypes.data), caps)
+        if rc:
+            raise RuntimeError(strerror(rc))
+        outs, off = [], 0
+        for i in range(n):
+            outs.append(out[off: off + caps[i]].copy())
+            off += caps[i]
+        return outs, list(lens)
 
     def process_device(self, d_in_ptr, in_frames, d_out_ptr, out_capacity, stream_ptr=0):
         il, ol = C.c_uint32(in_frames), C.c_uint32(out_capacity)

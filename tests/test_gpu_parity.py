@@ -500,3 +500,48 @@ def test_batch_mid_stream_quality_change_with_ragged_streams():
     step([3000, 3000, 3000, 3000], [8000, 8000, 8000, 8000])
     assert b.set_quality(11) == 3 and b.set_rate_frac(0, 1, 1, 1) == 3
     b.close()
+
+
+@pytest.mark.parametrize("mode", [speexhip.MODE_EXACT, speexhip.MODE_FAST])
+def test_chunk_coalescing_equals_the_separate_calls(mode):
+    """speexhip_resampler_process_chunks_int/_float = n consecutive calls as one
+    transfer + one launch.  Counters, state and bytes must be those of the separate calls on the
+    reference -- incl. capacity-bound calls that drop input (F5), empty and NULL chunks, and pending
+    frames left by a quality change (EXACT: identical bytes; FAST: +-1 LSB / 2e-6)."""
+    for (ch, i, o, q, dtype) in [(2, 44100, 48000, 7, np.int16), (1, 24000, 48000, 10, np.int16),
+                                 (8, 48000, 44100, 5, np.int16), (2, 48000, 16000, 6, np.float32),
+                                 (3, 8000, 48000, 3, np.float32)]:
+        rng = np.random.RandomState(ch * 100 + q)
+        r = speexhip.Resampler(ch, i, o, q, mode=mode)
+        ref = orc.Oracle(ch, i, o, q)
+        for rnd in range(4):
+            if rnd == 2:  # shorter filter: the next batch starts with pending frames
+                assert r.set_quality(max(q - 4, 0)) == 0 and ref.set_quality(max(q - 4, 0)) == 0
+            chunks, caps = [], []
+            for k in range(12):
+                f = int(rng.choice([0, 1, 37, 160, 441, 1000, 4096]))
+                full = int(np.ceil(f * o / i)) + 1
+                cap = int(rng.choice([full, full, full // 2, 0, 3]))
+                if rng.rand() < 0.1:
+                    chunks.append(None)
+                    caps.append((f, cap))
+                    continue
+                pcm = orc.lcg_pcm(f * ch, int(rng.randint(1, 1 << 30))).reshape(f, ch)
+                chunks.append(pcm if dtype == np.int16 else pcm.astype(np.float32) / np.float32(32768))
+                caps.append(cap)
+            outs, used = r.process_chunks(chunks, caps, dtype)
+            for k, (c, cap) in enumerate(zip(chunks, caps)):
+                fn = ref.process if dtype == np.int16 else ref.process_float
+                want, wu = fn(None, cap[1], null_frames=cap[0]) if c is None else fn(c, cap)
+                tag = ((ch, i, o, q), rnd, k)
+                assert used[k] == wu and outs[k].shape == want.shape, tag
+                if mode == speexhip.MODE_EXACT:
+                    assert np.array_equal(outs[k], want), tag
+                elif dtype == np.int16:
+                    assert np.abs(outs[k].astype(np.int32) - want.astype(np.int32)).max(initial=0) <= TOL_LSB, tag
+                else:
+                    assert np.abs(outs[k] - want).max(initial=0.0) <= 2e-6, tag
+            assert r.position() == ref.position() and len(r.pending()) == len(ref.pending())
+            for cc in range(ch):
+                assert np.array_equal(r.history()[:, cc], ref.history(cc))
+        r.close()
