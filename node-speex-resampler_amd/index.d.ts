@@ -22,6 +22,31 @@ declare class SpeexResampler {
       * @param chunk interleaved PCM data in signed 16bits int
       */
     processChunk(chunk: Buffer): Buffer;
+    /** Extension: consecutive chunks in one GPU launch; result[i] === processChunk(chunks[i]). */
+    processChunks(chunks: Buffer[]): Buffer[];
+    /** Extension: processChunk off the event loop; calls on one instance stay in order. */
+    processChunkAsync(chunk: Buffer): Promise<Buffer>;
+    /** Extension: interleaved float32 PCM in and out (speex_resampler_process_interleaved_float). */
+    processChunkFloat(chunk: Buffer): Buffer;
+    /** Extensions: mid-stream control (speex_resampler_set_rate / set_quality / skip_zeros / reset_mem). */
+    setRate(inRate: number, outRate: number): void;
+    setQuality(quality: number): void;
+    skipZeros(): void;
+    resetMem(): void;
+    readonly inputLatency: number;
+    readonly outputLatency: number;
+    /** Extension: the filter's tail (response to the last inputLatency frames). */
+    flush(): Buffer;
+    /** Extension: release the GPU state now. */
+    destroy(): void;
+}
+export interface SpeexResamplerTransformOptions {
+    /** hold up to n chunks and resample them in one GPU launch (same bytes out) */
+    coalesceChunks?: number;
+    /** run each call off the event loop */
+    async?: boolean;
+    /** at end of stream also emit the filter's tail */
+    flushTail?: boolean;
 }
 export declare class SpeexResamplerTransform extends Transform {
     channels: any;
@@ -30,7 +55,7 @@ export declare class SpeexResamplerTransform extends Transform {
     quality: number;
     resampler: SpeexResampler;
     _alignementBuffer: Buffer;
-    constructor(channels: any, inRate: any, outRate: any, quality?: number);
+    constructor(channels: any, inRate: any, outRate: any, quality?: number, options?: SpeexResamplerTransformOptions);
     _transform(chunk: any, encoding: any, callback: any): void;
 }
 export default SpeexResampler;

@@ -67,14 +67,137 @@ class SpeexResampler {
     const outCapacity = (this._outBufferSize / this.channels / Uint16Array.BYTES_PER_ELEMENT) | 0;
     return speexModule.process(this._resamplerPtr, chunk, inFrames | 0, outCapacity);
   }
+
+  // ------------------------------------------------------------------------------------------
+  // Extensions (not in the reference's class).  Nothing above depends on them.
+  // ------------------------------------------------------------------------------------------
+
+  /** Checks + lazy init + the capacity rule of processChunk, without the call itself. */
+  _prepare(chunk, bytesPerSample) {
+    if (!speexModule) {
+      throw new Error('You need to wait for SpeexResampler.initPromise before calling this method');
+    }
+    if (chunk.length % (this.channels * bytesPerSample) !== 0) {
+      throw new Error('Chunk length should be a multiple of channels * ' + bytesPerSample + ' bytes');
+    }
+    this._ensureNative();
+    const target = Math.ceil(chunk.length * this.outRate / this.inRate);
+    if (this._outBufferSize < target) {
+      this._outBufferSize = target;
+    }
+    return [(chunk.length / this.channels / bytesPerSample) | 0,
+      (this._outBufferSize / this.channels / bytesPerSample) | 0];
+  }
+
+  _ensureNative() {
+    if (!speexModule) {
+      throw new Error('You need to wait for SpeexResampler.initPromise before calling this method');
+    }
+    if (!this._resamplerPtr) {
+      this._resamplerPtr = speexModule.init(this.channels >>> 0, this.inRate >>> 0,
+        this.outRate >>> 0, this.quality | 0);
+    }
+    return this._resamplerPtr;
+  }
+
+  /**
+   * processChunk for a list of consecutive chunks in ONE GPU launch (SURVEY 8f row N1).
+   * Returns one Buffer per chunk, byte-identical to calling processChunk on each in turn
+   * (the capacity rule is applied per original chunk).
+   */
+  processChunks(chunks) {
+    const inFrames = [];
+    const caps = [];
+    for (const chunk of chunks) {
+      const [f, cap] = this._prepare(chunk, Uint16Array.BYTES_PER_ELEMENT);
+      inFrames.push(f);
+      caps.push(cap);
+    }
+    return speexModule.processChunks(this._resamplerPtr, chunks, inFrames, caps);
+  }
+
+  /**
+   * processChunk that does not block the event loop: the transfer and the kernels run on a
+   * libuv pool thread.  Calls on one instance are chained, so their order (and therefore the
+   * stream) is the order of the calls.  Resolves to the same bytes processChunk returns.
+   */
+  processChunkAsync(chunk) {
+    let args;
+    try {
+      args = this._prepare(chunk, Uint16Array.BYTES_PER_ELEMENT);
+    } catch (e) {
+      return Promise.reject(e);
+    }
+    const run = () => speexModule.processAsync(this._resamplerPtr, chunk, args[0], args[1]);
+    const p = (this._pending || Promise.resolve()).then(run, run);
+    this._pending = p.catch(() => {});
+    return p;
+  }
+
+  /**
+   * Float I/O (SURVEY 8f row N2, speex_resampler_process_interleaved_float): chunk is
+   * interleaved float32 PCM; the result is float32, neither rounded nor clipped.  Same stream
+   * state as processChunk; same grow-only capacity rule (in bytes of float32).
+   */
+  processChunkFloat(chunk) {
+    const [f, cap] = this._prepare(chunk, Float32Array.BYTES_PER_ELEMENT);
+    return speexModule.processFloat(this._resamplerPtr, chunk, f, cap);
+  }
+
+  /** Mid-stream control (SURVEY 8f row N3; speex_resampler_set_rate / set_quality / ...). */
+  setRate(inRate, outRate) {
+    if (this._resamplerPtr) speexModule.setRate(this._resamplerPtr, inRate >>> 0, outRate >>> 0);
+    this.inRate = inRate;
+    this.outRate = outRate;
+  }
+
+  setQuality(quality) {
+    if (this._resamplerPtr) speexModule.setQuality(this._resamplerPtr, quality | 0);
+    this.quality = quality;
+  }
+
+  /** Start half a filter in, so the stream does not begin with the filter's ramp-up. */
+  skipZeros() { speexModule.skipZeros(this._ensureNative()); }
+
+  resetMem() { speexModule.resetMem(this._ensureNative()); }
+
+  /** Frames of delay the filter adds, counted at the input rate / at the output rate. */
+  get inputLatency() { return speexModule.getLatency(this._ensureNative())[0]; }
+
+  get outputLatency() { return speexModule.getLatency(this._ensureNative())[1]; }
+
+  /**
+   * The tail the reference never emits (SURVEY 8f row N4): feeds inputLatency frames of silence
+   * and returns what comes out -- the response to the last real input frames.
+   */
+  flush() {
+    const ptr = this._ensureNative();
+    const frames = speexModule.getLatency(ptr)[0];
+    const cap = Math.ceil(frames * this.outRate / this.inRate) + 1;
+    return speexModule.process(ptr, null, frames, cap);
+  }
+
+  /** Release the GPU state now (otherwise it goes with garbage collection). */
+  destroy() {
+    if (this._resamplerPtr) speexModule.destroy(this._resamplerPtr);
+    this._resamplerPtr = undefined;
+    this._outBufferSize = -1;
+  }
 }
 SpeexResampler.initPromise = globalModulePromise;
 
 const EMPTY_BUFFER = Buffer.alloc(0);
 
 class SpeexResamplerTransform extends Transform {
-  /** Same arguments as SpeexResampler (reference src/index.ts:121-137). */
-  constructor(channels, inRate, outRate, quality = 7) {
+  /**
+   * Same arguments as SpeexResampler (reference src/index.ts:121-137).  The optional fifth
+   * argument is an extension and changes nothing unless set:
+   *   coalesceChunks: n  -- hold up to n aligned chunks and resample them in one GPU launch
+   *                         (bytes out unchanged, they just arrive n chunks at a time)
+   *   async: true        -- run each call off the event loop (processChunkAsync)
+   *   flushTail: true    -- at end of stream also emit SpeexResampler.flush()
+   */
+  constructor(channels, inRate, outRate, quality = 7, options = undefined) {
     super();
     this.channels = channels;
     this.inRate = inRate;
@@ -82,9 +205,67 @@ class SpeexResamplerTransform extends Transform {
     this.quality = quality;
     this.resampler = new SpeexResampler(channels, inRate, outRate, quality);
     this._alignementBuffer = EMPTY_BUFFER;
+    this._options = options || {};
+    this._held = [];
+    if (this._options.coalesceChunks > 1 || this._options.flushTail) {
+      // only defined when asked for: the reference has no _flush
+      this._flush = (callback) => {
+        try {
+          this._emitHeld();
+          if (this._options.flushTail) this.push(this.resampler.flush());
+          callback();
+        } catch (e) {
+          callback(e);
+        }
+      };
+    }
+  }
+
+  _emitHeld() {
+    if (this._held.length === 0) return;
+    const held = this._held;
+    this._held = [];
+    for (const out of this.resampler.processChunks(held)) this.push(out);
   }
 
   _transform(chunk, encoding, callback) {
+    if (this._options.coalesceChunks > 1 || this._options.async) {
+      return this._transformExtended(chunk, callback);
+    }
+    return this._transformReference(chunk, encoding, callback);
+  }
+
+  _align(chunk) {
+    let chunkToProcess = chunk;
+    if (this._alignementBuffer.length > 0) {
+      chunkToProcess = Buffer.concat([this._alignementBuffer, chunk]);
+      this._alignementBuffer = EMPTY_BUFFER;
+    }
+    const extraneousBytesCount = chunkToProcess.length % (this.channels * Uint16Array.BYTES_PER_ELEMENT);
+    if (extraneousBytesCount !== 0) {
+      this._alignementBuffer = Buffer.from(chunkToProcess.slice(chunkToProcess.length - extraneousBytesCount));
+      chunkToProcess = chunkToProcess.slice(0, chunkToProcess.length - extraneousBytesCount);
+    }
+    return chunkToProcess;
+  }
+
+  _transformExtended(chunk, callback) {
+    try {
+      // copy: a held chunk must not change under us while it waits for its launch
+      const aligned = Buffer.from(this._align(chunk));
+      if (this._options.coalesceChunks > 1) {
+        this._held.push(aligned);
+        if (this._held.length >= this._options.coalesceChunks) this._emitHeld();
+        callback();
+      } else {
+        this.resampler.processChunkAsync(aligned).then((res) => callback(null, res), callback);
+      }
+    } catch (e) {
+      callback(e);
+    }
+  }
+
+  _transformReference(chunk, encoding, callback) {
     let chunkToProcess = chunk;
     if (this._alignementBuffer.length > 0) {
       chunkToProcess = Buffer.concat([this._alignementBuffer, chunk]);

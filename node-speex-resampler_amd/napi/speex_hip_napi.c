@@ -5,10 +5,16 @@
  * Module._speex_resampler_init / _process_interleaved_int / _strerror on the WASM heap,
  * index.js calls init() / process() here with Buffers.  No arithmetic happens in this file.
  *
+ * Beyond the reference surface it carries the SURVEY 8(f) rows: float I/O (N2), mid-stream
+ * control (N3), explicit destroy (N4), chunk coalescing and an asynchronous call that keeps
+ * the event loop free while the GPU works (N1).
+ *
  * Built with plain gcc against /usr/include/node (N-API v3+, no node-addon-api).
  */
 #include <node_api.h>
+#include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -22,19 +28,39 @@
     }                                                            \
   } while (0)
 
+/* What a JS handle points at.  `st` becomes NULL on destroy(); the lock serialises calls that
+ * reach one state from libuv pool threads (processAsync). */
+typedef struct {
+  SpeexHipResamplerState *st;
+  pthread_mutex_t lock;
+} Handle;
+
 static void finalize_state(napi_env env, void *data, void *hint) {
   (void)env;
   (void)hint;
-  speexhip_resampler_destroy((SpeexHipResamplerState *)data);
+  Handle *h = (Handle *)data;
+  if (h->st != NULL) speexhip_resampler_destroy(h->st);
+  pthread_mutex_destroy(&h->lock);
+  free(h);
 }
 
-static SpeexHipResamplerState *unwrap(napi_env env, napi_value v) {
+static Handle *unwrap_handle(napi_env env, napi_value v) {
   void *p = NULL;
   if (napi_get_value_external(env, v, &p) != napi_ok || p == NULL) {
     napi_throw_type_error(env, NULL, "expected a resampler handle");
     return NULL;
   }
-  return (SpeexHipResamplerState *)p;
+  return (Handle *)p;
+}
+
+static SpeexHipResamplerState *unwrap(napi_env env, napi_value v) {
+  Handle *h = unwrap_handle(env, v);
+  if (h == NULL) return NULL;
+  if (h->st == NULL) {
+    napi_throw_error(env, NULL, speexhip_resampler_strerror(SPEEXHIP_ERR_BAD_STATE));
+    return NULL;
+  }
+  return h->st;
 }
 
 /* init(channels, inRate, outRate, quality) -> handle; throws Error(strerror(code)) like
@@ -55,39 +81,81 @@ static napi_value Init(napi_env env, napi_callback_info info) {
     napi_throw_error(env, NULL, speexhip_resampler_strerror(err));
     return NULL;
   }
+  Handle *h = (Handle *)malloc(sizeof(Handle));
+  if (h == NULL) {
+    speexhip_resampler_destroy(st);
+    napi_throw_error(env, NULL, speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED));
+    return NULL;
+  }
+  h->st = st;
+  pthread_mutex_init(&h->lock, NULL);
   napi_value handle;
-  NAPI_OK(napi_create_external(env, st, finalize_state, NULL, &handle));
+  NAPI_OK(napi_create_external(env, h, finalize_state, NULL, &handle));
   return handle;
 }
 
-/* process(handle, chunk: Buffer, inFrames, outCapacityFrames) -> Buffer (fresh copy of the
- * frames written), the src/index.ts:90-115 sequence without the WASM heap. */
-static napi_value Process(napi_env env, napi_callback_info info) {
+/* destroy(handle): release the device state now instead of at garbage collection (the
+ * reference never calls speex_resampler_destroy: SURVEY 8f row N4). */
+static napi_value Destroy(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  Handle *h = unwrap_handle(env, argv[0]);
+  if (h == NULL) return NULL;
+  pthread_mutex_lock(&h->lock);
+  if (h->st != NULL) speexhip_resampler_destroy(h->st);
+  h->st = NULL;
+  pthread_mutex_unlock(&h->lock);
+  return NULL;
+}
+
+/* Optional Buffer argument: null / undefined -> NULL pointer (the reference's in == NULL). */
+static int buffer_or_null(napi_env env, napi_value v, void **data, size_t *bytes) {
+  napi_valuetype t;
+  *data = NULL;
+  *bytes = 0;
+  if (napi_typeof(env, v, &t) != napi_ok) return 0;
+  if (t == napi_null || t == napi_undefined) return 1;
+  return napi_get_buffer_info(env, v, data, bytes) == napi_ok;
+}
+
+/* process / processFloat (handle, chunk: Buffer|null, inFrames, outCapacityFrames) -> Buffer
+ * (fresh copy of the frames written): the src/index.ts:90-115 sequence without the WASM heap. */
+static napi_value process_common(napi_env env, napi_callback_info info, size_t sample_bytes) {
   size_t argc = 4;
   napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
-  if (st == NULL) return NULL;
+  Handle *h = unwrap_handle(env, argv[0]);
+  if (h == NULL || unwrap(env, argv[0]) == NULL) return NULL;
   void *in_data = NULL;
   size_t in_bytes = 0;
-  NAPI_OK(napi_get_buffer_info(env, argv[1], &in_data, &in_bytes));
+  if (!buffer_or_null(env, argv[1], &in_data, &in_bytes)) {
+    napi_throw_type_error(env, NULL, "chunk must be a Buffer or null");
+    return NULL;
+  }
   uint32_t in_len = 0, out_len = 0;
   NAPI_OK(napi_get_value_uint32(env, argv[2], &in_len));
   NAPI_OK(napi_get_value_uint32(env, argv[3], &out_len));
   SpeexHipInfo si;
-  speexhip_resampler_get_info(st, &si);
-  if ((size_t)in_len * si.nb_channels * 2 > in_bytes) {
+  speexhip_resampler_get_info(h->st, &si);
+  const size_t frame_bytes = (size_t)si.nb_channels * sample_bytes;
+  if (in_data != NULL && (size_t)in_len * frame_bytes > in_bytes) {
     napi_throw_range_error(env, NULL, "input frame count exceeds the chunk");
     return NULL;
   }
-  size_t cap_bytes = (size_t)out_len * si.nb_channels * 2;
-  int16_t *tmp = (int16_t *)malloc(cap_bytes ? cap_bytes : 2);
+  size_t cap_bytes = (size_t)out_len * frame_bytes;
+  void *tmp = malloc(cap_bytes ? cap_bytes : 4);
   if (tmp == NULL) {
     napi_throw_error(env, NULL, speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED));
     return NULL;
   }
-  int rc = speexhip_resampler_process_interleaved_int(st, (const int16_t *)in_data, &in_len, tmp,
-                                                      &out_len);
+  pthread_mutex_lock(&h->lock);
+  int rc = sample_bytes == 2
+               ? speexhip_resampler_process_interleaved_int(h->st, (const int16_t *)in_data, &in_len,
+                                                            (int16_t *)tmp, &out_len)
+               : speexhip_resampler_process_interleaved_float(h->st, (const float *)in_data, &in_len,
+                                                              (float *)tmp, &out_len);
+  pthread_mutex_unlock(&h->lock);
   if (rc != 0) {
     free(tmp);
     napi_throw_error(env, NULL, speexhip_resampler_strerror(rc));
@@ -95,10 +163,247 @@ static napi_value Process(napi_env env, napi_callback_info info) {
   }
   napi_value out;
   void *copied = NULL;
-  napi_status s = napi_create_buffer_copy(env, (size_t)out_len * si.nb_channels * 2, tmp, &copied, &out);
+  napi_status s = napi_create_buffer_copy(env, (size_t)out_len * frame_bytes, tmp, &copied, &out);
   free(tmp);
   NAPI_OK(s);
   return out;
+}
+static napi_value Process(napi_env env, napi_callback_info info) { return process_common(env, info, 2); }
+static napi_value ProcessFloat(napi_env env, napi_callback_info info) { return process_common(env, info, 4); }
+
+/* processChunks(handle, chunks: Buffer[], inFrames: number[], outCapacities: number[]) -> Buffer[]
+ * n consecutive process() calls as one transfer + one launch
+ * (speexhip_resampler_process_chunks_int); the i-th Buffer is what the i-th call returns. */
+static napi_value ProcessChunks(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  Handle *h = unwrap_handle(env, argv[0]);
+  if (h == NULL || unwrap(env, argv[0]) == NULL) return NULL;
+  uint32_t n = 0;
+  NAPI_OK(napi_get_array_length(env, argv[1], &n));
+  SpeexHipInfo si;
+  speexhip_resampler_get_info(h->st, &si);
+  const size_t frame_bytes = (size_t)si.nb_channels * 2;
+  const int16_t **ptrs = (const int16_t **)calloc(n ? n : 1, sizeof(*ptrs));
+  uint32_t *in_len = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+  uint32_t *out_len = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+  int16_t *tmp = NULL;
+  napi_value result = NULL;
+  const char *fail = NULL;
+  size_t total_cap = 0;
+  if (ptrs == NULL || in_len == NULL || out_len == NULL) fail = speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED);
+  for (uint32_t i = 0; fail == NULL && i < n; i++) {
+    napi_value c, a, b;
+    void *data = NULL;
+    size_t bytes = 0;
+    if (napi_get_element(env, argv[1], i, &c) != napi_ok || napi_get_element(env, argv[2], i, &a) != napi_ok ||
+        napi_get_element(env, argv[3], i, &b) != napi_ok || !buffer_or_null(env, c, &data, &bytes) ||
+        napi_get_value_uint32(env, a, &in_len[i]) != napi_ok ||
+        napi_get_value_uint32(env, b, &out_len[i]) != napi_ok) {
+      fail = "processChunks expects (handle, Buffer[], number[], number[])";
+    } else if (data != NULL && (size_t)in_len[i] * frame_bytes > bytes) {
+      fail = "input frame count exceeds the chunk";
+    }
+    ptrs[i] = (const int16_t *)data;
+    total_cap += out_len[i];
+  }
+  if (fail == NULL) {
+    tmp = (int16_t *)malloc(total_cap * frame_bytes + 2);
+    if (tmp == NULL) fail = speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED);
+  }
+  if (fail == NULL) {
+    pthread_mutex_lock(&h->lock);
+    int rc = speexhip_resampler_process_chunks_int(h->st, n, ptrs, in_len, tmp, out_len);
+    pthread_mutex_unlock(&h->lock);
+    if (rc != 0) fail = speexhip_resampler_strerror(rc);
+  }
+  if (fail == NULL && napi_create_array_with_length(env, n, &result) == napi_ok) {
+    size_t off = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      napi_value buf;
+      void *copied = NULL;
+      if (napi_create_buffer_copy(env, (size_t)out_len[i] * frame_bytes, (char *)tmp + off, &copied, &buf) != napi_ok ||
+          napi_set_element(env, result, i, buf) != napi_ok) {
+        fail = "speexhip N-API failure: building the result array";
+        break;
+      }
+      off += (size_t)out_len[i] * frame_bytes;
+    }
+  }
+  free(tmp);
+  free(ptrs);
+  free(in_len);
+  free(out_len);
+  if (fail != NULL) {
+    napi_throw_error(env, NULL, fail);
+    return NULL;
+  }
+  return result;
+}
+
+/* processAsync(handle, chunk, inFrames, outCapacityFrames) -> Promise<Buffer>: the same call on
+ * a libuv pool thread, so H2D + kernels + D2H do not block the event loop.  The caller
+ * (index.js) chains the promises of one instance, so calls on one state stay in order. */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref chunk_ref, handle_ref;
+  Handle *h;
+  const int16_t *in;
+  int16_t *out;
+  uint32_t in_len, out_len, channels;
+  int rc;
+  char errmsg[256];
+} AsyncJob;
+
+static void async_execute(napi_env env, void *data) {
+  (void)env;
+  AsyncJob *j = (AsyncJob *)data;
+  pthread_mutex_lock(&j->h->lock);
+  if (j->h->st == NULL) {
+    j->rc = SPEEXHIP_ERR_BAD_STATE;
+  } else {
+    j->rc = speexhip_resampler_process_interleaved_int(j->h->st, j->in, &j->in_len, j->out, &j->out_len);
+  }
+  /* DEVICE errors keep their text per thread: fetch it on the thread that failed */
+  if (j->rc != 0) snprintf(j->errmsg, sizeof(j->errmsg), "%s", speexhip_resampler_strerror(j->rc));
+  pthread_mutex_unlock(&j->h->lock);
+}
+
+static void async_complete(napi_env env, napi_status status, void *data) {
+  AsyncJob *j = (AsyncJob *)data;
+  napi_value v;
+  if (status == napi_ok && j->rc == 0) {
+    void *copied = NULL;
+    if (napi_create_buffer_copy(env, (size_t)j->out_len * j->channels * 2, j->out, &copied, &v) == napi_ok)
+      napi_resolve_deferred(env, j->deferred, v);
+    else
+      status = napi_generic_failure;
+  }
+  if (status != napi_ok || j->rc != 0) {
+    napi_value msg;
+    napi_create_string_utf8(env, j->rc != 0 ? j->errmsg : "speexhip: asynchronous call failed", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &v);
+    napi_reject_deferred(env, j->deferred, v);
+  }
+  if (j->chunk_ref) napi_delete_reference(env, j->chunk_ref);
+  napi_delete_reference(env, j->handle_ref);
+  napi_delete_async_work(env, j->work);
+  free(j->out);
+  free(j);
+}
+
+static napi_value ProcessAsync(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  Handle *h = unwrap_handle(env, argv[0]);
+  if (h == NULL || unwrap(env, argv[0]) == NULL) return NULL;
+  void *in_data = NULL;
+  size_t in_bytes = 0;
+  if (!buffer_or_null(env, argv[1], &in_data, &in_bytes)) {
+    napi_throw_type_error(env, NULL, "chunk must be a Buffer or null");
+    return NULL;
+  }
+  uint32_t in_len = 0, out_len = 0;
+  NAPI_OK(napi_get_value_uint32(env, argv[2], &in_len));
+  NAPI_OK(napi_get_value_uint32(env, argv[3], &out_len));
+  SpeexHipInfo si;
+  speexhip_resampler_get_info(h->st, &si);
+  if (in_data != NULL && (size_t)in_len * si.nb_channels * 2 > in_bytes) {
+    napi_throw_range_error(env, NULL, "input frame count exceeds the chunk");
+    return NULL;
+  }
+  AsyncJob *j = (AsyncJob *)calloc(1, sizeof(AsyncJob));
+  if (j != NULL) j->out = (int16_t *)malloc((size_t)out_len * si.nb_channels * 2 + 2);
+  if (j == NULL || j->out == NULL) {
+    free(j);
+    napi_throw_error(env, NULL, speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED));
+    return NULL;
+  }
+  j->h = h;
+  j->in = (const int16_t *)in_data;
+  j->in_len = in_len;
+  j->out_len = out_len;
+  j->channels = si.nb_channels;
+  napi_value promise, name;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  if (in_data != NULL) NAPI_OK(napi_create_reference(env, argv[1], 1, &j->chunk_ref)); /* keep the bytes alive */
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->handle_ref));
+  NAPI_OK(napi_create_string_utf8(env, "speexhip.processAsync", NAPI_AUTO_LENGTH, &name));
+  NAPI_OK(napi_create_async_work(env, NULL, name, async_execute, async_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
+/* ---- mid-stream control: each throws Error(strerror(code)) on failure ---- */
+static napi_value control_result(napi_env env, int rc) {
+  if (rc != 0) napi_throw_error(env, NULL, speexhip_resampler_strerror(rc));
+  return NULL;
+}
+
+static napi_value SetRate(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  if (st == NULL) return NULL;
+  uint32_t v[4] = {0, 0, 0, 0};
+  for (size_t i = 1; i < argc && i < 5; i++) NAPI_OK(napi_get_value_uint32(env, argv[i], &v[i - 1]));
+  /* (handle, inRate, outRate) or (handle, ratioNum, ratioDen, inRate, outRate) */
+  return control_result(env, argc >= 5 ? speexhip_resampler_set_rate_frac(st, v[0], v[1], v[2], v[3])
+                                       : speexhip_resampler_set_rate(st, v[0], v[1]));
+}
+
+static napi_value SetQuality(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  if (st == NULL) return NULL;
+  int32_t q = 0;
+  NAPI_OK(napi_get_value_int32(env, argv[1], &q));
+  return control_result(env, speexhip_resampler_set_quality(st, q));
+}
+
+static napi_value SkipZeros(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  if (st == NULL) return NULL;
+  return control_result(env, speexhip_resampler_skip_zeros(st));
+}
+
+static napi_value ResetMem(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  if (st == NULL) return NULL;
+  return control_result(env, speexhip_resampler_reset_mem(st));
+}
+
+static napi_value pair_u32(napi_env env, uint32_t a, uint32_t b) {
+  napi_value arr, v;
+  NAPI_OK(napi_create_array_with_length(env, 2, &arr));
+  NAPI_OK(napi_create_uint32(env, a, &v));
+  NAPI_OK(napi_set_element(env, arr, 0, v));
+  NAPI_OK(napi_create_uint32(env, b, &v));
+  NAPI_OK(napi_set_element(env, arr, 1, v));
+  return arr;
+}
+
+/* getLatency(handle) -> [inputLatencyFrames, outputLatencyFrames] */
+static napi_value GetLatency(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  if (st == NULL) return NULL;
+  return pair_u32(env, (uint32_t)speexhip_resampler_get_input_latency(st),
+                  (uint32_t)speexhip_resampler_get_output_latency(st));
 }
 
 static napi_value SetMode(napi_env env, napi_callback_info info) {
@@ -109,9 +414,7 @@ static napi_value SetMode(napi_env env, napi_callback_info info) {
   if (st == NULL) return NULL;
   int32_t mode = 0;
   NAPI_OK(napi_get_value_int32(env, argv[1], &mode));
-  int rc = speexhip_resampler_set_mode(st, mode);
-  if (rc != 0) napi_throw_error(env, NULL, speexhip_resampler_strerror(rc));
-  return NULL;
+  return control_result(env, speexhip_resampler_set_mode(st, mode));
 }
 
 static napi_value GetInfo(napi_env env, napi_callback_info info) {
@@ -133,6 +436,7 @@ static napi_value GetInfo(napi_env env, napi_callback_info info) {
   PUT_U32(in_rate) PUT_U32(out_rate) PUT_U32(num_rate) PUT_U32(den_rate) PUT_U32(nb_channels)
   PUT_I32(quality) PUT_U32(filt_len) PUT_U32(oversample) PUT_U32(sinc_table_length) PUT_I32(kernel)
   PUT_I32(mode) PUT_I32(fast_path) PUT_I32(last_sample) PUT_U32(samp_frac_num) PUT_I32(device)
+  PUT_U32(magic_samples) PUT_U32(block_in)
   return obj;
 }
 
@@ -146,13 +450,7 @@ static napi_value GetRate(napi_env env, napi_callback_info info) {
   if (st == NULL) return NULL;
   uint32_t a = 0, b = 0;
   speexhip_resampler_get_rate(st, &a, &b);
-  napi_value arr, v;
-  NAPI_OK(napi_create_array_with_length(env, 2, &arr));
-  NAPI_OK(napi_create_uint32(env, a, &v));
-  NAPI_OK(napi_set_element(env, arr, 0, v));
-  NAPI_OK(napi_create_uint32(env, b, &v));
-  NAPI_OK(napi_set_element(env, arr, 1, v));
-  return arr;
+  return pair_u32(env, a, b);
 }
 
 static napi_value StrError(napi_env env, napi_callback_info info) {
@@ -176,7 +474,16 @@ static napi_value Version(napi_env env, napi_callback_info info) {
 static napi_value ModuleInit(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"init", NULL, Init, NULL, NULL, NULL, napi_default, NULL},
+      {"destroy", NULL, Destroy, NULL, NULL, NULL, napi_default, NULL},
       {"process", NULL, Process, NULL, NULL, NULL, napi_default, NULL},
+      {"processFloat", NULL, ProcessFloat, NULL, NULL, NULL, napi_default, NULL},
+      {"processChunks", NULL, ProcessChunks, NULL, NULL, NULL, napi_default, NULL},
+      {"processAsync", NULL, ProcessAsync, NULL, NULL, NULL, napi_default, NULL},
+      {"setRate", NULL, SetRate, NULL, NULL, NULL, napi_default, NULL},
+      {"setQuality", NULL, SetQuality, NULL, NULL, NULL, napi_default, NULL},
+      {"skipZeros", NULL, SkipZeros, NULL, NULL, NULL, napi_default, NULL},
+      {"resetMem", NULL, ResetMem, NULL, NULL, NULL, napi_default, NULL},
+      {"getLatency", NULL, GetLatency, NULL, NULL, NULL, napi_default, NULL},
       {"setMode", NULL, SetMode, NULL, NULL, NULL, napi_default, NULL},
       {"getInfo", NULL, GetInfo, NULL, NULL, NULL, napi_default, NULL},
       {"getRate", NULL, GetRate, NULL, NULL, NULL, napi_default, NULL},

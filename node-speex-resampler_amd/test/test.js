@@ -112,6 +112,122 @@ function errorTest() {
   assert(new SpeexResampler(1, 8000, 8000, 0).processChunk(Buffer.alloc(320)).length > 0, 'quality 0 accepted');
 }
 
+function lcgFloat(frames, channels, seed) {
+  const pcm = lcg(frames, channels, seed);
+  const f = new Float32Array(frames * channels);
+  for (let i = 0; i < f.length; i++) f[i] = pcm.readInt16LE(i * 2) / 32768;
+  return Buffer.from(f.buffer);
+}
+
+// SURVEY 8(f) rows N1-N4 through the JS / N-API surface.
+async function extensionsTest() {
+  const addon = require('../speex_hip_napi.node');
+  const mk = (mode) => {
+    const r = new SpeexResampler(2, 44100, 48000, 7);
+    r.processChunk(Buffer.alloc(0));
+    addon.setMode(r._resamplerPtr, mode);
+    return r;
+  };
+  // N1: coalesced chunks and async calls return the bytes of the separate synchronous calls --
+  // incl. 100-frame chunks, where the capacity rule drops input (F5)
+  const sizes = [4410, 100, 100, 7, 0, 4410, 333, 100, 2, 9000];
+  const chunks = sizes.map((n, i) => lcg(n, 2, 900 + i));
+  for (const mode of [1, 0]) {
+    const a = mk(mode), b = mk(mode), c = mk(mode);
+    const want = chunks.map((ch) => a.processChunk(ch));
+    const got = b.processChunks(chunks);
+    const promised = await Promise.all(chunks.map((ch) => c.processChunkAsync(ch))); // queued at once
+    assert(got.length === want.length, 'processChunks: count');
+    for (let i = 0; i < want.length; i++) {
+      assert(got[i].equals(want[i]), `processChunks: chunk ${i} differs (mode ${mode})`);
+      assert(promised[i].equals(want[i]), `processChunkAsync: chunk ${i} differs (mode ${mode})`);
+    }
+    const ia = addon.getInfo(a._resamplerPtr), ib = addon.getInfo(b._resamplerPtr), ic = addon.getInfo(c._resamplerPtr);
+    assert(ia.last_sample === ib.last_sample && ia.samp_frac_num === ib.samp_frac_num, 'processChunks: state');
+    assert(ia.last_sample === ic.last_sample && ia.samp_frac_num === ic.samp_frac_num, 'processChunkAsync: state');
+  }
+  const rejected = await new SpeexResampler(2, 44100, 48000).processChunkAsync(Buffer.alloc(7)).then(() => null, (e) => e.message);
+  assert(rejected === 'Chunk length should be a multiple of channels * 2 bytes', 'async length check');
+
+  // N1: the Transform options leave the bytes alone
+  const pcm = lcg(44100, 2, 31337);
+  const parts = [];
+  for (let o = 0; o < pcm.length; o += 4097) parts.push(pcm.slice(o, o + 4097));
+  const pipe = async (options) => {
+    const t = new SpeexResamplerTransform(2, 44100, 48000, 7, options);
+    let out = Buffer.alloc(0);
+    t.on('data', (d) => { out = Buffer.concat([out, d]); });
+    Readable.from(parts).pipe(t);
+    await new Promise((res, rej) => { t.on('end', res); t.on('error', rej); });
+    return [out, t];
+  };
+  const [plain] = await pipe(undefined);
+  const [coalesced] = await pipe({ coalesceChunks: 8 });
+  const [asynced] = await pipe({ async: true });
+  const [tailed, tt] = await pipe({ coalesceChunks: 5, flushTail: true });
+  assert(coalesced.equals(plain), 'Transform coalesceChunks changed the bytes');
+  assert(asynced.equals(plain), 'Transform async changed the bytes');
+  assert(tailed.slice(0, plain.length).equals(plain), 'Transform flushTail changed the stream');
+  const tailFrames = (tailed.length - plain.length) / 4;
+  assert(Math.abs(tailFrames - tt.resampler.outputLatency) <= 2, `flush tail of ${tailFrames} frames`);
+
+  // N2 + N3 through the addon: the reference's recorded control scripts (EXACT mode)
+  let ops = 0;
+  for (const c of golden.control_cases.slice(0, 12)) {
+    const h = addon.init(c.channels, c.in_rate, c.out_rate, c.quality);
+    addon.setMode(h, 1);
+    c.ops.forEach((op, k) => {
+      const want = c.results[k];
+      const kind = op[0];
+      let head = [];
+      if (kind === 'int' || kind === 'float' || kind === 'int_null' || kind === 'float_null') {
+        const isFloat = kind.startsWith('float');
+        const buf = kind.endsWith('_null') ? null : (isFloat ? lcgFloat(op[1], c.channels, op[3]) : lcg(op[1], c.channels, op[3]));
+        const out = (isFloat ? addon.processFloat : addon.process)(h, buf, op[1], op[2]);
+        head = [out.length / c.channels / (isFloat ? 4 : 2), sha1(out).slice(0, 16)];
+        assert(head[0] === want[1] && head[1] === want[2], `${c.name} op ${k} ${JSON.stringify(op)}: output differs`);
+      } else {
+        let rc = 0;
+        try {
+          if (kind === 'rate') addon.setRate(h, op[1], op[2]);
+          else if (kind === 'ratefrac') addon.setRate(h, op[1], op[2], op[3], op[4]);
+          else if (kind === 'quality') addon.setQuality(h, op[1]);
+          else if (kind === 'skip') addon.skipZeros(h);
+          else addon.resetMem(h);
+        } catch (e) { rc = e.message; }
+        assert(rc === (want[0] === 0 ? 0 : addon.strerror(want[0])), `${c.name} op ${k}: rc ${rc}`);
+      }
+      const st = want.slice(want.length - 10);
+      const i = addon.getInfo(h), lat = addon.getLatency(h);
+      const got = [i.last_sample, i.samp_frac_num, i.magic_samples, i.filt_len, lat[0], lat[1], i.in_rate, i.out_rate, i.num_rate, i.den_rate];
+      assert(JSON.stringify(got) === JSON.stringify(st), `${c.name} op ${k}: state ${got} want ${st}`);
+      ops++;
+    });
+    addon.destroy(h);
+    let dead = null;
+    try { addon.process(h, Buffer.alloc(0), 0, 0); } catch (e) { dead = e.message; }
+    assert(dead === 'Bad resampler state.', 'destroyed handle must refuse calls');
+  }
+  console.log(`control-script ops replayed through the addon: ${ops}`);
+
+  // N3/N4 on the class: setters before and after the lazy init, flush, destroy + re-init
+  const r = new SpeexResampler(1, 16000, 48000, 4);
+  r.setQuality(6);
+  assert(r.processChunk(lcg(1600, 1, 5)).length === 4800 * 2, 'x3 upsampling length');
+  r.setRate(16000, 8000);
+  assert(addon.getRate(r._resamplerPtr).join() === '16000,8000', 'setRate reached the native state');
+  assert(r.inputLatency > 0 && r.outputLatency > 0, 'latencies');
+  const f32 = r.processChunkFloat(lcgFloat(1600, 1, 6));
+  assert(f32.length % 4 === 0 && f32.length / 4 >= 700 && f32.length / 4 <= 800, 'float call on the same state');
+  assert(r.flush().length > 0, 'flush emits the tail');
+  r.skipZeros(); r.resetMem();
+  r.destroy();
+  assert(r._resamplerPtr === undefined && r.processChunk(lcg(160, 1, 7)).length > 0, 'destroy then lazy re-init');
+  let msg = null;
+  try { r.setQuality(42); } catch (e) { msg = e.message; }
+  assert(msg === 'Invalid argument.', 'setQuality(42) must throw the reference message');
+}
+
 (async () => {
   const early = (() => { try { new SpeexResampler(1, 8000, 8000).processChunk(Buffer.alloc(2)); return null; } catch (e) { return e.message; } })();
   assert(early === 'You need to wait for SpeexResampler.initPromise before calling this method', 'initPromise guard');
@@ -120,5 +236,6 @@ function errorTest() {
   await streamBasedTest();
   goldenTest();
   errorTest();
+  await extensionsTest();
   console.log('ALL NODE TESTS PASSED');
 })().catch((e) => { console.error(e); process.exit(1); });
