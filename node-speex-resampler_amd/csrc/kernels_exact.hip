@@ -219,21 +219,17 @@ hipError_t launch_k(const ExactParams &p, const StreamDesc *d_descs, const DescP
   DescPack empty;
   if (pack != nullptr) {
     auto kern = resample_exact<KIND, CT, STAGED, true, T>;
-    static bool lds_opt_in = false;  // once per kernel: allow the full 160 KiB of dynamic LDS
-    if (!lds_opt_in) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      lds_opt_in = true;
-    }
+    // once per kernel (thread-safe static init): allow the full 160 KiB of dynamic LDS
+    static const hipError_t lds_opt_in = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)lds_opt_in;
     hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, nullptr, *pack);
   } else {
     auto kern = resample_exact<KIND, CT, STAGED, false, T>;
-    static bool lds_opt_in = false;  // once per kernel: allow the full 160 KiB of dynamic LDS
-    if (!lds_opt_in) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      lds_opt_in = true;
-    }
+    // once per kernel (thread-safe static init): allow the full 160 KiB of dynamic LDS
+    static const hipError_t lds_opt_in = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)lds_opt_in;
     memset(&empty, 0, sizeof(empty));
     hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, d_descs, empty);
   }

@@ -311,16 +311,16 @@ hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const Des
                      bool persistent, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
-  static bool once = false;
-  if (!once) {
+  static const bool once = [] {  // thread-safe static init: calls may come from several host threads
     opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, true, T>);
     opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, false, T>);
     opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, true, T>);
     opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, false, T>);
     opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true, T>);
     opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false, T>);
-    once = true;
-  }
+    return true;
+  }();
+  (void)once;
   static const bool wide = std::getenv("SPEEXHIP_WIDE") && std::atoi(std::getenv("SPEEXHIP_WIDE")) != 0;
   if (persistent && wide) {
     if (pack != nullptr)

@@ -214,14 +214,14 @@ hipError_t launch_up(const SlideParams &p, const StreamDesc *d_descs, const Desc
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
-  static bool once = false;
-  if (!once) {
+  static const bool once = [] {  // thread-safe static init: calls may come from several host threads
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, true, T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, false, T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    once = true;
-  }
+    return true;
+  }();
+  (void)once;
   if (pack != nullptr)
     hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, true, T>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, nullptr, *pack);
