@@ -221,11 +221,14 @@ __device__ __forceinline__ void window_commit(float *xs, const StreamDesc &d, co
 
 // Two floats -> packed s16 pair {lo, hi} with the reference's rounding: floor(x + .5), then
 // saturation to [-32768, 32767] (equivalent to arch.h:208-209: the < -32767.5 / > 32766.5
-// branches are the clamp of floor(x + .5)).  The fp32 add is exact for every x but
-// 0.5 - 2^-25, so no double arithmetic is needed on the fast path.
+// branches are the clamp of floor(x + .5)).  v_cvt_rpi_i32_f32 IS floor(x + .5) ("round to plus
+// infinity" of the halves): one instruction per sample instead of add + floor + convert.
+// tools/check_rpi.hip compared it on gfx950 with floor(.5 + (double)x) for every multiple of
+// 1/64 in [-40000, 40000] and the +-1 ulp neighbours of every half-integer: no difference.
 __device__ __forceinline__ uint32_t round_pack_pcm(float lo, float hi) {
-  const int a = static_cast<int>(floorf(lo + 0.5f));
-  const int b = static_cast<int>(floorf(hi + 0.5f));
+  int a, b;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(a) : "v"(lo));
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(b) : "v"(hi));
   typedef short short2_t __attribute__((ext_vector_type(2)));
   const short2_t pk = __builtin_amdgcn_cvt_pk_i16(a, b);  // saturating v_cvt_pk_i16_i32
   return __builtin_bit_cast(uint32_t, pk);

@@ -65,6 +65,7 @@ struct PeriodParams {
   uint32_t wave_groups;   // waves per workgroup; wave w of split z takes groups z*wave_groups+w, ...
   uint32_t tail_frames;   // input frames a period needs beyond its start
   uint32_t history_block; // one-shot form: blockIdx.x of the workgroup that rolls the history
+  uint32_t image_stride;  // != 0: outputs leave through an LDS image, rows this many dwords apart
   uint32_t pad;           // LDS bank padding: floats inserted after every period of the window
   uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP), 0 in normal operation
 };

@@ -53,6 +53,166 @@ __device__ __forceinline__ void fma_tap(f32x2 &acc, const f32x2 &tap_pair, const
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
 }
 
+// What a lane needs to know about its place in a tile.
+struct LaneCtx {
+  uint32_t C;       // channels per frame
+  uint32_t cg;      // channel group of this lane
+  bool live;        // the lane's period exists in this tile
+  uint32_t xlane;   // float index of the lane's first sample of a group with delta_g = 0
+  uint64_t K_lane;  // canonical output index of the lane's period, phase 0
+};
+
+template <int CT, bool ONE_GROUP, bool PADDED>
+__device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshift, uint32_t m_lo,
+                                            uint32_t m_cnt, uint32_t lane) {
+  // ONE_GROUP: the frame is exactly one channel group (mono, stereo): the sample stride is a
+  // compile-time constant and the LDS reads of an iteration share one address register.
+  LaneCtx c;
+  c.C = ONE_GROUP ? static_cast<uint32_t>(CT) : p.channels;
+  c.cg = ONE_GROUP ? 0 : lane % p.cgroups;
+  const uint32_t pl = ONE_GROUP ? lane : lane / p.cgroups;  // period of this lane inside the tile
+  c.live = pl < m_cnt;
+  // PADDED: the LDS image carries p.pad floats after every period (num frames) so that the
+  // lanes of a wave -- num*C floats apart, a multiple of the bank count for e.g. 8 channels at
+  // num = 160 -- hit distinct banks; the per-step offset is then wave-uniform scalar arithmetic.
+  c.xlane = xshift + min(pl, p.lane_periods - 1) * (p.num * c.C + (PADDED ? p.pad : 0u)) + c.cg * CT;
+  c.K_lane = static_cast<uint64_t>(m_lo + pl) * p.den;
+  return c;
+}
+
+// acc[i] += sum over iterations [it_lo, it_hi) of group g's taps times the lane's samples.
+template <int R, int CT, bool PADDED>
+__device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
+                                          const LaneCtx &c, uint32_t g, uint32_t it_lo, uint32_t it_hi,
+                                          f32x2 (&acc)[R]) {
+  const uint32_t C = c.C;
+  const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
+  // (delta_g < num: no padding boundary before the group's first sample)
+  const float *xp = xs + c.xlane + delta_g * C + it_lo * 4 * C;
+  // padded layout: the host shifted this group's start by <= 3 frames so that the one padding
+  // boundary its window crosses falls between iterations wrap_it-1 and wrap_it
+  const uint32_t wrap_it = PADDED ? p.delta[p.groups + g] : 0xffffffffu;
+  // Taps are wave-uniform: they travel HBM/L2 -> scalar cache -> SGPRs (s_load: the row pointer
+  // is a __restrict__ kernel argument, so the loads are provably invariant) and feed
+  // v_pk_fma_f32 directly.
+  // Bank A = steps 0-1 of an iteration, bank B = steps 2-3: each bank is its 2R taps (R SGPR
+  // pairs) plus its two sample reads.  Order per iteration, pinned with sched_barrier:
+  //   wait A | issue loads B | 2R FMAs A | wait B | issue loads A(next) | 2R FMAs B
+  // A wait is lgkmcnt(0) (scalar loads return out of order and share the counter with LDS),
+  // so a bank's loads must be issued right AFTER the other bank's wait; `touch_bank` is an
+  // empty asm that reads the bank and thereby makes hipcc put the wait exactly there.
+  const float *__restrict__ trow = rows + (static_cast<size_t>(g) * p.l4 + it_lo) * (4 * R);
+  f32x2 ta[R], tb[R], xa[2], xb[2];
+  auto load_bank = [&](f32x2 (&t)[R], f32x2 (&x)[2], const float *tp, const float *sp) {
+#pragma unroll
+    for (int j = 0; j < R; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (CT == 2) {
+        x[u] = *reinterpret_cast<const f32x2 *>(sp + u * C);
+      } else {
+        x[u].x = sp[u * C];
+        x[u].y = 0.f;
+      }
+    }
+  };
+  auto touch_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
+    asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
+                 "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]));
+  };
+  auto fma_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int i = 0; i < R; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
+  };
+  static_assert(R == 10, "touch_bank lists R = 10 tap pairs");
+  load_bank(ta, xa, trow, xp);
+  for (uint32_t it = it_lo; it < it_hi; it++) {
+    touch_bank(ta, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    load_bank(tb, xb, trow + 2 * R, xp + 2 * C);
+    __builtin_amdgcn_sched_barrier(0);
+    fma_bank(ta, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    touch_bank(tb, xb);
+    __builtin_amdgcn_sched_barrier(0);
+    trow += 4 * R;
+    xp += 4 * C + ((PADDED && it + 1 == wrap_it) ? p.pad : 0u);  // wave-uniform select
+    // next iteration's bank A: the rows carry one iteration of zero padding past the last
+    // group and the window one step group of slack, so the final prefetch stays in bounds
+    load_bank(ta, xa, trow, xp);
+    __builtin_amdgcn_sched_barrier(0);
+    fma_bank(tb, xb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  touch_bank(ta, xa);  // retire the last prefetch
+}
+
+// Round / interleave / store the R phases of group g for this lane's period: R consecutive
+// frames per lane, 4 bytes each per channel pair.  With two workgroups per CU the stores
+// overlap the other workgroup's FMAs (an LDS transpose for fully coalesced stores measured
+// slower).
+template <int R, int CT, bool ONE_GROUP, typename T>
+__device__ __forceinline__ void store_group(const PeriodParams &p, const StreamDesc &d, const LaneCtx &c,
+                                            uint32_t g, const f32x2 (&acc)[R]) {
+  const uint32_t C = c.C, cg = c.cg;
+  // rows i in [i_lo, i_hi) of this group are real phases that fall inside this call
+  const int64_t k0 = static_cast<int64_t>(c.K_lane) + static_cast<int64_t>(g) * R - d.k_shift;
+  const int64_t lo64 = k0 < 0 ? -k0 : 0;
+  const int64_t hi64 = min(static_cast<int64_t>(R), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * R,
+                                                       static_cast<int64_t>(d.n_out) - k0));
+  const int i_lo = static_cast<int>(min(lo64, static_cast<int64_t>(R)));
+  const int i_hi = static_cast<int>(max(hi64, static_cast<int64_t>(0)));
+  if constexpr (sizeof(T) == 4) {
+    // float I/O (resample.c:927-963): the FIR value as is
+    G<float> *o = out_ptr<float>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
+    if (ONE_GROUP && CT == 2 && i_lo == 0 && i_hi == R) {
+      static_assert(R % 2 == 0, "R frames of 2 floats go out as R/2 float4");
+#pragma unroll
+      for (int i = 0; i < R; i += 2)
+        *(G<f32x4_a4> *)(o + 2 * i) = f32x4_a4{acc[i].x, acc[i].y, acc[i + 1].x, acc[i + 1].y};
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++, o += C) {
+      if (i < i_lo || i >= i_hi) continue;
+      o[0] = acc[i].x;
+      if (CT == 2) o[1] = acc[i].y;
+    }
+  } else {
+    g_i16 *o = out_ptr<int16_t>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
+    const bool aligned = CT == 2 && ((reinterpret_cast<uintptr_t>(d.out) | (C * 2u)) & 3u) == 0;
+    if (ONE_GROUP && CT == 2 && aligned && i_lo == 0 && i_hi == R) {
+      // the lane's R frames are R consecutive dwords: 16 + 16 + 8 bytes instead of R narrow
+      // stores (each store instruction costs one line request per lane whatever its width)
+      uint32_t v[R];
+#pragma unroll
+      for (int i = 0; i < R; i++) v[i] = round_pack_pcm(acc[i].x, acc[i].y);
+      g_u32x4_a4 *o4 = (g_u32x4_a4 *)o;
+      o4[0] = u32x4_a4{v[0], v[1], v[2], v[3]};
+      o4[1] = u32x4_a4{v[4], v[5], v[6], v[7]};
+      *(g_u32x2_a4 *)(o + 16) = u32x2_a4{v[8], v[9]};
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++, o += C) {
+      if (i < i_lo || i >= i_hi) continue;
+      if (CT == 2) {
+        const uint32_t v = round_pack_pcm(acc[i].x, acc[i].y);
+        if (aligned) {
+          *(g_u32 *)o = v;
+        } else {
+          o[0] = static_cast<int16_t>(v & 0xffffu);
+          o[1] = static_cast<int16_t>(v >> 16);
+        }
+      } else {
+        o[0] = static_cast<int16_t>(round_pack_pcm(acc[i].x, 0.f) & 0xffffu);
+      }
+    }
+  }
+}
+
 // FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
 // followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
 template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T>
@@ -60,142 +220,78 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
                                          const StreamDesc &d, const float *xs, uint32_t xshift,
                                          uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
                                          uint32_t zsplit, uint32_t nsplit) {
-  // ONE_GROUP: the frame is exactly one channel group (mono, stereo): the sample stride is a
-  // compile-time constant and the LDS reads of an iteration share one address register.
-  const uint32_t C = ONE_GROUP ? static_cast<uint32_t>(CT) : p.channels;
-  const uint32_t cg = ONE_GROUP ? 0 : lane % p.cgroups;
-  const uint32_t pl = ONE_GROUP ? lane : lane / p.cgroups;  // period of this lane inside the tile
-  const bool lane_live = pl < m_cnt;
-  // float index of this lane's first sample of a group with delta_g = 0
-  // PADDED: the LDS image carries p.pad floats after every period (num frames) so that the
-  // lanes of a wave -- num*C floats apart, a multiple of the bank count for e.g. 8 channels at
-  // num = 160 -- hit distinct banks; the per-step offset is then wave-uniform scalar arithmetic.
-  const uint32_t xlane = xshift + min(pl, p.lane_periods - 1) * (p.num * C + (PADDED ? p.pad : 0u)) + cg * CT;
-  const uint64_t K_lane = static_cast<uint64_t>(m_lo + pl) * p.den;
-
+  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED>(p, xshift, m_lo, m_cnt, lane);
   const uint32_t g_step = p.wave_groups * nsplit;
   for (uint32_t g = zsplit * p.wave_groups + wave; g < p.groups; g += g_step) {
     f32x2 acc[R];  // .x = first channel of the pair, .y = second (unused when CT == 1)
 #pragma unroll
     for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
-    const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
-    const float *xp = xs + xlane + delta_g * C;  // delta_g < num: no padding boundary before it
-    const uint32_t n_it = (p.skip & 4u) ? 0 : p.l4;
-    // padded layout: the host shifted this group's start by <= 3 frames so that the one padding
-    // boundary its window crosses falls between iterations wrap_it-1 and wrap_it
-    const uint32_t wrap_it = PADDED ? p.delta[p.groups + g] : 0xffffffffu;
-    // Taps are wave-uniform: they travel HBM/L2 -> scalar cache -> SGPRs (s_load: the row pointer
-    // is a __restrict__ kernel argument, so the loads are provably invariant) and feed
-    // v_pk_fma_f32 directly.
-    // Bank A = steps 0-1 of an iteration, bank B = steps 2-3: each bank is its 2R taps (R SGPR
-    // pairs) plus its two sample reads.  Order per iteration, pinned with sched_barrier:
-    //   wait A | issue loads B | 2R FMAs A | wait B | issue loads A(next) | 2R FMAs B
-    // A wait is lgkmcnt(0) (scalar loads return out of order and share the counter with LDS),
-    // so a bank's loads must be issued right AFTER the other bank's wait; `touch_bank` is an
-    // empty asm that reads the bank and thereby makes hipcc put the wait exactly there.
-    const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (4 * R);
-    f32x2 ta[R], tb[R], xa[2], xb[2];
-    auto load_bank = [&](f32x2 (&t)[R], f32x2 (&x)[2], const float *tp, const float *sp) {
-#pragma unroll
-      for (int j = 0; j < R; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        if (CT == 2) {
-          x[u] = *reinterpret_cast<const f32x2 *>(sp + u * C);
-        } else {
-          x[u].x = sp[u * C];
-          x[u].y = 0.f;
-        }
-      }
-    };
-    auto touch_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
-      asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
-                   "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]));
-    };
-    auto fma_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int i = 0; i < R; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
-    };
-    static_assert(R == 10, "touch_bank lists R = 10 tap pairs");
-    load_bank(ta, xa, trow, xp);
-    for (uint32_t it = 0; it < n_it; it++) {
-      touch_bank(ta, xa);
-      __builtin_amdgcn_sched_barrier(0);
-      load_bank(tb, xb, trow + 2 * R, xp + 2 * C);
-      __builtin_amdgcn_sched_barrier(0);
-      fma_bank(ta, xa);
-      __builtin_amdgcn_sched_barrier(0);
-      touch_bank(tb, xb);
-      __builtin_amdgcn_sched_barrier(0);
-      trow += 4 * R;
-      xp += 4 * C + ((PADDED && it + 1 == wrap_it) ? p.pad : 0u);  // wave-uniform select
-      // next iteration's bank A: the rows carry one iteration of zero padding past the last
-      // group and the window one step group of slack, so the final prefetch stays in bounds
-      load_bank(ta, xa, trow, xp);
-      __builtin_amdgcn_sched_barrier(0);
-      fma_bank(tb, xb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    touch_bank(ta, xa);  // retire the last prefetch
-    if ((p.skip & 8u) || !lane_live) continue;
+    fir_group<R, CT, PADDED>(p, rows, xs, c, g, 0, (p.skip & 4u) ? 0 : p.l4, acc);
+    if ((p.skip & 8u) || !c.live) continue;
+    store_group<R, CT, ONE_GROUP, T>(p, d, c, g, acc);
+  }
+}
 
-    // ---- direct stores: R consecutive frames per lane, 4 bytes each per channel pair.  With
-    //      two workgroups per CU they overlap the other workgroup's FMAs (an LDS transpose
-    //      for fully coalesced stores measured slower).
-    // rows i in [i_lo, i_hi) of this group are real phases that fall inside this call
-    const int64_t k0 = static_cast<int64_t>(K_lane) + static_cast<int64_t>(g) * R - d.k_shift;
-    const int64_t lo64 = k0 < 0 ? -k0 : 0;
-    const int64_t hi64 = min(static_cast<int64_t>(R), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * R,
-                                                         static_cast<int64_t>(d.n_out) - k0));
-    const int i_lo = static_cast<int>(min(lo64, static_cast<int64_t>(R)));
-    const int i_hi = static_cast<int>(max(hi64, static_cast<int64_t>(0)));
-    if constexpr (sizeof(T) == 4) {
-      // float I/O (resample.c:927-963): the FIR value as is
-      G<float> *o = out_ptr<float>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
-      if (ONE_GROUP && CT == 2 && i_lo == 0 && i_hi == R) {
-        static_assert(R % 2 == 0, "R frames of 2 floats go out as R/2 float4");
+// Stereo int16, one pass over the groups: the tile's outputs -- frames K = m*den + r of 64
+// consecutive periods -- are one contiguous run in HBM, but a lane holds only R consecutive
+// frames of its own period (40 bytes at a 4*den-byte stride), and a store instruction costs one
+// L2 request per lane whatever its width: stores alone run at 2 TB/s that way.  Here the
+// workgroup lays its results out as an image in LDS (the window is dead by then), one row per
+// period, and writes whole rows: 16 bytes per lane, consecutive lanes, full cache lines.
+// Row stride = 2 (mod 4) dwords: the 32 lanes of a half-wave, one row apart, hit 32 distinct
+// banks when they deposit their dwords, and rows stay 8-byte aligned for the read-back.
+template <int R, bool PADDED>
+__device__ __forceinline__ void fir_tile_rows(const PeriodParams &p, const float *__restrict__ rows,
+                                              const StreamDesc &d, float *xs, uint32_t xshift, uint32_t m_lo,
+                                              uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit) {
+  const LaneCtx c = lane_ctx<2, true, PADDED>(p, xshift, m_lo, m_cnt, lane);
+  const uint32_t g0 = zsplit * p.wave_groups;  // this workgroup owns groups [g0, g0 + wave_groups)
+  const uint32_t g = g0 + wave;
+  const bool valid = g < p.groups;
+  f32x2 acc[R];
 #pragma unroll
-        for (int i = 0; i < R; i += 2)
-          *(G<f32x4_a4> *)(o + 2 * i) = f32x4_a4{acc[i].x, acc[i].y, acc[i + 1].x, acc[i + 1].y};
-        continue;
-      }
+  for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
+  if (valid && !(p.skip & 4u)) fir_group<R, 2, PADDED>(p, rows, xs, c, g, 0, p.l4, acc);
+  __syncthreads();  // every wave is done with the window
+  if (p.skip & 8u) return;
+
+  const uint32_t cols = min(p.wave_groups * R, p.den - g0 * R);  // frames of a row held by this workgroup
+  const uint32_t stride = p.image_stride;                          // dwords, even, = 2 (mod 4)
+  uint32_t *img = reinterpret_cast<uint32_t *>(xs);
+  if (valid && c.live) {
+    const uint32_t real = min(static_cast<uint32_t>(R), p.den - g * R);  // padding phases of the last group
+    uint32_t *row = img + lane * stride + wave * R;  // R even: 8-byte aligned
 #pragma unroll
-      for (int i = 0; i < R; i++, o += C) {
-        if (i < i_lo || i >= i_hi) continue;
-        o[0] = acc[i].x;
-        if (CT == 2) o[1] = acc[i].y;
-      }
-    } else {
-      g_i16 *o = out_ptr<int16_t>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
-      const bool aligned = CT == 2 && ((reinterpret_cast<uintptr_t>(d.out) | (C * 2u)) & 3u) == 0;
-      if (ONE_GROUP && CT == 2 && aligned && i_lo == 0 && i_hi == R) {
-        // the lane's R frames are R consecutive dwords: 16 + 16 + 8 bytes instead of R narrow
-        // stores (each store instruction costs one line request per lane whatever its width)
-        uint32_t v[R];
+    for (int i = 0; i < R; i += 2) {
+      const uint32_t a = round_pack_pcm(acc[i].x, acc[i].y), b = round_pack_pcm(acc[i + 1].x, acc[i + 1].y);
+      if (i + 1 < static_cast<int>(real))
+        *reinterpret_cast<uint2 *>(row + i) = make_uint2(a, b);
+      else if (i < static_cast<int>(real))
+        row[i] = a;
+    }
+  }
+  __syncthreads();
+
+  // copy-out: wave w takes rows w, w + nw, ...; lane l the dwords [4l, 4l+4) of the row
+  const uint32_t nw = blockDim.x >> 6;
+  g_u32 *out = reinterpret_cast<g_u32 *>(out_ptr<int16_t>(d));
+  for (uint32_t m = wave; m < m_cnt; m += nw) {
+    // canonical index of the row's first frame held here, relative to the call's first output
+    const int64_t k0 = static_cast<int64_t>(m_lo + m) * p.den + g0 * R - d.k_shift;
+    const int64_t lo = k0 < 0 ? -k0 : 0;                                        // first valid column
+    const int64_t hi = min<int64_t>(cols, static_cast<int64_t>(d.n_out) - k0);  // one past the last
+    const uint32_t *row = img + m * stride;
+    for (uint32_t j = 4 * lane; j < cols; j += 256) {
+      const uint2 v01 = *reinterpret_cast<const uint2 *>(row + j);
+      const uint2 v23 = *reinterpret_cast<const uint2 *>(row + j + 2);  // (rows carry 2+ dwords of slack)
+      g_u32 *o = out + (k0 + j);
+      if (static_cast<int64_t>(j) >= lo && static_cast<int64_t>(j) + 4 <= hi) {
+        *(g_u32x4_a4 *)o = u32x4_a4{v01.x, v01.y, v23.x, v23.y};
+      } else {
+        const uint32_t v[4] = {v01.x, v01.y, v23.x, v23.y};
 #pragma unroll
-        for (int i = 0; i < R; i++) v[i] = round_pack_pcm(acc[i].x, acc[i].y);
-        g_u32x4_a4 *o4 = (g_u32x4_a4 *)o;
-        o4[0] = u32x4_a4{v[0], v[1], v[2], v[3]};
-        o4[1] = u32x4_a4{v[4], v[5], v[6], v[7]};
-        *(g_u32x2_a4 *)(o + 16) = u32x2_a4{v[8], v[9]};
-        continue;
-      }
-#pragma unroll
-      for (int i = 0; i < R; i++, o += C) {
-        if (i < i_lo || i >= i_hi) continue;
-        if (CT == 2) {
-          const uint32_t v = round_pack_pcm(acc[i].x, acc[i].y);
-          if (aligned) {
-            *(g_u32 *)o = v;
-          } else {
-            o[0] = static_cast<int16_t>(v & 0xffffu);
-            o[1] = static_cast<int16_t>(v >> 16);
-          }
-        } else {
-          o[0] = static_cast<int16_t>(round_pack_pcm(acc[i].x, 0.f) & 0xffffu);
-        }
+        for (int e = 0; e < 4; e++)
+          if (static_cast<int64_t>(j) + e >= lo && static_cast<int64_t>(j) + e < hi) o[e] = v[e];
       }
     }
   }
@@ -210,6 +306,7 @@ template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
+  if (p.skip & 64u) return;  // diagnostics: bare dispatch cost
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == p.history_block) {
     if (blockIdx.z == 0) roll_history<T>(p.channels, d);
@@ -229,9 +326,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
     window_commit<3, T>(xs, d, wg, w);
   }
   __syncthreads();
+  if (p.skip & 128u) return;  // diagnostics: prologue + staging only
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (ONE_GROUP && CT == 2 && sizeof(T) == 2) {
+    // whole-row stores need dword-aligned frames (uniform per stream)
+    if (p.image_stride != 0 && (reinterpret_cast<uintptr_t>(d.out) & 3u) == 0) {
+      fir_tile_rows<R, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
+      return;
+    }
+  }
   fir_tile<R, CT, ONE_GROUP, PADDED, T>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
-                                     blockIdx.z, gridDim.z);
+                                        blockIdx.z, gridDim.z);
 }
 
 // Persistent form: gridDim.x workgroups (two per CU) walk the launch's flat tile list
@@ -484,7 +589,11 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   }();
   static const uint32_t per_cu = std::getenv("SPEEXHIP_WG_PER_CU") ? std::atoi(std::getenv("SPEEXHIP_WG_PER_CU")) : 2;
   const uint32_t resident = per_cu * static_cast<uint32_t>(device_cus);  // two workgroups fit per CU
-  static const bool allow_persistent = !(std::getenv("SPEEXHIP_PERSISTENT") && std::atoi(std::getenv("SPEEXHIP_PERSISTENT")) == 0);
+  // The persistent walk is opt-in (SPEEXHIP_PERSISTENT=1): with the GPU at its sustained clocks the
+  // plain grid is 7 % faster at 32 and 64 streams (212 vs 228 us) and equal below -- the hardware
+  // dispatcher refills a CU the moment a workgroup retires, which desynchronises the workgroups at
+  // least as well as the software walk does.
+  static const bool allow_persistent = std::getenv("SPEEXHIP_PERSISTENT") && std::atoi(std::getenv("SPEEXHIP_PERSISTENT")) != 0;
   // More tiles than resident workgroups: persistent walk of the tile list.  Fewer: one workgroup
   // per tile, and when even that leaves CUs idle (one short stream) the phase groups of a tile
   // are split over several workgroups.
@@ -495,7 +604,12 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
     splits = std::min<uint32_t>(force_splits, t.groups);
   else if (!persistent)
     // (measured on cfg2, one stream: 1/2/4/8 shares -> 19.6/15.1/16.0/27.3 us: split until the
-    //  launch has about one workgroup per CU, not more -- every share re-stages the window)
+    //  launch has about one workgroup per CU, not more -- every share re-stages the window.
+    //  Also tried: splitting each group's TAP range over the spare waves of a share, partial sums
+    //  meeting in LDS -- 15.7 us, the two extra barriers cost more than the occupancy gains.
+    //  Phase costs of the 14.6 us (rocprofv3, parts skipped): bare dispatch 2.3, descriptor +
+    //  geometry 1.1, window staging 1.6, FIR 7.3, stores 2.5 -- strictly serial in a launch that
+    //  is a single generation of workgroups.)
     while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident / 2 &&
            (t.groups + splits * 2 - 1) / (splits * 2) >= 2)
       splits *= 2;
@@ -516,6 +630,22 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   p.tail_frames = t.tail_frames;
   p.pad = t.pad;
   p.history_block = max_periods == 0 ? 0 : tiles;
+  // Whole-row stores through an LDS image (fir_tile_rows): stereo int16, one pass over the
+  // groups, image within the window's LDS.  Its two extra barriers only pay when the launch runs
+  // for several generations of workgroups (measured at sustained clocks: 32 streams 216 -> 212 us,
+  // but 4 streams 33.9 -> 35.1 and one stream 13.7 -> 14.9; stores alone 74 -> 48 us).
+  // (Also tried against lock-step between the two workgroups of a CU: delaying the first-generation
+  //  workgroup in the CU's odd slot (HW_ID.TG_ID) by half a tile -- no effect, they drift apart
+  //  on their own.)
+  static const int env_rows = std::getenv("SPEEXHIP_ROWS") ? std::atoi(std::getenv("SPEEXHIP_ROWS")) : -1;
+  const bool many_generations = static_cast<uint64_t>(tiles) * n_streams * splits >= 3ull * resident;
+  p.image_stride = 0;
+  if (!persistent && (env_rows > 0 || (env_rows < 0 && many_generations)) && !float_io && t.ct == 2 &&
+      t.cgroups == 1 && wave_groups * splits >= t.groups) {
+    uint32_t stride = (wave_groups * kR + 2 + 1) & ~1u;  // >= 2 dwords of slack, even
+    if (stride % 4 == 0) stride += 2;
+    if (static_cast<size_t>(stride) * t.lane_periods * 4 + 16 <= t.window_bytes) p.image_stride = stride;
+  }
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
   const uint32_t threads = wave_groups * 64;

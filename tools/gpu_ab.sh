@@ -1,11 +1,17 @@
 #!/bin/bash
-# tools/gpu_ab.sh -- diagnostics: single-stream geometry variants of the one-shot period kernel.
+# tools/gpu_ab.sh -- diagnostics at sustained clocks (bench.py preheats): a table of the BASELINE configs
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 : > $O/ab.txt
-for SPL in 1 2 4 8; do for SKIP in 0 2 4 8 32; do
-  echo -n "splits=$SPL skip=$SKIP " >> $O/ab.txt
-  SPEEXHIP_SPLITS=$SPL SPEEXHIP_SKIP=$SKIP timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-parity 2>/dev/null | python3 -c "
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 >> $O/ab.txt
+run() { echo -n "$1 $2 steps=$3 : " >> $O/ab.txt; env $1 timeout 300 python bench.py $2 --steps $3 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys, json
-d = json.loads(sys.stdin.readline()); print('launch_us', d['roofline']['launch_us'])" >> $O/ab.txt
-done; done
+d = json.loads(sys.stdin.readline()); print('launch_us', d['roofline']['launch_us'], 'value', d['value'], 'hbm', d['roofline']['frac'], 'valu', d['valu']['frac'], 'parity', d.get('parity'))" >> $O/ab.txt; }
+for CFG in cfg2 cfg3 cfg4 f3; do
+run "BENCH_STREAMS=1" "--config $CFG" 1000
+run "BENCH_STREAMS=32" "--config $CFG" 100
+done
+run "BENCH_STREAMS=1" "--io float" 1000
+run "BENCH_STREAMS=32" "--io float" 100
+run "BENCH_STREAMS=4" "" 500
+run "BENCH_STREAMS=1" "--mode exact" 500
 cat $O/ab.txt
