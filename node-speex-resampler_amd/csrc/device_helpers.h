@@ -85,16 +85,24 @@ struct WindowGeom {
   uint32_t xshift;             // float index of the window's first frame inside the image
   uint32_t pad, period_elems;  // bank padding: `pad` floats inserted after every period_elems
                                // (= num*channels) floats counted from the window's first frame
+  uint32_t period_magic;       // ceil(2^32 / period_elems): n / period_elems == umulhi(n, magic) for
+                               // the n < 2^17 that index an LDS image (host: period_magic_of)
 };
+
+// host + device: the multiplier above (exact for n * (magic*d - 2^32) < 2^32, i.e. n < 2^32 / d)
+__host__ __device__ inline uint32_t period_magic_of(uint32_t d) {
+  return d <= 1 ? 0u : static_cast<uint32_t>(((1ull << 32) + d - 1) / d);
+}
 
 template <typename T>
 __device__ __forceinline__ WindowGeom window_geom(const StreamDesc &d, uint32_t channels,
                                                   uint32_t num, uint32_t tail_frames, uint32_t m_lo,
-                                                  uint32_t m_cnt, uint32_t pad = 0) {
+                                                  uint32_t m_cnt, uint32_t pad = 0, uint32_t period_magic = 0) {
   constexpr int GS = PerLoad<T>::value;
   WindowGeom w;
   w.pad = pad;
   w.period_elems = num * channels;
+  w.period_magic = period_magic;
   w.hist_elems = static_cast<int64_t>(d.hist_frames) * channels;
   w.in_elems = static_cast<int64_t>(d.in_frames) * channels;
   const int64_t q_lo =
@@ -161,7 +169,9 @@ __device__ __forceinline__ void unpack_group(const u32x4 &w, float (&f)[4], floa
 // LDS float position of image float j when the layout is padded (pad floats after every
 // period_elems floats counted from the window's first frame, i.e. from image float xshift)
 __device__ __forceinline__ uint32_t padded_pos(const WindowGeom &g, uint32_t j) {
-  return j + (j >= g.xshift ? (j - g.xshift) / g.period_elems : 0u) * g.pad;
+  const uint32_t n = j >= g.xshift ? j - g.xshift : 0u;
+  const uint32_t period = g.period_magic ? __umulhi(n, g.period_magic) : n;  // n / period_elems
+  return j + period * g.pad;
 }
 
 // the floats of one group, image floats j .. j+GS-1 (j a multiple of GS): 16-byte LDS writes

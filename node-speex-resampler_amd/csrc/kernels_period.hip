@@ -90,8 +90,11 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   // (delta_g < num: no padding boundary before the group's first sample)
   const float *xp = xs + c.xlane + delta_g * C + it_lo * 4 * C;
   // padded layout: the host shifted this group's start by <= 3 frames so that the one padding
-  // boundary its window crosses falls between iterations wrap_it-1 and wrap_it
-  const uint32_t wrap_it = PADDED ? p.delta[p.groups + g] : 0xffffffffu;
+  // boundaries its window crosses fall between iterations (the first before iteration wrap_it)
+  // (counted DOWN to the next boundary, like the loop itself: with 80 SGPRs there is no register to
+  //  spare for loop bounds, and a bound reloaded from the kernel arguments drags an lgkmcnt(0) wait
+  //  -- i.e. the whole tap prefetch -- into every iteration)
+  uint32_t to_wrap = PADDED ? p.delta[p.groups + g] - it_lo : 0u;
   // Taps are wave-uniform: they travel HBM/L2 -> scalar cache -> SGPRs (s_load: the row pointer
   // is a __restrict__ kernel argument, so the loads are provably invariant) and feed
   // v_pk_fma_f32 directly.
@@ -128,7 +131,7 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   };
   static_assert(R == 10, "touch_bank lists R = 10 tap pairs");
   load_bank(ta, xa, trow, xp);
-  for (uint32_t it = it_lo; it < it_hi; it++) {
+  for (uint32_t left = it_hi - it_lo; left != 0; left--) {
     touch_bank(ta, xa);
     __builtin_amdgcn_sched_barrier(0);
     load_bank(tb, xb, trow + 2 * R, xp + 2 * C);
@@ -138,7 +141,11 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
     touch_bank(tb, xb);
     __builtin_amdgcn_sched_barrier(0);
     trow += 4 * R;
-    xp += 4 * C + ((PADDED && it + 1 == wrap_it) ? p.pad : 0u);  // wave-uniform select
+    xp += 4 * C;
+    if (PADDED && --to_wrap == 0) {  // wave-uniform: the window pointer steps over the bank padding
+      xp += p.pad;
+      to_wrap = p.wrap_step;         // the next period boundary, num/4 iterations on (or never)
+    }
     // next iteration's bank A: the rows carry one iteration of zero padding past the last
     // group and the window one step group of slack, so the final prefetch stays in bounds
     load_bank(ta, xa, trow, xp);
@@ -319,7 +326,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   if (m_lo >= m_total) return;
   const uint32_t m_cnt = min(p.lane_periods, m_total - m_lo);
 
-  const WindowGeom wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
+  const WindowGeom wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u,
+                                       PADDED ? p.period_magic : 0u);
   if (!(p.skip & 2u)) {
     u32x4 w[3];
     window_fetch<3, T>(wg, w);
@@ -366,7 +374,8 @@ __device__ __forceinline__ void persistent_body(const PeriodParams &p, const flo
     m_lo = (t - s * tiles_per_stream) * p.lane_periods;
     m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 0;
     if (m_cnt) {
-      wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u);
+      wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u,
+                                       PADDED ? p.period_magic : 0u);
       window_fetch<3, T>(wg, w);
     }
   };
@@ -472,45 +481,49 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
   t.row_len = (f.taps + dmax + 3) / 4 * 4;
   t.l4 = t.row_len / 4;
   t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * t.r * f.num) / f.den) + t.row_len;
-  t.lane_periods = 64 / t.cgroups;
+  t.lane_periods = 64 / t.cgroups;  // revised below once the window size is known
   // + one iteration (4R floats) of zero padding: the tap pipeline prefetches one past the end
   t.rows_floats = static_cast<size_t>(t.groups) * t.l4 * 4 * t.r + 4 * t.r;
-  // Bank padding: the lanes of a wave read the window num*channels floats apart.  Find the
-  // smallest pad (multiple of 4 floats, inserted after every period) for which the 32 lanes of a
-  // half-wave hit 32 distinct banks (ds_read_b32) / bank pairs (ds_read_b64).
+  // Bank padding: the lanes of a wave read the window num*channels floats apart.  Pick the pad
+  // (multiple of 4 floats, inserted after every period) with the fewest lanes of a half-wave on
+  // the same bank (ds_read_b32) / bank pair (ds_read_b64); 1 = conflict-free.
+  auto worst_bank_load = [&](uint32_t pad) {
+    const uint32_t unit = t.ct;  // floats per lane access
+    const uint32_t stride = f.num * channels + pad;
+    uint32_t count[64] = {0}, worst = 0;
+    for (uint32_t lane = 0; lane < 32; lane++) {
+      const uint32_t cg = lane % t.cgroups, pl = lane / t.cgroups;
+      const uint32_t slot = ((pl * stride + cg * t.ct) / unit) % (64 / unit);
+      worst = std::max(worst, ++count[slot]);
+    }
+    return worst;
+  };
   t.pad = 0;
   {
-    const uint32_t unit = t.ct;  // floats per lane access
-    for (uint32_t pad = 0; pad <= 64; pad += 4) {
-      const uint32_t stride = f.num * channels + pad;
-      bool seen[64] = {false};
-      bool ok = true;
-      for (uint32_t lane = 0; lane < 32 && ok; lane++) {
-        const uint32_t cg = lane % t.cgroups, pl = lane / t.cgroups;
-        if (pl >= t.lane_periods) break;
-        const uint32_t slot = ((pl * stride + cg * t.ct) / unit) % (64 / unit);
-        ok = !seen[slot];
-        seen[slot] = true;
-      }
-      if (ok) {
+    uint32_t best = worst_bank_load(0);
+    for (uint32_t pad = 4; pad <= 64 && best > 1; pad += 4) {
+      const uint32_t w = worst_bank_load(pad);
+      if (w < best) {
+        best = w;
         t.pad = pad;
-        break;
       }
     }
   }
   static const bool no_pad = std::getenv("SPEEXHIP_NO_PAD") != nullptr;
   if (no_pad) t.pad = 0;
+  if (std::getenv("SPEEXHIP_PAD")) t.pad = static_cast<uint32_t>(std::atoi(std::getenv("SPEEXHIP_PAD"))) & ~3u;  // diagnostics
   if (t.pad != 0) {
-    // A padded window is only walked cheaply if each group crosses at most ONE period boundary
-    // and that boundary can be moved onto an iteration boundary by starting the group k <= 3
-    // frames early (k extra zero taps in front of its rows).
+    // A padded window is only walked cheaply if every period boundary a group's window crosses
+    // falls between two iterations: the first one is moved there by starting the group k <= 3
+    // frames early (k extra zero taps in front of its rows); further ones follow num/4
+    // iterations apart, which needs num to be a multiple of 4.
     const uint32_t row_len = (f.taps + dmax + 3 + 3) / 4 * 4;
     bool ok = true;
     for (uint32_t g = 0; g < t.groups && ok; g++) {
       const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
       if (dg + row_len + 4 <= f.num) continue;                 // never reaches the boundary
       const uint32_t k = (dg % 4 + 4 - f.num % 4) % 4;  // delta' = dg - k == num (mod 4)
-      ok = dg >= k && (dg - k) + row_len + 4 <= 2 * f.num;     // shiftable, and a single crossing
+      ok = dg >= k && ((dg - k) + row_len + 4 <= 2 * f.num || f.num % 4 == 0);
     }
     if (ok) {
       t.row_len = row_len;
@@ -523,13 +536,33 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
   }
   // (+ 4 frames: the tap/sample pipeline prefetches one bank past the last step; + the padding
   //  of every period the window can touch)
-  const size_t pad_floats = static_cast<size_t>(t.pad) * (t.lane_periods + t.tail_frames / f.num + 2);
-  t.window_bytes = (((static_cast<size_t>(t.lane_periods) - 1) * f.num + t.tail_frames + 4) * channels + pad_floats) * 4 +
+  auto window_bytes_for = [&](uint32_t lane_periods) {
+    const size_t pad_floats = static_cast<size_t>(t.pad) * (lane_periods + t.tail_frames / f.num + 2);
+    size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + 4) * channels + pad_floats) * 4 +
                    kSlack * 4;
-  // the same LDS later holds the tile's output image (one packed s16 pair per dword)
-  t.window_bytes = std::max(t.window_bytes, static_cast<size_t>(t.lane_periods) * f.den * t.cgroups * 4);
+    // the same LDS later holds the tile's output image (one packed s16 pair per dword)
+    return std::max(bytes, static_cast<size_t>(lane_periods) * f.den * t.cgroups * 4);
+  };
+  // Periods per tile: all the lanes of a wave if that leaves room for TWO workgroups per CU (one
+  // workgroup's staging and stores only overlap FMAs if another one is resident; measured on the
+  // 8-channel 48k->44.1k case: 811 -> 738 us with 15 of 16 periods).  Otherwise weigh a second
+  // workgroup (~20 %) against the lanes it costs.
+  const uint32_t full = 64 / t.cgroups;
+  const size_t half_lds = 80 * 1024;
+  uint32_t fit_half = 0, fit_all = 0;
+  for (uint32_t lp = full; lp >= 1; lp--) {
+    const size_t bytes = window_bytes_for(lp);
+    if (fit_all == 0 && bytes <= lds_budget) fit_all = lp;
+    if (bytes <= half_lds) {
+      fit_half = lp;
+      break;
+    }
+  }
+  t.lane_periods = (fit_half != 0 && 5 * fit_half >= 4 * fit_all) ? fit_half : fit_all;
+  t.window_bytes = t.lane_periods ? window_bytes_for(t.lane_periods) : 0;
   // needs enough phases to fill the R-wide register tile and a window that fits one CU's LDS
-  t.usable = f.den >= 7 && t.cgroups <= 64 && t.lane_periods >= 1 && t.window_bytes <= lds_budget;
+  // ... and at least a quarter of each wave at work (below that the exact kernel's mapping wins)
+  t.usable = f.den >= 7 && t.cgroups <= 64 && 4 * t.lane_periods >= full && t.window_bytes <= lds_budget;
   return t;
 }
 
@@ -629,6 +662,8 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   p.wave_groups = wave_groups;
   p.tail_frames = t.tail_frames;
   p.pad = t.pad;
+  p.wrap_step = f.num % 4 == 0 ? f.num / 4 : 0x40000000u;
+  p.period_magic = period_magic_of(f.num * channels);
   p.history_block = max_periods == 0 ? 0 : tiles;
   // Whole-row stores through an LDS image (fir_tile_rows): stereo int16, one pass over the
   // groups, image within the window's LDS.  Its two extra barriers only pay when the launch runs
