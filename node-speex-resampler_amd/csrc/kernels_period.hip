@@ -305,10 +305,11 @@ __device__ __forceinline__ void fir_tile_rows(const PeriodParams &p, const float
 }
 
 // <= 80 SGPRs: the hardware admits 8 waves per SIMD (two 16-wave workgroups per CU) only then
-// (MI355X_MICROARCH.md, residency); the compiler alone settles at ~106.
+// (MI355X_MICROARCH.md, residency; measured again with caps of 88, 90 and 96: 206 -> 260 us);
+// the compiler alone settles at ~106.
 //
-// One-shot form: workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one
-// of gridDim.z shares of its phase groups.  Used when a launch has too few tiles to loop over.
+// Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
+// shares of its phase groups.
 template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
@@ -347,72 +348,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
                                         blockIdx.z, gridDim.z);
 }
 
-// Persistent form: gridDim.x workgroups (two per CU) walk the launch's flat tile list
-// T = stream * tiles_per_stream + tile.  While the FIR of tile T runs, the 16-byte loads of the
-// next tile's input window are already in flight (registers), so HBM latency, the int16->float
-// conversion and the stores of one workgroup hide behind the other's FMAs and the workgroups
-// never fall into lock-step the way back-to-back launches of the one-shot form do.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
-__device__ __forceinline__ void persistent_body(const PeriodParams &p, const float *__restrict__ rows,
-                                                const StreamDesc *streams, const DescPack &pack,
-                                                uint32_t n_streams, uint32_t tiles_per_stream, float *xs) {
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t s = blockIdx.x; s < n_streams; s += gridDim.x)  // history rolls ride along
-    roll_history<T>(p.channels, PACKED ? pack.d[s] : streams[s]);
-
-  const uint32_t total = n_streams * tiles_per_stream;
-  uint32_t tile = blockIdx.x;
-  u32x4 w[3];
-  WindowGeom wg;
-  StreamDesc d;
-  uint32_t m_lo = 0, m_cnt = 0;
-  auto open_tile = [&](uint32_t t) {  // descriptor + geometry + loads in flight for tile t
-    const uint32_t s = t / tiles_per_stream;
-    d = PACKED ? pack.d[s] : streams[s];
-    const uint32_t m_total = d.n_out ? (d.k_shift + d.n_out + p.den - 1) / p.den : 0;
-    m_lo = (t - s * tiles_per_stream) * p.lane_periods;
-    m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 0;
-    if (m_cnt) {
-      wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u,
-                                       PADDED ? p.period_magic : 0u);
-      window_fetch<3, T>(wg, w);
-    }
-  };
-  if (tile < total) open_tile(tile);
-  while (tile < total) {
-    const StreamDesc d_cur = d;
-    const uint32_t m_lo_cur = m_lo, m_cnt_cur = m_cnt, xshift_cur = wg.xshift;
-    if (m_cnt_cur && !(p.skip & 2u)) window_commit<3, T>(xs, d_cur, wg, w);
-    __syncthreads();
-    const uint32_t next = tile + gridDim.x;
-    if (next < total) open_tile(next);  // next window's loads fly during this tile's FIR
-    if (m_cnt_cur)
-      fir_tile<R, CT, ONE_GROUP, PADDED, T>(p, rows, d_cur, xs, xshift_cur, m_lo_cur, m_cnt_cur, wave, lane, 0, 1);
-    __syncthreads();  // every wave is done with this window before it is overwritten
-    tile = next;
-  }
-}
-
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period_persistent(
-    PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack,
-    uint32_t n_streams, uint32_t tiles_per_stream) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];
-  persistent_body<R, CT, ONE_GROUP, PADDED, PACKED, T>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
-}
-
-// Same walk without the SGPR cap: all 4R taps of an iteration arrive with ONE scalar-load wait
-// (~106 SGPRs -> 7 waves per SIMD -> one 16-wave workgroup per CU; the software pipeline, not
-// a second workgroup, hides the staging).
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
-__global__ __launch_bounds__(1024) void resample_period_persistent_wide(
-    PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack,
-    uint32_t n_streams, uint32_t tiles_per_stream) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];
-  persistent_body<R, CT, ONE_GROUP, PADDED, PACKED, T>(p, rows, streams, pack, n_streams, tiles_per_stream, xs);
-}
-
 template <typename K>
 void opt_in_lds(K kern) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -421,43 +356,21 @@ void opt_in_lds(K kern) {
 
 template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
-                     uint32_t threads, size_t lds_bytes, uint32_t n_streams, uint32_t tiles_per_stream,
-                     bool persistent, hipStream_t stream) {
+                     uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static const bool once = [] {  // thread-safe static init: calls may come from several host threads
     opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, true, T>);
     opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, false, T>);
-    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, true, T>);
-    opt_in_lds(resample_period_persistent<R, CT, ONE_GROUP, PADDED, false, T>);
-    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true, T>);
-    opt_in_lds(resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false, T>);
     return true;
   }();
   (void)once;
-  static const bool wide = std::getenv("SPEEXHIP_WIDE") && std::atoi(std::getenv("SPEEXHIP_WIDE")) != 0;
-  if (persistent && wide) {
-    if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes,
-                         stream, p, p.rows, nullptr, *pack, n_streams, tiles_per_stream);
-    else
-      hipLaunchKernelGGL((resample_period_persistent_wide<R, CT, ONE_GROUP, PADDED, false, T>), grid, dim3(threads), lds_bytes,
-                         stream, p, p.rows, d_descs, empty, n_streams, tiles_per_stream);
-  } else if (persistent) {
-    if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes,
-                         stream, p, p.rows, nullptr, *pack, n_streams, tiles_per_stream);
-    else
-      hipLaunchKernelGGL((resample_period_persistent<R, CT, ONE_GROUP, PADDED, false, T>), grid, dim3(threads), lds_bytes,
-                         stream, p, p.rows, d_descs, empty, n_streams, tiles_per_stream);
-  } else {
-    if (pack != nullptr)
-      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes, stream, p,
-                         p.rows, nullptr, *pack);
-    else
-      hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T>), grid, dim3(threads), lds_bytes, stream, p,
-                         p.rows, d_descs, empty);
-  }
+  if (pack != nullptr)
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes, stream, p,
+                       p.rows, nullptr, *pack);
+  else
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T>), grid, dim3(threads), lds_bytes, stream, p,
+                       p.rows, d_descs, empty);
   return hipGetLastError();
 }
 
@@ -486,7 +399,9 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
   t.rows_floats = static_cast<size_t>(t.groups) * t.l4 * 4 * t.r + 4 * t.r;
   // Bank padding: the lanes of a wave read the window num*channels floats apart.  Pick the pad
   // (multiple of 4 floats, inserted after every period) with the fewest lanes of a half-wave on
-  // the same bank (ds_read_b32) / bank pair (ds_read_b64); 1 = conflict-free.
+  // the same bank (ds_read_b32) / bank pair (ds_read_b64); 1 = conflict-free.  (Measured on
+  // stereo 48k->44.1k, 32 streams: no pad 622 us, pad 4 -- two lanes per bank pair -- 188 us, pad 2
+  // -- conflict-free, but 8-byte staging writes -- 199 us, pad 8: 288, pad 16: 411.)
   auto worst_bank_load = [&](uint32_t pad) {
     const uint32_t unit = t.ct;  // floats per lane access
     const uint32_t stride = f.num * channels + pad;
@@ -620,27 +535,23 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n;
   }();
-  static const uint32_t per_cu = std::getenv("SPEEXHIP_WG_PER_CU") ? std::atoi(std::getenv("SPEEXHIP_WG_PER_CU")) : 2;
-  const uint32_t resident = per_cu * static_cast<uint32_t>(device_cus);  // two workgroups fit per CU
-  // The persistent walk is opt-in (SPEEXHIP_PERSISTENT=1): with the GPU at its sustained clocks the
-  // plain grid is 7 % faster at 32 and 64 streams (212 vs 228 us) and equal below -- the hardware
-  // dispatcher refills a CU the moment a workgroup retires, which desynchronises the workgroups at
-  // least as well as the software walk does.
-  static const bool allow_persistent = std::getenv("SPEEXHIP_PERSISTENT") && std::atoi(std::getenv("SPEEXHIP_PERSISTENT")) != 0;
-  // More tiles than resident workgroups: persistent walk of the tile list.  Fewer: one workgroup
-  // per tile, and when even that leaves CUs idle (one short stream) the phase groups of a tile
-  // are split over several workgroups.
-  const bool persistent = allow_persistent && static_cast<uint64_t>(tiles) * n_streams > resident;
+  const uint32_t resident = 2 * static_cast<uint32_t>(device_cus);  // two workgroups fit per CU
+  // One workgroup per (tile, stream); the hardware dispatcher refills a CU the moment a workgroup
+  // retires.  (A persistent walk of the tile list with the next tile's window prefetched into
+  // registers lived here until round 1's last measurements at sustained clocks: 7 % slower at 32
+  // streams -- 228 vs 212 us --, 25 % slower on the 8-channel configuration.)
+  // When one workgroup per tile leaves CUs idle (one short stream), the phase groups of a tile are
+  // split over several workgroups.
   uint32_t splits = 1;
   static const uint32_t force_splits = std::getenv("SPEEXHIP_SPLITS") ? std::atoi(std::getenv("SPEEXHIP_SPLITS")) : 0;
-  if (!persistent && force_splits)
+  if (force_splits)
     splits = std::min<uint32_t>(force_splits, t.groups);
-  else if (!persistent)
-    // (measured on cfg2, one stream: 1/2/4/8 shares -> 19.6/15.1/16.0/27.3 us: split until the
-    //  launch has about one workgroup per CU, not more -- every share re-stages the window.
+  else
+    // (measured on cfg2, one stream: 1/2/4 shares -> 18.5/13.6/14.8 us: split until the launch has
+    //  about one workgroup per CU, not more -- every share re-stages the window.
     //  Also tried: splitting each group's TAP range over the spare waves of a share, partial sums
-    //  meeting in LDS -- 15.7 us, the two extra barriers cost more than the occupancy gains.
-    //  Phase costs of the 14.6 us (rocprofv3, parts skipped): bare dispatch 2.3, descriptor +
+    //  meeting in LDS -- +1 us, the two extra barriers cost more than the occupancy gains.
+    //  Phase costs of that launch (rocprofv3, parts skipped): bare dispatch 2.3, descriptor +
     //  geometry 1.1, window staging 1.6, FIR 7.3, stores 2.5 -- strictly serial in a launch that
     //  is a single generation of workgroups.)
     while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident / 2 &&
@@ -675,7 +586,7 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   static const int env_rows = std::getenv("SPEEXHIP_ROWS") ? std::atoi(std::getenv("SPEEXHIP_ROWS")) : -1;
   const bool many_generations = static_cast<uint64_t>(tiles) * n_streams * splits >= 3ull * resident;
   p.image_stride = 0;
-  if (!persistent && (env_rows > 0 || (env_rows < 0 && many_generations)) && !float_io && t.ct == 2 &&
+  if ((env_rows > 0 || (env_rows < 0 && many_generations)) && !float_io && t.ct == 2 &&
       t.cgroups == 1 && wave_groups * splits >= t.groups) {
     uint32_t stride = (wave_groups * kR + 2 + 1) & ~1u;  // >= 2 dwords of slack, even
     if (stride % 4 == 0) stride += 2;
@@ -684,18 +595,16 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
   const uint32_t threads = wave_groups * 64;
-  // One-shot grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8
+  // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8
   // when a tile is split: workgroups whose linear ids differ by a multiple of 8 share an XCD, so
   // the `splits` workgroups that stage the same input window hit in that XCD's L2 instead of
   // each fetching it from HBM (measured 2.7x read amplification without this).
   uint32_t grid_x = (max_periods == 0 ? 0 : tiles) + 1;
   if (splits > 1 && n_streams == 1) grid_x = (grid_x + 7) / 8 * 8;
-  dim3 grid = persistent ? dim3(resident, 1, 1) : dim3(grid_x, n_streams, splits);
+  const dim3 grid(grid_x, n_streams, splits);
 #define SPEEXHIP_PERIOD_CASE(CTV, ONE, PADV)                                                            \
-  return float_io ? launch_rc<kR, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, \
-                                                         n_streams, tiles, persistent, stream)           \
-                  : launch_rc<kR, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, \
-                                                           n_streams, tiles, persistent, stream)
+  return float_io ? launch_rc<kR, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, stream)   \
+                  : launch_rc<kR, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
   const bool padded = t.pad != 0;
   if (t.ct == 2) {
     if (t.cgroups == 1 && !padded) SPEEXHIP_PERIOD_CASE(2, true, false);
