@@ -337,6 +337,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   __syncthreads();
   if (p.skip & 128u) return;  // diagnostics: prologue + staging only
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
   if constexpr (ONE_GROUP && CT == 2 && sizeof(T) == 2) {
     // whole-row stores need dword-aligned frames (uniform per stream)
     if (p.image_stride != 0 && (reinterpret_cast<uintptr_t>(d.out) & 3u) == 0) {
@@ -594,7 +595,11 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   }
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
-  const uint32_t threads = wave_groups * 64;
+  // A workgroup that owns only a share of the groups still stages the whole window: lend it the
+  // waves it has no groups for, they leave after the staging barrier.
+  static const int env_helpers = std::getenv("SPEEXHIP_HELPERS") ? std::atoi(std::getenv("SPEEXHIP_HELPERS")) : 1;
+  const bool helpers = env_helpers != 0 && splits > 1 && p.image_stride == 0;
+  const uint32_t threads = (helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
   // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8
   // when a tile is split: workgroups whose linear ids differ by a multiple of 8 share an XCD, so
   // the `splits` workgroups that stage the same input window hit in that XCD's L2 instead of
