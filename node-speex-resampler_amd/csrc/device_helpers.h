@@ -84,7 +84,8 @@ struct WindowGeom {
   uint32_t u_begin, n_wide;    // wide groups: LDS floats [G*u_begin, G*(u_begin+n_wide))
   uint32_t xshift;             // float index of the window's first frame inside the image
   uint32_t pad, period_elems;  // bank padding: `pad` floats inserted after every period_elems
-                               // (= num*channels) floats counted from the window's first frame
+                               // floats (a period of the period kernel, a row of the slide
+                               // kernel) counted from the window's first frame
   uint32_t period_magic;       // ceil(2^32 / period_elems): n / period_elems == umulhi(n, magic) for
                                // the n < 2^17 that index an LDS image (host: period_magic_of)
 };
@@ -97,11 +98,12 @@ __host__ __device__ inline uint32_t period_magic_of(uint32_t d) {
 template <typename T>
 __device__ __forceinline__ WindowGeom window_geom(const StreamDesc &d, uint32_t channels,
                                                   uint32_t num, uint32_t tail_frames, uint32_t m_lo,
-                                                  uint32_t m_cnt, uint32_t pad = 0, uint32_t period_magic = 0) {
+                                                  uint32_t m_cnt, uint32_t pad = 0, uint32_t period_magic = 0,
+                                                  uint32_t pad_every = 0) {
   constexpr int GS = PerLoad<T>::value;
   WindowGeom w;
   w.pad = pad;
-  w.period_elems = num * channels;
+  w.period_elems = pad_every ? pad_every : num * channels;  // floats between two paddings
   w.period_magic = period_magic;
   w.hist_elems = static_cast<int64_t>(d.hist_frames) * channels;
   w.in_elems = static_cast<int64_t>(d.in_frames) * channels;
@@ -175,7 +177,8 @@ __device__ __forceinline__ uint32_t padded_pos(const WindowGeom &g, uint32_t j) 
 }
 
 // the floats of one group, image floats j .. j+GS-1 (j a multiple of GS): 16-byte LDS writes
-// unless the group straddles a padding boundary
+// (8-byte ones where the padding leaves the group only 8-byte aligned) unless the group
+// straddles a padding boundary
 template <typename T>
 __device__ __forceinline__ void commit_group(float *xs, const WindowGeom &g, uint32_t j, const u32x4 &w) {
   constexpr int GS = PerLoad<T>::value;
@@ -185,12 +188,15 @@ __device__ __forceinline__ void commit_group(float *xs, const WindowGeom &g, uin
   bool contiguous = true;
   if (g.pad != 0) {
     a = padded_pos(g, j);
-    contiguous = padded_pos(g, j + GS - 1) - a == GS - 1 && (a & 3u) == 0;
+    contiguous = padded_pos(g, j + GS - 1) - a == GS - 1;
   }
-  if (contiguous) {
+  if (contiguous && (a & 3u) == 0) {
 #pragma unroll
     for (int k = 0; k < GS; k += 4)
       *reinterpret_cast<float4 *>(xs + a + k) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
+  } else if (contiguous && (a & 1u) == 0) {
+#pragma unroll
+    for (int k = 0; k < GS; k += 2) *reinterpret_cast<float2 *>(xs + a + k) = make_float2(f[k], f[k + 1]);
   } else {
 #pragma unroll
     for (int k = 0; k < GS; k++) xs[padded_pos(g, j + k)] = f[k];

@@ -51,6 +51,7 @@ struct SlideParams {
   uint32_t blocks_per_wave; // lane blocks (P periods each) per wave
   uint32_t blocks_per_tile; // ... per workgroup
   uint32_t row_stride;      // floats between LDS rows (P frames + bank padding)
+  uint32_t row_magic;       // ceil(2^32 / floats per row): division-free row index while staging
   uint32_t skip;            // diagnostics only
 };
 

@@ -70,18 +70,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   if (m_lo >= m_total) return;
   const uint32_t m_cnt = min(tile_periods, m_total - m_lo);
 
-  // ---- stage: frames [f0, f0 + m_cnt*num + row_len) of V; frame f -> row f / (P*NUM), column ... ----
-  {
-    const int64_t hist_elems = static_cast<int64_t>(d.hist_frames) * C;
-    const int64_t in_elems = static_cast<int64_t>(d.in_frames) * C;
-    const int64_t q0 = (static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * NUM) * C - hist_elems;
-    const uint32_t frames = m_cnt * NUM + p.row_len + P * NUM;  // + one row of slack for the last iteration
-    const uint32_t total = frames * C;
-    const uint32_t row_elems = P * NUM * C;
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
-      const uint32_t row = e / row_elems, col = e - row * row_elems;
-      xs[row * p.row_stride + col] = rel_sample<T>(d, q0 + e, hist_elems, in_elems);
-    }
+  // ---- stage: frames [f0, f0 + m_cnt*num + row_len + one row) of V as float, in rows of P*NUM
+  //      frames `row_stride` floats apart: the shared loader's padded image with the row as its
+  //      padding period (16-byte loads, all in flight at once; device_helpers.h) ----
+  const WindowGeom wg = window_geom<T>(d, C, NUM, NUM + p.row_len + P * NUM, m_lo, m_cnt,
+                                       p.row_stride - P * NUM * C, p.row_magic, P * NUM * C);
+  if (!(p.skip & 2u)) {
+    u32x4 w[3];
+    window_fetch<3, T>(wg, w);
+    window_commit<3, T>(xs, d, wg, w);
   }
   __syncthreads();
 
@@ -91,7 +88,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   const uint32_t lb = wave * p.blocks_per_wave + lane / p.cgroups;  // lane block inside the tile
   const bool lane_live = (lane / p.cgroups) < p.blocks_per_wave && lb * P < m_cnt;
   constexpr int CW = PAIR_CH ? 2 : 1;          // floats this lane reads per frame
-  const float *xrow = xs + min(lb, p.blocks_per_tile - 1) * p.row_stride + cg * CW;
+  const float *xrow = xs + wg.xshift + min(lb, p.blocks_per_tile - 1) * p.row_stride + cg * CW;
 
   f32x2 acc[P][NP];
 #pragma unroll
@@ -313,6 +310,7 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   p.blocks_per_wave = blocks_per_wave;
   p.blocks_per_tile = blocks_per_wave * waves;
   p.row_stride = t.row_stride;
+  p.row_magic = period_magic_of(t.p * f.num * channels);
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
   const uint32_t tile_periods = p.blocks_per_tile * t.p;
@@ -320,7 +318,8 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   // LDS: one row per lane block, + the rows the last lane's window runs into
   const uint32_t steps = t.p * f.num;
   const size_t rows_needed = p.blocks_per_tile + t.row_len / steps + 2;
-  const size_t lds = rows_needed * t.row_stride * 4;
+  // (+ 16 floats: the image starts on the input's 16-byte grid and ends on a whole load)
+  const size_t lds = (rows_needed * t.row_stride + 16) * 4;
   dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
   const uint32_t threads = waves * 64;
 #define SPEEXHIP_SLIDE_CASE(PP, NUMV, NPV, CHV)                           \
