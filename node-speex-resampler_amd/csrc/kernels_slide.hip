@@ -297,7 +297,11 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   // lane blocks per wave, waves per workgroup: fewer waves when the launch is small, so that it
   // still spreads over the chip
   const uint32_t blocks_per_wave = 64 / t.cgroups;
-  uint32_t waves = 16;
+  // (8 waves per workgroup: the kernel's 96 SGPRs admit 7 waves per SIMD, i.e. three such
+  //  workgroups per CU but only one of 16 waves; measured 16 -> 8: 2:1 decimation 241 -> 205 us,
+  //  16k->48k mono 463 -> 425 us, the rest within 2 %)
+  static const uint32_t max_waves = std::getenv("SPEEXHIP_SLIDE_WAVES") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_WAVES")) : 8;
+  uint32_t waves = max_waves;
   while (waves > 2 && static_cast<uint64_t>(max_periods) * n_streams < 512ull * waves * blocks_per_wave * t.p)
     waves /= 2;
   SlideParams p;
