@@ -32,7 +32,8 @@ def assert_close(got, want, name, tol=TOL_LSB, rate=MISMATCH_RATE):
         return
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= tol, "%s: max |diff| = %d LSB at %s" % (name, diff.max(), np.argmax(diff))
-    assert (diff != 0).mean() <= rate, "%s: %.2e of samples differ" % (name, (diff != 0).mean())
+    if got.size >= 20000:  # a rate means nothing on a handful of samples
+        assert (diff != 0).mean() <= rate, "%s: %.2e of samples differ" % (name, (diff != 0).mean())
 
 
 def test_library_is_loaded_in_tree_and_device_is_gfx950():
@@ -443,7 +444,7 @@ def test_mid_stream_control_scripts_fast_mode(golden):
             if got is not None:
                 assert got.shape == wout.shape, tag
                 if got.dtype == np.int16:
-                    assert_close(got, wout, str(tag), rate=1.0 if got.size < 20000 else MISMATCH_RATE)
+                    assert_close(got, wout, str(tag))
                 else:
                     assert np.abs(got - wout).max(initial=0.0) <= 2e-6 * scale, tag
             for cc in range(ch):
@@ -545,3 +546,57 @@ def test_chunk_coalescing_equals_the_separate_calls(mode):
             for cc in range(ch):
                 assert np.array_equal(r.history()[:, cc], ref.history(cc))
         r.close()
+
+
+def test_window_layout_variants_of_the_period_kernel():
+    """Every LDS layout decision of the period kernel on its own ratio: bank padding with one and
+    with several period boundaries per group (num % 4 == 0), fewer periods per tile so that two
+    workgroups share a CU, partly filled waves for very wide windows (num = 320, 441, 640), odd
+    channel counts, a split tile with staging helper waves, and whole-row stores (>= 3 generations of
+    workgroups).  fast_path must stay 2 and every sample within +-1 LSB, multi-call, history equal."""
+    cases = [(2, 48000, 44100, 5), (2, 48000, 44100, 10), (1, 48000, 44100, 7), (4, 48000, 44100, 5),
+             (6, 44100, 48000, 7), (2, 96000, 44100, 7), (2, 32000, 44100, 7), (2, 44100, 32000, 7),
+             (3, 48000, 44100, 4), (2, 11025, 48000, 6), (2, 48000, 11025, 3), (2, 44100, 8000, 5),
+             (7, 22050, 16000, 8), (2, 88200, 96000, 9)]
+    for (ch, i, o, q) in cases:
+        ref = orc.Oracle(ch, i, o, q)
+        r = speexhip.Resampler(ch, i, o, q)
+        assert r.info()["fast_path"] == 2, (ch, i, o, q)
+        for call, frames in enumerate([30000, 3, 0, 61234]):
+            x = orc.tone_pcm(frames, ch, seed=call + q) if call % 2 else orc.lcg_pcm(frames * ch, 77 + call).reshape(frames, ch)
+            got, used = r.process(x, 1 << 20)
+            want, wu = ref.process(x, 1 << 20)
+            assert used == wu and r.position() == ref.position(), (ch, i, o, q, call)
+            assert_close(got, want, "layout %s call %d" % ((ch, i, o, q), call))
+        for c in range(ch):
+            assert np.array_equal(r.history()[:, c], ref.history(c)), (ch, i, o, q)
+        r.close()
+
+
+def test_many_generation_launch_uses_whole_row_stores_correctly():
+    """40 stereo streams x 400k frames: > 3 generations of workgroups, so the outputs leave through the
+    LDS image (whole-row stores); ragged lengths put partial rows and partial tiles at both ends."""
+    import torch
+    ch, i, o, q, S, frames = 2, 44100, 48000, 7, 40, 400000
+    cap = int(frames * o / i) + 16
+    base = orc.lcg_pcm(frames * ch, 4242).reshape(frames, ch)
+    xs = np.stack([np.roll(base, 13 * s, axis=0) for s in range(S)])
+    d_in = torch.from_numpy(xs).cuda()
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    b = speexhip.Batch(S, ch, i, o, q)
+    lens = [frames - 1000 * s - (s % 7) for s in range(S)]
+    sp = torch.cuda.current_stream().cuda_stream
+    for call in range(2):  # the second call starts mid-period (k_shift != 0)
+        used, made = b.process_device(d_in.data_ptr(), frames * ch, lens, d_out.data_ptr(), cap * ch, cap, sp)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        for s in (0, 1, 17, 39):
+            if call == 0:
+                refs = getattr(test_many_generation_launch_uses_whole_row_stores_correctly, "refs", {})
+                refs[s] = orc.Oracle(ch, i, o, q)
+                test_many_generation_launch_uses_whole_row_stores_correctly.refs = refs
+            ref = test_many_generation_launch_uses_whole_row_stores_correctly.refs[s]
+            want, wu = ref.process(xs[s, : lens[s]], cap)
+            assert (used[s], made[s]) == (wu, want.shape[0]), (call, s)
+            assert_close(out[s, : made[s]], want, "rows path call %d stream %d" % (call, s))
+    b.close()
