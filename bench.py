@@ -151,6 +151,9 @@ def main():
     used, made = step(0)
     torch.cuda.synchronize()
     first_chunk = (d_out[0][0, : made[0]].cpu().numpy(), used[0], made[0]) if rank == 0 and not fio else None
+    # checksum of the first step's outputs (all streams of this rank): deterministic, unlike the
+    # buffers after a time-based preheat
+    first_sum = int((d_out[0] * (32768.0 if fio else 1)).to(torch.int64).sum().item())
 
     # clock ramp (untimed, before the warmup steps): same calls as the timed loop
     t_heat, i_heat = time.perf_counter(), 0
@@ -181,7 +184,7 @@ def main():
     elapsed_max = dist_util.reduce_scalar(elapsed, "max", dev)
     total_in_samples = dist_util.reduce_int(args.steps * S * F * ch, dev)
     total_out_samples = dist_util.reduce_int(produced * ch, dev)
-    checksum = dist_util.reduce_int(int((d_out[0] * (32768.0 if fio else 1)).to(torch.int64).sum().item()), dev)
+    checksum = dist_util.reduce_int(first_sum, dev)
 
     if rank == 0:
         value = total_in_samples / elapsed_max / 1e6
