@@ -1,12 +1,18 @@
 #!/bin/bash
-# tools/gpu_ab.sh -- diagnostics at sustained clocks: slide kernel, waves per workgroup
+# tools/gpu_ab.sh -- diagnostics at sustained clocks (bench.py preheats the GPU): a table of
+# configurations, optionally with parts of the kernels skipped.  Run through gpurun; edit the
+# lists below for the experiment at hand.  SPEEXHIP_SKIP bits: 2 = window staging, 4 = FIR loop,
+# 8 = stores, 64 = return at once (bare dispatch), 128 = return after staging.
+# Other switches: SPEEXHIP_SPLITS, SPEEXHIP_WAVES, SPEEXHIP_ROWS, SPEEXHIP_HELPERS, SPEEXHIP_PAD,
+# SPEEXHIP_SLIDE_WAVES.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
 : > $O/ab.txt
 run() { echo -n "$1 $2 steps=$3 : " >> $O/ab.txt; env $1 timeout 300 python bench.py $2 --steps $3 --warmup 20 --no-cpu-baseline --no-parity 2>/dev/null | python3 -c "
 import sys, json
-d = json.loads(sys.stdin.readline()); print('launch_us', d['roofline']['launch_us'], 'valu', d['valu']['frac'])" >> $O/ab.txt; }
-for C in "2,48000,24000,7" "2,44100,44100,7" "2,24000,48000,7" "1,24000,48000,10" "1,24000,48000,5" "1,16000,48000,7"; do
-for W in 16 8 4; do
-run "BENCH_STREAMS=32 SPEEXHIP_SLIDE_WAVES=$W" "--custom $C" 50
-done; done
+d = json.loads(sys.stdin.readline()); print('launch_us', d['roofline']['launch_us'], 'value', d['value'], 'hbm', d['roofline']['frac'], 'valu', d['valu']['frac'], 'path', d['config']['fast_path'])" >> $O/ab.txt; }
+for CFG in cfg2 cfg3 cfg4 f3; do
+  run "BENCH_STREAMS=1" "--config $CFG" 1000
+  run "BENCH_STREAMS=32" "--config $CFG" 100
+done
+for SKIP in 10 12 6; do run "BENCH_STREAMS=32 SPEEXHIP_SKIP=$SKIP" "--config cfg2" 100; done
 cat $O/ab.txt

@@ -14,10 +14,10 @@ else
   timeout 600 python -m pytest tests -m gpu -q -k "golden or baseline or batched" > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt
 fi
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench1.txt 2>&1
-timeout 300 python bench.py --steps 50 --warmup 5 --streams 32 --no-cpu-baseline > $O/bench_s32.txt 2>&1
+timeout 300 python bench.py --steps 100 --warmup 20 --streams 32 --no-cpu-baseline > $O/bench_s32.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity > $O/prof1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-parity > $O/prof1.log 2>&1
 cd $R
 tail -2 $O/pytest_gpu.txt
 grep -h metric $O/bench1.txt $O/bench_s32.txt | python3 -c "
