@@ -165,6 +165,16 @@ SPEEXHIP_API int speexhip_resampler_process_chunks_float(SpeexHipResamplerState 
                                                          const float *const *in, uint32_t *in_len,
                                                          float *out, uint32_t *out_len);
 
+/* What the next processing call WOULD consume and produce for (in_len, out_capacity), without
+ * touching the state: the counters are integer functions of the stream position alone, so a
+ * binding can size its output buffer exactly before the call: the processing calls write
+ * exactly `produced` frames, so a buffer of that size suffices even though *out_len is larger
+ * (the N-API addon does this; do NOT pass `produced` as the capacity instead -- a tighter
+ * capacity can end the block loop before trailing input is consumed).  float_entry selects the
+ * float call's rules. */
+SPEEXHIP_API int speexhip_resampler_peek(SpeexHipResamplerState *st, uint32_t in_len, uint32_t out_capacity,
+                                         int float_entry, uint32_t *consumed, uint32_t *produced);
+
 /* SPEEXHIP_MODE_FAST (default; +-1 LSB) or SPEEXHIP_MODE_EXACT (bit-identical arithmetic
  * order, slower).  The environment variable SPEEXHIP_MODE=exact|fast sets the initial mode. */
 SPEEXHIP_API int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode);

@@ -159,6 +159,15 @@ const char *speexhip_resampler_strerror(int err) {
   }
 }
 
+int speexhip_resampler_peek(SpeexHipResamplerState *st, uint32_t in_len, uint32_t out_capacity, int float_entry,
+                            uint32_t *consumed, uint32_t *produced) {
+  if (st == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  const speexhip::CallPlan plan = st->batch->peek(0, in_len, out_capacity, float_entry != 0);
+  if (consumed) *consumed = plan.consumed;
+  if (produced) *produced = plan.produced;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
 int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode) {
   return st ? st->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG;
 }

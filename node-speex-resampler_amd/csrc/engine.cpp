@@ -249,6 +249,13 @@ Batch::~Batch() {
   if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
+CallPlan Batch::peek(uint32_t s, uint32_t in_len, uint32_t out_capacity, bool float_io) const {
+  EntryRules rules;
+  rules.block_in = block_in();
+  rules.float_entry = float_io;
+  return plan_call(filter_.num, filter_.den, in_len, out_capacity, pos_[s], rules);
+}
+
 int Batch::set_mode(int mode) {
   if (mode != SPEEXHIP_MODE_FAST && mode != SPEEXHIP_MODE_EXACT) return SPEEXHIP_ERR_INVALID_ARG;
   mode_ = mode;

@@ -51,6 +51,9 @@ class Batch {
     return static_cast<int>(((filter_.taps / 2) * filter_.den + (filter_.num >> 1)) / filter_.num);
   }
 
+  // Counters of the next call for stream s, state untouched.
+  CallPlan peek(uint32_t s, uint32_t in_len, uint32_t out_capacity, bool float_io) const;
+
   int set_mode(int mode);
   void info(uint32_t stream, SpeexHipInfo *out) const;
   int history(uint32_t stream, float *dst);

@@ -143,29 +143,28 @@ static napi_value process_common(napi_env env, napi_callback_info info, size_t s
     napi_throw_range_error(env, NULL, "input frame count exceeds the chunk");
     return NULL;
   }
-  size_t cap_bytes = (size_t)out_len * frame_bytes;
-  void *tmp = malloc(cap_bytes ? cap_bytes : 4);
-  if (tmp == NULL) {
-    napi_throw_error(env, NULL, speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED));
-    return NULL;
-  }
+  /* the counters are known before any GPU work: size the result exactly and let the library write
+   * straight into it (one copy instead of three) */
+  uint32_t will_use = 0, will_make = 0;
+  speexhip_resampler_peek(h->st, in_len, out_len, sample_bytes == 4, &will_use, &will_make);
+  napi_value out;
+  void *dst = NULL;
+  NAPI_OK(napi_create_buffer(env, (size_t)will_make * frame_bytes, &dst, &out));
+  uint64_t nowhere = 0;
+  if (dst == NULL) dst = &nowhere; /* empty Buffer: nothing will be written, but NULL means "no buffer" */
+  /* out_len stays the caller's capacity (a smaller one could end the call's block loop early and
+   * leave trailing input unconsumed); the library writes exactly will_make frames */
   pthread_mutex_lock(&h->lock);
   int rc = sample_bytes == 2
                ? speexhip_resampler_process_interleaved_int(h->st, (const int16_t *)in_data, &in_len,
-                                                            (int16_t *)tmp, &out_len)
+                                                            (int16_t *)dst, &out_len)
                : speexhip_resampler_process_interleaved_float(h->st, (const float *)in_data, &in_len,
-                                                              (float *)tmp, &out_len);
+                                                              (float *)dst, &out_len);
   pthread_mutex_unlock(&h->lock);
-  if (rc != 0) {
-    free(tmp);
-    napi_throw_error(env, NULL, speexhip_resampler_strerror(rc));
+  if (rc != 0 || out_len != will_make) {
+    napi_throw_error(env, NULL, speexhip_resampler_strerror(rc != 0 ? rc : SPEEXHIP_ERR_BAD_STATE));
     return NULL;
   }
-  napi_value out;
-  void *copied = NULL;
-  napi_status s = napi_create_buffer_copy(env, (size_t)out_len * frame_bytes, tmp, &copied, &out);
-  free(tmp);
-  NAPI_OK(s);
   return out;
 }
 static napi_value Process(napi_env env, napi_callback_info info) { return process_common(env, info, 2); }

@@ -37,6 +37,7 @@ EXPORTS = [
     "speexhip_design_filter_frac", "speexhip_plan_call_ex", "speexhip_plan_filter_change",
     # chunk coalescing
     "speexhip_resampler_process_chunks_int", "speexhip_resampler_process_chunks_float",
+    "speexhip_resampler_peek",
 ]
 
 
@@ -137,6 +138,8 @@ def lib():
         for f in (L.speexhip_resampler_process_chunks_int, L.speexhip_resampler_process_chunks_float):
             f.restype = i32
             f.argtypes = [p, u32, C.POINTER(C.c_void_p), pu32, p, pu32]
+        L.speexhip_resampler_peek.restype = i32
+        L.speexhip_resampler_peek.argtypes = [p, u32, u32, i32, pu32, pu32]
         _lib = L
     return _lib
 
@@ -332,6 +335,14 @@ class Resampler:
         if rc:
             raise RuntimeError(strerror(rc))
         return out[: ol.value].copy(), il.value
+
+    def peek(self, in_frames, out_capacity, float_entry=False):
+        """(consumed, produced) of the next call, state untouched"""
+        c, p_ = C.c_uint32(), C.c_uint32()
+        rc = lib().speexhip_resampler_peek(self._h, in_frames, out_capacity, int(float_entry), C.byref(c), C.byref(p_))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return c.value, p_.value
 
     def process_chunks(self, chunks, capacities, dtype=np.int16):
         """n consecutive calls as one launch (speexhip_resampler_process_chunks_int / _float).

@@ -600,3 +600,29 @@ def test_many_generation_launch_uses_whole_row_stores_correctly():
             assert (used[s], made[s]) == (wu, want.shape[0]), (call, s)
             assert_close(out[s, : made[s]], want, "rows path call %d stream %d" % (call, s))
     b.close()
+
+
+def test_peek_predicts_the_counters_and_leaves_the_state_alone():
+    """speexhip_resampler_peek: what the next call would consume / produce, from the integer state
+    alone (the N-API addon sizes its result Buffer with it)."""
+    rng = np.random.RandomState(5)
+    for (ch, i, o, q) in [(2, 44100, 48000, 7), (1, 48000, 8000, 3), (2, 8000, 48000, 5)]:
+        r = speexhip.Resampler(ch, i, o, q)
+        ref = orc.Oracle(ch, i, o, q)
+        for k in range(25):
+            f = int(rng.choice([0, 1, 159, 160, 161, 1000, 4096]))
+            cap = int(rng.choice([0, 1, 50, 1024, 1025, 1 << 20]))
+            flt = bool(k % 3 == 0)
+            before = r.position()
+            want_used, want_made = r.peek(f, cap, flt)
+            assert r.position() == before
+            x = orc.lcg_pcm(f * ch, 100 + k).reshape(f, ch)
+            if flt:
+                xf = x.astype(np.float32) / np.float32(32768)
+                got, used = r.process_float(xf, cap)
+                want, wu = ref.process_float(xf, cap)
+            else:
+                got, used = r.process(x, cap)
+                want, wu = ref.process(x, cap)
+            assert (used, got.shape[0]) == (want_used, want_made) == (wu, want.shape[0]), ((ch, i, o, q), k)
+        r.close()
