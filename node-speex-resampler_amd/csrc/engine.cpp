@@ -20,6 +20,7 @@ bool hip_failed(hipError_t e, const char *what) {
   } while (0)
 
 const size_t kLdsBudget = 150 * 1024;  // of the CU's 160 KiB
+const size_t kDirectCopyBytes = 256 * 1024;  // host buffers at least this big skip the pinned bounce buffer
 }  // namespace
 
 const char *last_device_error() { return g_last_error.c_str(); }
@@ -428,18 +429,27 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   const size_t out_bytes = static_cast<size_t>(will_make) * channels_ * es;
   int rc = ensure_stage(in_bytes, out_bytes);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  // Large buffers go straight from / to the caller's pageable memory: the HIP runtime stages such
+  // copies itself and does it 2.2-2.5x faster than memcpy -> pinned -> DMA in one thread (2^20
+  // stereo frames: 0.46 -> 0.21 ms per call, 8 channels 1.57 -> 0.63 ms).  Small ones keep the
+  // pinned bounce buffers (a few % faster below ~256 KB).
+  const bool direct_in = in_bytes >= kDirectCopyBytes, direct_out = out_bytes >= kDirectCopyBytes;
   if (in != nullptr && in_bytes != 0) {
-    std::memcpy(h_pin_in_, in, in_bytes);
-    HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, in_bytes, hipMemcpyHostToDevice, own_stream_));
+    if (direct_in) {
+      HIP_TRY(hipMemcpyAsync(d_stage_in_, in, in_bytes, hipMemcpyHostToDevice, own_stream_));
+    } else {
+      std::memcpy(h_pin_in_, in, in_bytes);
+      HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, in_bytes, hipMemcpyHostToDevice, own_stream_));
+    }
   }
   rc = process_device(in != nullptr ? d_stage_in_ : nullptr, 0, in_len, d_stage_out_, 0, out_len, float_io,
                       own_stream_);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   const size_t made = static_cast<size_t>(*out_len) * channels_ * es;
   if (made != 0)
-    HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, made, hipMemcpyDeviceToHost, own_stream_));
+    HIP_TRY(hipMemcpyAsync(direct_out ? out : h_pin_out_, d_stage_out_, made, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
-  if (made != 0) std::memcpy(out, h_pin_out_, made);
+  if (made != 0 && !direct_out) std::memcpy(out, h_pin_out_, made);
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -514,9 +524,11 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
                    float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
-  if (made != 0) HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, made * fb, hipMemcpyDeviceToHost, own_stream_));
+  const bool direct_out = made * fb >= kDirectCopyBytes;
+  if (made != 0)
+    HIP_TRY(hipMemcpyAsync(direct_out ? out : h_pin_out_, d_stage_out_, made * fb, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
-  if (made != 0) std::memcpy(out, h_pin_out_, made * fb);
+  if (made != 0 && !direct_out) std::memcpy(out, h_pin_out_, made * fb);
   for (uint32_t i = 0; i < n_chunks; i++) {
     in_len[i] = plans[i].consumed;
     out_len[i] = plans[i].produced;
