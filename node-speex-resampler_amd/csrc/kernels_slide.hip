@@ -1,4 +1,4 @@
-// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6, num <= 4):
+// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6, num <= 4, and n:1 up to 6:1):
 // integer up-sampling 24k->48k, 16k->48k, 8k->48k, same-rate, 2:1 / 3:1 / 4:1 decimation, 3:2,
 // 2:3 ... (BASELINE configs[2]; the reference picks resampler_basic_direct_* for
 // most of these, deps/speex/resample.c:331-435).  +-1 LSB.
@@ -233,13 +233,15 @@ hipError_t launch_up(const SlideParams &p, const StreamDesc *d_descs, const Desc
 namespace {
 struct SlideShape { uint32_t num, np; bool pair_ch; uint32_t p; };
 // the instantiated (num, accumulator pairs per period, packing) -> periods per lane.  Bounds kept:
-// tap floats per iteration <= 48, window (2P-1)*num <= 31 frames, P*np <= 24 accumulator pairs.
+// tap floats per iteration <= 48, window (2P-1)*num <= 42 frames, P*np <= 24 accumulator pairs.
 const SlideShape kShapes[] = {
     {1, 1, true, 8}, {1, 2, true, 8}, {1, 3, true, 8}, {1, 4, true, 4}, {1, 6, true, 4},
     {1, 1, false, 8}, {1, 2, false, 8}, {1, 3, false, 4},
     {2, 1, true, 8}, {2, 3, true, 4}, {2, 1, false, 8}, {2, 2, false, 4},
     {3, 1, true, 4}, {3, 2, true, 4}, {3, 1, false, 4},
     {4, 1, true, 4}, {4, 1, false, 4},
+    // 5:1 and 6:1 decimation (48k -> 8k, 96k -> 16k): a 42-frame register window, 4 waves per SIMD
+    {5, 1, true, 4}, {5, 1, false, 4}, {6, 1, true, 4}, {6, 1, false, 4},
 };
 }  // namespace
 
@@ -347,6 +349,10 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   SPEEXHIP_SLIDE_CASE(4, 3, 1, false)
   SPEEXHIP_SLIDE_CASE(4, 4, 1, true)
   SPEEXHIP_SLIDE_CASE(4, 4, 1, false)
+  SPEEXHIP_SLIDE_CASE(4, 5, 1, true)
+  SPEEXHIP_SLIDE_CASE(4, 5, 1, false)
+  SPEEXHIP_SLIDE_CASE(4, 6, 1, true)
+  SPEEXHIP_SLIDE_CASE(4, 6, 1, false)
 #undef SPEEXHIP_SLIDE_CASE
   return hipErrorInvalidValue;
 }

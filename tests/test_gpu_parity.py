@@ -329,10 +329,10 @@ def test_eight_channel_padded_window_and_odd_channel_counts():
 
 
 def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
-    """Ratios no fast kernel covers (den = 5, 6:1, filters too long for LDS) must still be right:
+    """Ratios no fast kernel covers (den = 5, 7:1, filters too long for LDS) must still be right:
     FAST mode falls back to the bit-exact kernel (fast_path == 0), staged in LDS or streaming
     straight from L2 when the filter does not fit."""
-    for (ch, i, o, q, frames) in [(1, 48000, 8000, 5, 30000), (2, 8000, 40000, 4, 4000),
+    for (ch, i, o, q, frames) in [(1, 56000, 8000, 5, 30000), (2, 8000, 40000, 4, 4000),
                                   (1, 192000, 1000, 10, 120000), (2, 96000, 1500, 3, 90000)]:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -343,6 +343,25 @@ def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
             want, wu = ref.process(part, 1 << 20)
             assert used == wu and r.position() == ref.position()
             assert np.array_equal(got, want), "exact fallback differs for %s" % ((ch, i, o, q),)
+        r.close()
+
+
+def test_five_and_six_to_one_decimation_take_the_slide_kernel():
+    """48k -> 8k, 96k -> 16k (6:1) and 40k -> 8k (5:1): telephony down-sampling runs the small-ratio
+    fast kernel (42-frame register window), stereo (channel pairs) and mono (phase pairs)."""
+    for (ch, i, o, q) in [(1, 48000, 8000, 5), (2, 48000, 8000, 7), (2, 96000, 16000, 3), (1, 40000, 8000, 10),
+                          (2, 40000, 8000, 4), (3, 48000, 8000, 6)]:
+        ref = orc.Oracle(ch, i, o, q)
+        r = speexhip.Resampler(ch, i, o, q)
+        assert r.info()["fast_path"] == 3, (ch, i, o, q)
+        for call, frames in enumerate([60000, 5, 120001]):
+            x = orc.tone_pcm(frames, ch, seed=call) if call else orc.lcg_pcm(frames * ch, 9).reshape(frames, ch)
+            got, used = r.process(x, 1 << 20)
+            want, wu = ref.process(x, 1 << 20)
+            assert used == wu and r.position() == ref.position(), (ch, i, o, q, call)
+            assert_close(got, want, "n:1 %s call %d" % ((ch, i, o, q), call))
+        for c in range(ch):
+            assert np.array_equal(r.history()[:, c], ref.history(c))
         r.close()
 
 
