@@ -120,8 +120,13 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
     }
   };
   auto touch_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
-    asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
-                 "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]));
+    if constexpr (R == 10) {
+      asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
+                   "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]));
+    } else {
+      static_assert(R == 5, "touch_bank lists the tap pairs of R = 10 or R = 5");
+      asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "v"(x[0]), "v"(x[1]));
+    }
   };
   auto fma_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
 #pragma unroll
@@ -129,7 +134,6 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
 #pragma unroll
       for (int i = 0; i < R; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
   };
-  static_assert(R == 10, "touch_bank lists R = 10 tap pairs");
   load_bank(ta, xa, trow, xp);
   for (uint32_t left = it_hi - it_lo; left != 0; left--) {
     touch_bank(ta, xa);
@@ -175,10 +179,13 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
     // float I/O (resample.c:927-963): the FIR value as is
     G<float> *o = out_ptr<float>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
     if (ONE_GROUP && CT == 2 && i_lo == 0 && i_hi == R) {
-      static_assert(R % 2 == 0, "R frames of 2 floats go out as R/2 float4");
 #pragma unroll
-      for (int i = 0; i < R; i += 2)
+      for (int i = 0; i + 1 < R; i += 2)
         *(G<f32x4_a4> *)(o + 2 * i) = f32x4_a4{acc[i].x, acc[i].y, acc[i + 1].x, acc[i + 1].y};
+      if constexpr (R % 2 != 0) {
+        o[2 * (R - 1)] = acc[R - 1].x;
+        o[2 * (R - 1) + 1] = acc[R - 1].y;
+      }
       return;
     }
 #pragma unroll
@@ -196,10 +203,11 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
       uint32_t v[R];
 #pragma unroll
       for (int i = 0; i < R; i++) v[i] = round_pack_pcm(acc[i].x, acc[i].y);
-      g_u32x4_a4 *o4 = (g_u32x4_a4 *)o;
-      o4[0] = u32x4_a4{v[0], v[1], v[2], v[3]};
-      o4[1] = u32x4_a4{v[4], v[5], v[6], v[7]};
-      *(g_u32x2_a4 *)(o + 16) = u32x2_a4{v[8], v[9]};
+      g_u32 *od = (g_u32 *)o;
+#pragma unroll
+      for (int i = 0; i + 4 <= R; i += 4) *(g_u32x4_a4 *)(od + i) = u32x4_a4{v[i], v[i + 1], v[i + 2], v[i + 3]};
+      if constexpr (R % 4 >= 2) *(g_u32x2_a4 *)(od + R / 4 * 4) = u32x2_a4{v[R / 4 * 4], v[R / 4 * 4 + 1]};
+      if constexpr (R % 2 != 0) od[R - 1] = v[R - 1];
       return;
     }
 #pragma unroll
@@ -268,13 +276,19 @@ __device__ __forceinline__ void fir_tile_rows(const PeriodParams &p, const float
   if (valid && c.live) {
     const uint32_t real = min(static_cast<uint32_t>(R), p.den - g * R);  // padding phases of the last group
     uint32_t *row = img + lane * stride + wave * R;  // R even: 8-byte aligned
+    if constexpr (R % 2 == 0) {
 #pragma unroll
-    for (int i = 0; i < R; i += 2) {
-      const uint32_t a = round_pack_pcm(acc[i].x, acc[i].y), b = round_pack_pcm(acc[i + 1].x, acc[i + 1].y);
-      if (i + 1 < static_cast<int>(real))
-        *reinterpret_cast<uint2 *>(row + i) = make_uint2(a, b);
-      else if (i < static_cast<int>(real))
-        row[i] = a;
+      for (int i = 0; i < R; i += 2) {
+        const uint32_t a = round_pack_pcm(acc[i].x, acc[i].y), b = round_pack_pcm(acc[i + 1].x, acc[i + 1].y);
+        if (i + 1 < static_cast<int>(real))
+          *reinterpret_cast<uint2 *>(row + i) = make_uint2(a, b);
+        else if (i < static_cast<int>(real))
+          row[i] = a;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < R; i++)
+        if (i < static_cast<int>(real)) row[i] = round_pack_pcm(acc[i].x, acc[i].y);
     }
   }
   __syncthreads();
@@ -376,7 +390,13 @@ hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const Des
 }
 
 const size_t kSlack = 16;  // floats: window starts on the input's 16-byte grid, staged by 8
-const uint32_t kR = 10;
+// Phases per wave.  -DSPEEXHIP_R=5 builds the alternative that was measured against it: half the
+// FMAs per sample read and tap load, but rows padded by 4 instead of 9 steps -- one stream 13.26 ->
+// 12.88 us, 32 streams 202 -> 212 us, stereo 48k->44.1k 189 -> 182 us: not worth a second table.
+#ifndef SPEEXHIP_R
+#define SPEEXHIP_R 10
+#endif
+const uint32_t kR = SPEEXHIP_R;
 
 }  // namespace
 
