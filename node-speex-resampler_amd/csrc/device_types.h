@@ -62,7 +62,9 @@ struct PeriodParams {
   uint32_t groups;        // phase groups (R phases each)
   uint32_t num, den, taps, channels;
   uint32_t cgroups;       // channel groups per frame (CT channels each)
-  uint32_t lane_periods;  // output periods per workgroup tile (= lanes / cgroups)
+  uint32_t lane_periods;  // output periods per workgroup tile
+  uint32_t half_periods;  // odd channel counts: lanes carry periods pl and pl + half_periods (0 = one period)
+  uint32_t half_offset;   // ... floats between the two periods' samples in the LDS window
   uint32_t wave_groups;   // waves per workgroup; wave w of split z takes groups z*wave_groups+w, ...
   uint32_t tail_frames;   // input frames a period needs beyond its start
   uint32_t history_block; // one-shot form: blockIdx.x of the workgroup that rolls the history

@@ -58,6 +58,7 @@ struct LaneCtx {
   uint32_t C;       // channels per frame
   uint32_t cg;      // channel group of this lane
   bool live;        // the lane's period exists in this tile
+  bool live_b;      // single-channel lanes: the lane's SECOND period (half a tile further) exists
   uint32_t xlane;   // float index of the lane's first sample of a group with delta_g = 0
   uint64_t K_lane;  // canonical output index of the lane's period, phase 0
 };
@@ -71,11 +72,15 @@ __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshi
   c.C = ONE_GROUP ? static_cast<uint32_t>(CT) : p.channels;
   c.cg = ONE_GROUP ? 0 : lane % p.cgroups;
   const uint32_t pl = ONE_GROUP ? lane : lane / p.cgroups;  // period of this lane inside the tile
-  c.live = pl < m_cnt;
+  // CT == 1 (odd channel counts): a packed FMA has no second channel to work on, so the lane takes
+  // a second PERIOD instead, half a tile further (p.half_periods): .x = period pl, .y = pl + half.
+  const uint32_t lane_max = CT == 1 ? p.half_periods : p.lane_periods;
+  c.live = pl < lane_max && pl < m_cnt;
+  c.live_b = CT == 1 && pl < lane_max && pl + p.half_periods < m_cnt;
   // PADDED: the LDS image carries p.pad floats after every period (num frames) so that the
   // lanes of a wave -- num*C floats apart, a multiple of the bank count for e.g. 8 channels at
   // num = 160 -- hit distinct banks; the per-step offset is then wave-uniform scalar arithmetic.
-  c.xlane = xshift + min(pl, p.lane_periods - 1) * (p.num * c.C + (PADDED ? p.pad : 0u)) + c.cg * CT;
+  c.xlane = xshift + min(pl, lane_max - 1) * (p.num * c.C + (PADDED ? p.pad : 0u)) + c.cg * CT;
   c.K_lane = static_cast<uint64_t>(m_lo + pl) * p.den;
   return c;
 }
@@ -115,7 +120,7 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
         x[u] = *reinterpret_cast<const f32x2 *>(sp + u * C);
       } else {
         x[u].x = sp[u * C];
-        x[u].y = 0.f;
+        x[u].y = sp[u * C + p.half_offset];  // the same step of the lane's second period
       }
     }
   };
@@ -168,6 +173,45 @@ template <int R, int CT, bool ONE_GROUP, typename T>
 __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamDesc &d, const LaneCtx &c,
                                             uint32_t g, const f32x2 (&acc)[R]) {
   const uint32_t C = c.C, cg = c.cg;
+  if constexpr (CT == 1) {
+    // single-channel lanes: .x belongs to the lane's period, .y to its second period half a tile on
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (half == 0 ? !c.live : !c.live_b) continue;
+      const int64_t k0 = static_cast<int64_t>(c.K_lane) + static_cast<int64_t>(half * p.half_periods) * p.den +
+                         static_cast<int64_t>(g) * R - d.k_shift;
+      const int64_t lo64 = k0 < 0 ? -k0 : 0;
+      const int64_t hi64 = min(static_cast<int64_t>(R), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * R,
+                                                           static_cast<int64_t>(d.n_out) - k0));
+      G<T> *o = out_ptr<T>(d) + k0 * static_cast<int64_t>(C) + cg;
+      if constexpr (ONE_GROUP && sizeof(T) == 2 && R % 2 == 0) {
+        // mono int16: the lane's R samples are R/2 consecutive dwords when they start on one
+        if (lo64 == 0 && hi64 == R && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+          uint32_t w[R / 2];
+#pragma unroll
+          for (int j = 0; j < R / 2; j++)
+            w[j] = half == 0 ? round_pack_pcm(acc[2 * j].x, acc[2 * j + 1].x) : round_pack_pcm(acc[2 * j].y, acc[2 * j + 1].y);
+          g_u32 *od = (g_u32 *)o;
+#pragma unroll
+          for (int j = 0; j + 4 <= R / 2; j += 4) *(g_u32x4_a4 *)(od + j) = u32x4_a4{w[j], w[j + 1], w[j + 2], w[j + 3]};
+          if constexpr ((R / 2) % 4 >= 2)
+            *(g_u32x2_a4 *)(od + R / 2 / 4 * 4) = u32x2_a4{w[R / 2 / 4 * 4], w[R / 2 / 4 * 4 + 1]};
+          if constexpr ((R / 2) % 2 != 0) od[R / 2 - 1] = w[R / 2 - 1];
+          continue;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < R; i++, o += C) {
+        if (i < lo64 || i >= hi64) continue;
+        const float v = half == 0 ? acc[i].x : acc[i].y;
+        if constexpr (sizeof(T) == 4)
+          o[0] = v;
+        else
+          o[0] = static_cast<int16_t>(round_pack_pcm(v, 0.f) & 0xffffu);
+      }
+    }
+    return;
+  }
   // rows i in [i_lo, i_hi) of this group are real phases that fall inside this call
   const int64_t k0 = static_cast<int64_t>(c.K_lane) + static_cast<int64_t>(g) * R - d.k_shift;
   const int64_t lo64 = k0 < 0 ? -k0 : 0;
@@ -270,7 +314,8 @@ __device__ __forceinline__ void fir_tile_rows(const PeriodParams &p, const float
   __syncthreads();  // every wave is done with the window
   if (p.skip & 8u) return;
 
-  const uint32_t cols = min(p.wave_groups * R, p.den - g0 * R);  // frames of a row held by this workgroup
+  // frames of a row held by this workgroup (a share past the last group holds none)
+  const uint32_t cols = g0 * R < p.den ? min(p.wave_groups * R, p.den - g0 * R) : 0u;
   const uint32_t stride = p.image_stride;                          // dwords, even, = 2 (mod 4)
   uint32_t *img = reinterpret_cast<uint32_t *>(xs);
   if (valid && c.live) {
@@ -318,6 +363,81 @@ __device__ __forceinline__ void fir_tile_rows(const PeriodParams &p, const float
   }
 }
 
+// The same for mono int16, where it matters most: a lane's R samples of one period are 20 bytes
+// at a 2*den-byte stride, and per-lane stores alone take longer than the FIR (121 vs 108 us for
+// 32 streams of 44.1k->48k).  Lanes deposit their samples in the image with 2-byte LDS writes,
+// shifted by one sample when the rows start on an odd sample of the output buffer, so that image
+// dwords and output dwords coincide; whole rows then leave as in the stereo case.  Row stride odd
+// (in dwords): the lanes of a half-wave, one row apart, deposit into distinct banks.
+template <int R, bool PADDED>
+__device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const float *__restrict__ rows,
+                                                   const StreamDesc &d, float *xs, uint32_t xshift, uint32_t m_lo,
+                                                   uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit) {
+  const LaneCtx c = lane_ctx<1, true, PADDED>(p, xshift, m_lo, m_cnt, lane);
+  const uint32_t g0 = zsplit * p.wave_groups;
+  const uint32_t g = g0 + wave;
+  const bool valid = g < p.groups;
+  f32x2 acc[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
+  if (valid && !(p.skip & 4u)) fir_group<R, 1, PADDED>(p, rows, xs, c, g, 0, p.l4, acc);
+  __syncthreads();  // every wave is done with the window
+  if (p.skip & 8u) return;
+
+  // samples of a row held by this workgroup (a share past the last group holds none)
+  const uint32_t cols = g0 * R < p.den ? min(p.wave_groups * R, p.den - g0 * R) : 0u;
+  const uint32_t stride = p.image_stride;                          // dwords, odd
+  // all rows of a tile start on the same parity of the output buffer's sample index (den is even)
+  const int64_t k_tile = static_cast<int64_t>(m_lo) * p.den + g0 * R - d.k_shift;
+  const uint32_t sh = static_cast<uint32_t>((static_cast<int64_t>(reinterpret_cast<uintptr_t>(d.out) >> 1) + k_tile) & 1);
+  int16_t *img16 = reinterpret_cast<int16_t *>(xs);
+  if (valid) {
+    const uint32_t real = min(static_cast<uint32_t>(R), p.den - g * R);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (half == 0 ? !c.live : !c.live_b) continue;
+      int16_t *row = img16 + static_cast<size_t>(lane + half * p.half_periods) * stride * 2 + wave * R + sh;
+#pragma unroll
+      for (int i = 0; i < R; i++)
+        if (i < static_cast<int>(real))
+          row[i] = static_cast<int16_t>(round_pack_pcm(half == 0 ? acc[i].x : acc[i].y, 0.f) & 0xffffu);
+    }
+  }
+  __syncthreads();
+
+  // copy-out: wave w takes rows w, w + nw, ...; lane l the dwords [4l, 4l+4) of the row; image
+  // dword j holds the row's samples 2j - sh and 2j + 1 - sh
+  const uint32_t nw = blockDim.x >> 6;
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(xs);
+  const uint32_t n_dw = (cols + sh + 1) / 2;
+  for (uint32_t m = wave; m < m_cnt; m += nw) {
+    const int64_t k0 = k_tile + static_cast<int64_t>(m) * p.den;  // output index of the row's sample 0
+    const int64_t lo = k0 < 0 ? -k0 : 0;
+    const int64_t hi = min<int64_t>(cols, static_cast<int64_t>(d.n_out) - k0);
+    const uint32_t *row = img + static_cast<size_t>(m) * stride;
+    g_i16 *o16 = out_ptr<int16_t>(d) + (k0 - sh);  // dword-aligned by the choice of sh
+    for (uint32_t j = 4 * lane; j < n_dw; j += 256) {
+      const uint32_t v[4] = {row[j], row[j + 1], row[j + 2], row[j + 3]};  // (rows carry 4 dwords of slack)
+      const int64_t s0 = 2 * static_cast<int64_t>(j) - sh;                  // row sample of v[0]'s low half
+      if (s0 >= lo && s0 + 8 <= hi) {
+        *(g_u32x4_a4 *)(o16 + 2 * j) = u32x4_a4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int64_t a = s0 + 2 * e;
+          const bool lo_ok = a >= lo && a < hi, hi_ok = a + 1 >= lo && a + 1 < hi;
+          if (lo_ok && hi_ok)
+            *(g_u32 *)(o16 + 2 * (j + e)) = v[e];
+          else if (lo_ok)
+            o16[2 * (j + e)] = static_cast<int16_t>(v[e] & 0xffffu);
+          else if (hi_ok)
+            o16[2 * (j + e) + 1] = static_cast<int16_t>(v[e] >> 16);
+        }
+      }
+    }
+  }
+}
+
 // <= 80 SGPRs: the hardware admits 8 waves per SIMD (two 16-wave workgroups per CU) only then
 // (MI355X_MICROARCH.md, residency; measured again with caps of 88, 90 and 96: 206 -> 260 us);
 // the compiler alone settles at ~106.
@@ -356,6 +476,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
     // whole-row stores need dword-aligned frames (uniform per stream)
     if (p.image_stride != 0 && (reinterpret_cast<uintptr_t>(d.out) & 3u) == 0) {
       fir_tile_rows<R, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
+      return;
+    }
+  }
+  if constexpr (ONE_GROUP && CT == 1 && sizeof(T) == 2 && R % 2 == 0) {
+    if (p.image_stride != 0) {
+      fir_tile_rows_mono<R, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
       return;
     }
   }
@@ -476,14 +602,16 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
     const size_t pad_floats = static_cast<size_t>(t.pad) * (lane_periods + t.tail_frames / f.num + 2);
     size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + 4) * channels + pad_floats) * 4 +
                    kSlack * 4;
-    // the same LDS later holds the tile's output image (one packed s16 pair per dword)
-    return std::max(bytes, static_cast<size_t>(lane_periods) * f.den * t.cgroups * 4);
+    // stereo: the same LDS may later hold the tile's output image (one packed s16 pair per dword)
+    if (t.ct == 2 && t.cgroups == 1) bytes = std::max(bytes, static_cast<size_t>(lane_periods) * f.den * 4);
+    return bytes;
   };
   // Periods per tile: all the lanes of a wave if that leaves room for TWO workgroups per CU (one
   // workgroup's staging and stores only overlap FMAs if another one is resident; measured on the
   // 8-channel 48k->44.1k case: 811 -> 738 us with 15 of 16 periods).  Otherwise weigh a second
   // workgroup (~20 %) against the lanes it costs.
-  const uint32_t full = 64 / t.cgroups;
+  // (single-channel lanes carry two periods each, see lane_ctx)
+  const uint32_t full = 64 / t.cgroups * (t.ct == 1 ? 2 : 1);
   const size_t half_lds = 80 * 1024;
   uint32_t fit_half = 0, fit_all = 0;
   for (uint32_t lp = full; lp >= 1; lp--) {
@@ -594,6 +722,8 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   p.wave_groups = wave_groups;
   p.tail_frames = t.tail_frames;
   p.pad = t.pad;
+  p.half_periods = t.ct == 1 ? (t.lane_periods + 1) / 2 : 0;
+  p.half_offset = p.half_periods * (f.num * channels + t.pad);
   p.wrap_step = f.num % 4 == 0 ? f.num / 4 : 0x40000000u;
   p.period_magic = period_magic_of(f.num * channels);
   p.history_block = max_periods == 0 ? 0 : tiles;
@@ -613,12 +743,20 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
     if (stride % 4 == 0) stride += 2;
     if (static_cast<size_t>(stride) * t.lane_periods * 4 + 16 <= t.window_bytes) p.image_stride = stride;
   }
+  // mono int16 (fir_tile_rows_mono): per-lane stores of 20-byte pieces cost more than the FIR, so the
+  // image pays as soon as the launch fills the chip (44.1k->48k: 8 streams 52.7 -> 46.8 us, 32 streams
+  // 159.6 -> 137.6 us; but one stream 16.6 -> 27.4 us: its few waves copy 16 rows each, in series)
+  if ((env_rows > 0 || (env_rows < 0 && static_cast<uint64_t>(tiles) * n_streams * 2 >= resident)) && !float_io &&
+      t.ct == 1 && t.cgroups == 1 && f.den % 2 == 0 && kR % 2 == 0 && wave_groups * splits >= t.groups) {
+    const uint32_t stride = ((wave_groups * kR + 1) / 2 + 5) | 1u;  // samples/2 + the shift + 4 dwords of slack, odd
+    if (static_cast<size_t>(stride) * t.lane_periods * 4 + 16 <= t.window_bytes) p.image_stride = stride;
+  }
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
   // A workgroup that owns only a share of the groups still stages the whole window: lend it the
   // waves it has no groups for, they leave after the staging barrier.
   static const int env_helpers = std::getenv("SPEEXHIP_HELPERS") ? std::atoi(std::getenv("SPEEXHIP_HELPERS")) : 1;
-  const bool helpers = env_helpers != 0 && splits > 1 && p.image_stride == 0;
+  const bool helpers = env_helpers != 0 && splits > 1 && p.image_stride == 0;  // (the image paths have barriers of their own)
   const uint32_t threads = (helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
   // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8
   // when a tile is split: workgroups whose linear ids differ by a multiple of 8 share an XCD, so

@@ -645,3 +645,43 @@ def test_peek_predicts_the_counters_and_leaves_the_state_alone():
                 want, wu = ref.process(x, cap)
             assert (used, got.shape[0]) == (want_used, want_made) == (wu, want.shape[0]), ((ch, i, o, q), k)
         r.close()
+
+
+def test_mono_rows_path_with_odd_and_even_starts():
+    """Mono int16 through the LDS image (launches that fill the chip): image dwords must line up with
+    output dwords whatever the parity of the row starts (k_shift odd or even, output pointer 2- or
+    4-byte aligned), partial rows at both ends of a call."""
+    import torch
+    ch, i, o, q, S, frames = 1, 44100, 48000, 7, 20, 400000  # 22 tiles x 20 streams: fills the chip
+    cap = int(frames * o / i) + 16
+    xs = np.stack([orc.lcg_pcm(frames, 900 + s) for s in range(S)]).reshape(S, frames, 1)
+    d_in = torch.from_numpy(xs).cuda()
+    d_store = torch.zeros((S, cap + 8, ch), dtype=torch.int16, device="cuda")
+    sp = torch.cuda.current_stream().cuda_stream
+    for shift in (0, 1):  # output rows of every stream start 4-byte aligned, then 2 bytes off
+        d_out = d_store[:, shift: shift + cap]
+        assert (d_out.data_ptr() - d_store.data_ptr()) == 2 * shift
+        b = speexhip.Batch(S, ch, i, o, q)
+        refs = [orc.Oracle(ch, i, o, q) for _ in range(S)]
+        for lens in ([frames - 7 * s for s in range(S)], [1000 + 13 * s for s in range(S)], [390001] * S):
+            used, made = b.process_device(d_in.data_ptr(), frames * ch, lens, d_out.data_ptr(), (cap + 8) * ch, cap, sp)
+            torch.cuda.synchronize()
+            out = d_out.cpu().numpy()
+            for s in range(S):
+                want, wu = refs[s].process(xs[s, : lens[s]], cap)
+                assert (used[s], made[s]) == (wu, want.shape[0]), (shift, s)
+                assert_close(out[s, : made[s]], want, "mono rows shift %d stream %d" % (shift, s))
+        b.close()
+
+
+def test_forced_image_stores_on_every_layout():
+    """The LDS-image store paths are normally chosen only for launches that fill the chip; force them
+    (SPEEXHIP_ROWS=1, read once per process) on the small multi-call layout cases, where tiles are split
+    into shares and some shares own no phase group at all."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEEXHIP_ROWS="1")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "window_layout_variants or every_golden_case or edge_cases or mono_rows"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
