@@ -387,16 +387,18 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
   // samples of a row held by this workgroup (a share past the last group holds none)
   const uint32_t cols = g0 * R < p.den ? min(p.wave_groups * R, p.den - g0 * R) : 0u;
   const uint32_t stride = p.image_stride;                          // dwords, odd
-  // all rows of a tile start on the same parity of the output buffer's sample index (den is even)
+  // parity of the output buffer's sample index at which row r starts (alternates when den is odd)
   const int64_t k_tile = static_cast<int64_t>(m_lo) * p.den + g0 * R - d.k_shift;
-  const uint32_t sh = static_cast<uint32_t>((static_cast<int64_t>(reinterpret_cast<uintptr_t>(d.out) >> 1) + k_tile) & 1);
+  const uint32_t sh0 = static_cast<uint32_t>((static_cast<int64_t>(reinterpret_cast<uintptr_t>(d.out) >> 1) + k_tile) & 1);
+  auto shift_of = [&](uint32_t r) { return (sh0 + (r & p.den)) & 1u; };  // (sh0 + r*den) & 1
   int16_t *img16 = reinterpret_cast<int16_t *>(xs);
   if (valid) {
     const uint32_t real = min(static_cast<uint32_t>(R), p.den - g * R);
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       if (half == 0 ? !c.live : !c.live_b) continue;
-      int16_t *row = img16 + static_cast<size_t>(lane + half * p.half_periods) * stride * 2 + wave * R + sh;
+      const uint32_t r = lane + half * p.half_periods;
+      int16_t *row = img16 + static_cast<size_t>(r) * stride * 2 + wave * R + shift_of(r);
 #pragma unroll
       for (int i = 0; i < R; i++)
         if (i < static_cast<int>(real))
@@ -409,8 +411,9 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
   // dword j holds the row's samples 2j - sh and 2j + 1 - sh
   const uint32_t nw = blockDim.x >> 6;
   const uint32_t *img = reinterpret_cast<const uint32_t *>(xs);
-  const uint32_t n_dw = (cols + sh + 1) / 2;
   for (uint32_t m = wave; m < m_cnt; m += nw) {
+    const uint32_t sh = shift_of(m);
+    const uint32_t n_dw = (cols + sh + 1) / 2;
     const int64_t k0 = k_tile + static_cast<int64_t>(m) * p.den;  // output index of the row's sample 0
     const int64_t lo = k0 < 0 ? -k0 : 0;
     const int64_t hi = min<int64_t>(cols, static_cast<int64_t>(d.n_out) - k0);
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
       return;
     }
   }
-  if constexpr (ONE_GROUP && CT == 1 && sizeof(T) == 2 && R % 2 == 0) {
+  if constexpr (ONE_GROUP && CT == 1 && sizeof(T) == 2) {
     if (p.image_stride != 0) {
       fir_tile_rows_mono<R, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
       return;
@@ -746,8 +749,10 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   // mono int16 (fir_tile_rows_mono): per-lane stores of 20-byte pieces cost more than the FIR, so the
   // image pays as soon as the launch fills the chip (44.1k->48k: 8 streams 52.7 -> 46.8 us, 32 streams
   // 159.6 -> 137.6 us; but one stream 16.6 -> 27.4 us: its few waves copy 16 rows each, in series)
-  if ((env_rows > 0 || (env_rows < 0 && static_cast<uint64_t>(tiles) * n_streams * 2 >= resident)) && !float_io &&
-      t.ct == 1 && t.cgroups == 1 && f.den % 2 == 0 && kR % 2 == 0 && wave_groups * splits >= t.groups) {
+  // (odd den -- rows alternate between even and odd starts -- works too, but measured no gain:
+  //  48k->44.1k q5 mono 146 -> 153 us; it stays reachable with SPEEXHIP_ROWS=1 for the tests)
+  if ((env_rows > 0 || (env_rows < 0 && static_cast<uint64_t>(tiles) * n_streams * 2 >= resident && f.den % 2 == 0)) &&
+      !float_io && t.ct == 1 && t.cgroups == 1 && wave_groups * splits >= t.groups) {
     const uint32_t stride = ((wave_groups * kR + 1) / 2 + 5) | 1u;  // samples/2 + the shift + 4 dwords of slack, odd
     if (static_cast<size_t>(stride) * t.lane_periods * 4 + 16 <= t.window_bytes) p.image_stride = stride;
   }

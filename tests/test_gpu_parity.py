@@ -652,13 +652,15 @@ def test_mono_rows_path_with_odd_and_even_starts():
     output dwords whatever the parity of the row starts (k_shift odd or even, output pointer 2- or
     4-byte aligned), partial rows at both ends of a call."""
     import torch
-    ch, i, o, q, S, frames = 1, 44100, 48000, 7, 20, 400000  # 22 tiles x 20 streams: fills the chip
-    cap = int(frames * o / i) + 16
+    ch, S, frames = 1, 20, 400000  # ~22 tiles x 20 streams: fills the chip
     xs = np.stack([orc.lcg_pcm(frames, 900 + s) for s in range(S)]).reshape(S, frames, 1)
     d_in = torch.from_numpy(xs).cuda()
-    d_store = torch.zeros((S, cap + 8, ch), dtype=torch.int16, device="cuda")
     sp = torch.cuda.current_stream().cuda_stream
-    for shift in (0, 1):  # output rows of every stream start 4-byte aligned, then 2 bytes off
+    # den even (rows all start on one parity) and den odd (the parity alternates row by row);
+    # output rows of every stream 4-byte aligned, then 2 bytes off
+    for (i, o, q, shift) in [(44100, 48000, 7, 0), (44100, 48000, 7, 1), (48000, 44100, 5, 0), (48000, 44100, 5, 1)]:
+        cap = int(frames * o / i) + 16
+        d_store = torch.zeros((S, cap + 8, ch), dtype=torch.int16, device="cuda")
         d_out = d_store[:, shift: shift + cap]
         assert (d_out.data_ptr() - d_store.data_ptr()) == 2 * shift
         b = speexhip.Batch(S, ch, i, o, q)
@@ -682,6 +684,6 @@ def test_forced_image_stores_on_every_layout():
     import sys
     env = dict(os.environ, SPEEXHIP_ROWS="1")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
-                          "window_layout_variants or every_golden_case or edge_cases or mono_rows"],
+                          "window_layout_variants or every_golden_case or edge_cases or mono_rows or many_rates"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
