@@ -1,45 +1,9 @@
 /// <reference types="node" />
-import { Transform } from 'stream';
-/** Same public surface as the reference's app/index.d.ts; computation runs on an MI355X. */
-declare class SpeexResampler {
-    channels: any;
-    inRate: any;
-    outRate: any;
-    quality: number;
-    _resamplerPtr: any;
-    _outBufferSize: number;
-    static initPromise: Promise<any>;
-    /**
-      * Create an SpeexResampler tranform stream.
-      * @param channels Number of channels, minimum is 1, no maximum
-      * @param inRate frequency in Hz for the input chunk
-      * @param outRate frequency in Hz for the target chunk
-      * @param quality number from 1 to 10, default to 7, 1 is fast but of bad quality, 10 is slow but best quality
-      */
-    constructor(channels: any, inRate: any, outRate: any, quality?: number);
-    /**
-      * Resample a chunk of audio.
-      * @param chunk interleaved PCM data in signed 16bits int
-      */
-    processChunk(chunk: Buffer): Buffer;
-    /** Extension: consecutive chunks in one GPU launch; result[i] === processChunk(chunks[i]). */
-    processChunks(chunks: Buffer[]): Buffer[];
-    /** Extension: processChunk off the event loop; calls on one instance stay in order. */
-    processChunkAsync(chunk: Buffer): Promise<Buffer>;
-    /** Extension: interleaved float32 PCM in and out (speex_resampler_process_interleaved_float). */
-    processChunkFloat(chunk: Buffer): Buffer;
-    /** Extensions: mid-stream control (speex_resampler_set_rate / set_quality / skip_zeros / reset_mem). */
-    setRate(inRate: number, outRate: number): void;
-    setQuality(quality: number): void;
-    skipZeros(): void;
-    resetMem(): void;
-    readonly inputLatency: number;
-    readonly outputLatency: number;
-    /** Extension: the filter's tail (response to the last inputLatency frames). */
-    flush(): Buffer;
-    /** Extension: release the GPU state now. */
-    destroy(): void;
-}
+// Type declarations of the drop-in (hand-written; the reference ships tsc output with `any`
+// arguments -- the call signatures below accept everything that one accepts).
+import { Transform, TransformCallback } from 'stream';
+
+/** Options of the streaming wrapper; all of them are extensions and default to off. */
 export interface SpeexResamplerTransformOptions {
     /** hold up to n chunks and resample them in one GPU launch (same bytes out) */
     coalesceChunks?: number;
@@ -48,14 +12,64 @@ export interface SpeexResamplerTransformOptions {
     /** at end of stream also emit the filter's tail */
     flushTail?: boolean;
 }
+
+/**
+ * Speex resampler whose filter runs on an MI355X.  Constructor, `processChunk`, `initPromise`
+ * and the instance fields are the reference's public surface; the rest are extensions.
+ */
+declare class SpeexResampler {
+    /** resolves once the native module is loaded; `processChunk` throws before that */
+    static initPromise: Promise<unknown>;
+
+    channels: number;
+    inRate: number;
+    outRate: number;
+    /** Speex quality, 0..10 */
+    quality: number;
+    /** native state handle, created by the first call */
+    _resamplerPtr: unknown;
+    /** grow-only byte size that caps the frames one call may return */
+    _outBufferSize: number;
+
+    constructor(channels: number, inRate: number, outRate: number, quality?: number);
+
+    /** interleaved s16le PCM in, resampled s16le PCM out */
+    processChunk(chunk: Buffer): Buffer;
+
+    /** consecutive chunks in one GPU launch; result[i] equals processChunk(chunks[i]) */
+    processChunks(chunks: Buffer[]): Buffer[];
+    /** processChunk off the event loop; calls on one instance stay in order */
+    processChunkAsync(chunk: Buffer): Promise<Buffer>;
+    /** interleaved float32 PCM in and out (speex_resampler_process_interleaved_float) */
+    processChunkFloat(chunk: Buffer): Buffer;
+
+    /** mid-stream control (speex_resampler_set_rate / set_quality / skip_zeros / reset_mem) */
+    setRate(inRate: number, outRate: number): void;
+    setQuality(quality: number): void;
+    skipZeros(): void;
+    resetMem(): void;
+    /** filter delay in frames at the input rate / at the output rate */
+    readonly inputLatency: number;
+    readonly outputLatency: number;
+
+    /** the filter's tail: the response to the last inputLatency frames */
+    flush(): Buffer;
+    /** release the GPU state now instead of at garbage collection */
+    destroy(): void;
+}
+
+/** `stream.Transform` around a SpeexResampler; misaligned trailing bytes wait for the next chunk. */
 export declare class SpeexResamplerTransform extends Transform {
-    channels: any;
-    inRate: any;
-    outRate: any;
+    channels: number;
+    inRate: number;
+    outRate: number;
     quality: number;
     resampler: SpeexResampler;
     _alignementBuffer: Buffer;
-    constructor(channels: any, inRate: any, outRate: any, quality?: number, options?: SpeexResamplerTransformOptions);
-    _transform(chunk: any, encoding: any, callback: any): void;
+
+    constructor(channels: number, inRate: number, outRate: number, quality?: number,
+                options?: SpeexResamplerTransformOptions);
+    _transform(chunk: Buffer, encoding: string, callback: TransformCallback): void;
 }
+
 export default SpeexResampler;

@@ -23,10 +23,8 @@ const globalModulePromise = new Promise((resolve, reject) => {
 
 class SpeexResampler {
   /**
-   * @param channels Number of channels, minimum is 1, no maximum
-   * @param inRate frequency in Hz for the input chunk
-   * @param outRate frequency in Hz for the target chunk
-   * @param quality number from 1 to 10, default to 7 (0 is accepted too, as in the reference)
+   * Same four arguments as the reference class: channel count (>= 1), input and output sample
+   * rates in Hz, Speex quality 0..10 (default 7; higher = longer filter).
    */
   constructor(channels, inRate, outRate, quality = 7) {
     this.channels = channels;
@@ -38,8 +36,7 @@ class SpeexResampler {
   }
 
   /**
-   * Resample a chunk of audio.
-   * @param chunk interleaved PCM data in signed 16bits int
+   * One chunk of interleaved s16le PCM in, the resampled chunk out (a fresh Buffer), synchronously.
    */
   processChunk(chunk) {
     if (!speexModule) {
@@ -235,18 +232,19 @@ class SpeexResamplerTransform extends Transform {
     return this._transformReference(chunk, encoding, callback);
   }
 
+  /**
+   * Whole frames of (carry ++ chunk); the 0 .. channels*2-1 bytes that do not complete a frame
+   * are carried to the next chunk in `_alignementBuffer` (the field name, typo included, is the
+   * reference's: src/index.ts:148-154 keeps it on the instance).
+   */
   _align(chunk) {
-    let chunkToProcess = chunk;
-    if (this._alignementBuffer.length > 0) {
-      chunkToProcess = Buffer.concat([this._alignementBuffer, chunk]);
-      this._alignementBuffer = EMPTY_BUFFER;
-    }
-    const extraneousBytesCount = chunkToProcess.length % (this.channels * Uint16Array.BYTES_PER_ELEMENT);
-    if (extraneousBytesCount !== 0) {
-      this._alignementBuffer = Buffer.from(chunkToProcess.slice(chunkToProcess.length - extraneousBytesCount));
-      chunkToProcess = chunkToProcess.slice(0, chunkToProcess.length - extraneousBytesCount);
-    }
-    return chunkToProcess;
+    const frameBytes = this.channels * Uint16Array.BYTES_PER_ELEMENT;
+    const carry = this._alignementBuffer;
+    const joined = carry.length > 0 ? Buffer.concat([carry, chunk]) : chunk;
+    const whole = joined.length - (joined.length % frameBytes);
+    // (a copy: the carried bytes must survive the caller reusing its chunk)
+    this._alignementBuffer = whole === joined.length ? EMPTY_BUFFER : Buffer.from(joined.slice(whole));
+    return whole === joined.length ? joined : joined.slice(0, whole);
   }
 
   _transformExtended(chunk, callback) {
@@ -265,25 +263,16 @@ class SpeexResamplerTransform extends Transform {
     }
   }
 
+  // the reference's behaviour: one synchronous call per chunk, output pushed at once
   _transformReference(chunk, encoding, callback) {
-    let chunkToProcess = chunk;
-    if (this._alignementBuffer.length > 0) {
-      chunkToProcess = Buffer.concat([this._alignementBuffer, chunk]);
-      this._alignementBuffer = EMPTY_BUFFER;
-    }
-    // whole frames only; the 0..(channels*2-1) trailing bytes wait for the next chunk
-    // (reference src/index.ts:148-154)
-    const extraneousBytesCount = chunkToProcess.length % (this.channels * Uint16Array.BYTES_PER_ELEMENT);
-    if (extraneousBytesCount !== 0) {
-      this._alignementBuffer = Buffer.from(chunkToProcess.slice(chunkToProcess.length - extraneousBytesCount));
-      chunkToProcess = chunkToProcess.slice(0, chunkToProcess.length - extraneousBytesCount);
-    }
+    let out;
     try {
-      const res = this.resampler.processChunk(chunkToProcess);
-      callback(null, res);
-    } catch (e) {
-      callback(e);
+      out = this.resampler.processChunk(this._align(chunk));
+    } catch (err) {
+      callback(err);
+      return;
     }
+    callback(null, out);
   }
 }
 
