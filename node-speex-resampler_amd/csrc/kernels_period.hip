@@ -103,6 +103,7 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   // Taps are wave-uniform: they travel HBM/L2 -> scalar cache -> SGPRs (s_load: the row pointer
   // is a __restrict__ kernel argument, so the loads are provably invariant) and feed
   // v_pk_fma_f32 directly.
+  // (s_setprio around the loop -- FIR waves ahead of staging / storing ones -- measured 6 % slower.)
   // Bank A = steps 0-1 of an iteration, bank B = steps 2-3: each bank is its 2R taps (R SGPR
   // pairs) plus its two sample reads.  Order per iteration, pinned with sched_barrier:
   //   wait A | issue loads B | 2R FMAs A | wait B | issue loads A(next) | 2R FMAs B
