@@ -704,9 +704,10 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
     //  about one workgroup per CU, not more -- every share re-stages the window.
     //  Also tried: splitting each group's TAP range over the spare waves of a share, partial sums
     //  meeting in LDS -- +1 us, the two extra barriers cost more than the occupancy gains.
-    //  Phase costs of that launch (rocprofv3, parts skipped): bare dispatch 2.3, descriptor +
-    //  geometry 1.1, window staging 1.6, FIR 7.3, stores 2.5 -- strictly serial in a launch that
-    //  is a single generation of workgroups.)
+    //  Phase costs of that launch (rocprofv3, parts skipped, profiles/r01_phases_cfg2_s1.txt): bare
+    //  dispatch 1.7, descriptor + geometry 1.0, window staging 1.9, FIR loop 6.6, stores 3.0 --
+    //  14.8 us if serial against 13.2 us measured: a launch that is a single generation of
+    //  workgroups overlaps very little.)
     while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident / 2 &&
            (t.groups + splits * 2 - 1) / (splits * 2) >= 2)
       splits *= 2;
