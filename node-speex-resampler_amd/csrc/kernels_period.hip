@@ -611,9 +611,10 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
     return bytes;
   };
   // Periods per tile: all the lanes of a wave if that leaves room for TWO workgroups per CU (one
-  // workgroup's staging and stores only overlap FMAs if another one is resident; measured on the
-  // 8-channel 48k->44.1k case: 811 -> 738 us with 15 of 16 periods).  Otherwise weigh a second
-  // workgroup (~20 %) against the lanes it costs.
+  // workgroup's staging and stores only overlap FMAs if another one is resident; same box,
+  // SPEEXHIP_FULL_TILE=1 against the default: 8-channel 48k->44.1k 785 -> 643 us with 15 of 16
+  // periods, stereo 48k->44.1k 225 -> 190 us with 62 of 64).  Otherwise weigh a second workgroup
+  // (~20 %) against the lanes it costs.
   // (single-channel lanes carry two periods each, see lane_ctx)
   const uint32_t full = 64 / t.cgroups * (t.ct == 1 ? 2 : 1);
   const size_t half_lds = 80 * 1024;
@@ -627,6 +628,8 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
     }
   }
   t.lane_periods = (fit_half != 0 && 5 * fit_half >= 4 * fit_all) ? fit_half : fit_all;
+  static const bool full_tile = std::getenv("SPEEXHIP_FULL_TILE") != nullptr;  // diagnostics: A/B of the rule above
+  if (full_tile) t.lane_periods = fit_all;
   t.window_bytes = t.lane_periods ? window_bytes_for(t.lane_periods) : 0;
   // needs enough phases to fill the R-wide register tile and a window that fits one CU's LDS
   // ... and at least a quarter of each wave at work (below that the exact kernel's mapping wins)
