@@ -240,3 +240,39 @@ def test_planner_and_realignment_match_the_reference_control_scripts(golden):
             assert got == want, (c["name"], k, op, got, want)
             checked += 1
     assert checked == 960
+
+
+def test_committed_bench_lines_keep_the_driver_contract():
+    """profiles/r01_bench_lines.jsonl holds the JSON lines bench.py printed on the GPU box.  The default
+    one (BASELINE configs[1], one stream) must carry every key the driver's contract names, with the
+    roofline and cpu_baseline objects; the others at least metric/value/roofline.  (bench.py itself
+    needs a GPU; this keeps the evidence and the contract from drifting apart unnoticed.)"""
+    import json
+    path = os.path.join(ROOT, "profiles", "r01_bench_lines.jsonl")
+    lines = [json.loads(l) for l in open(path) if l.strip()]
+    assert len(lines) >= 6
+    default = [d for d in lines if d["config"]["streams_per_gpu"] == 1 and d["config"]["mode"] == "fast" and
+               d["config"]["io"] == "int16" and "configs[1]" in d["config"]["workload"]]
+    assert len(default) == 1
+    d = default[0]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # traffic (PMC) must be at least the algorithmic bytes and not wildly above them
+    assert r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 2 * r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c)
+    assert c["kind"] == "reference" and c["cores"] == 1 and c["unit"] == "Msamples/s" and c["value"] > 0
+    assert d["parity"]["max_abs_diff_lsb"] <= 1 and d["parity"]["counters_equal"] is True
+    # value is whole-job input samples per second: consistent with ms_per_step and the chunk size
+    per_step = d["config"]["frames_per_chunk"] * 2 * d["config"]["streams_per_gpu"]
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    for other in lines:
+        assert other["value"] > 0 and 0 < other["roofline"]["frac"] < 1 and other["metric"].startswith("input Msamples/s")
