@@ -603,6 +603,9 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
   // (+ 4 frames: the tap/sample pipeline prefetches one bank past the last step; + the padding
   //  of every period the window can touch)
   auto window_bytes_for = [&](uint32_t lane_periods) {
+    // (single-channel lanes read their second period at pl + ceil(periods/2): an odd tile still
+    //  reads -- and discards -- one period past its last, so size the image for an even count)
+    if (t.ct == 1) lane_periods = (lane_periods + 1) / 2 * 2;
     const size_t pad_floats = static_cast<size_t>(t.pad) * (lane_periods + t.tail_frames / f.num + 2);
     size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + 4) * channels + pad_floats) * 4 +
                    kSlack * 4;
