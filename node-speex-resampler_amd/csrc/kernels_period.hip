@@ -444,7 +444,10 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
 
 // <= 80 SGPRs: the hardware admits 8 waves per SIMD (two 16-wave workgroups per CU) only then
 // (MI355X_MICROARCH.md, residency; measured again with caps of 88, 90 and 96: 206 -> 260 us);
-// the compiler alone settles at ~106.
+// the compiler alone settles at ~106.  (A second, uncapped build of the kernel for launches of at
+// most one workgroup per CU was tried: removing the cap from this kernel gave 13.36 -> 13.0 us on
+// one stream, but as a separate __global__ around a shared device body it measured 13.59 vs 13.53 us,
+// i.e. nothing, and the refactoring cost the capped kernel 0.17 us -- not kept.)
 //
 // Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
 // shares of its phase groups.
