@@ -289,9 +289,10 @@ def test_small_ratio_sliding_window_kernel_variants():
         r.close()
 
 
-def test_persistent_tile_walk_with_many_ragged_streams():
-    """More tiles than resident workgroups -> resample_period_persistent; ragged stream lengths
-    leave some workgroups with empty tiles; descriptors travel through the device ring."""
+def test_many_ragged_streams_through_the_descriptor_ring():
+    """40 streams (> 8: descriptors travel through the pinned -> device ring instead of the kernel
+    arguments) with ragged lengths: the grid is sized for the longest stream, so the shorter ones
+    leave workgroups with empty tiles."""
     import torch
     ch, i, o, q, S, frames = 2, 44100, 48000, 7, 40, 100000
     lens = [frames - 997 * (s % 7) for s in range(S)]
@@ -689,3 +690,28 @@ def test_forced_image_stores_on_every_layout():
                           "window_layout_variants or every_golden_case or edge_cases or mono_rows or many_rates"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_one_very_large_call():
+    """Maximum sizes: a single call of 2^24 stereo frames (64 MiB in, 73 MiB out) -- 16 times the
+    BASELINE chunk -- through the host-buffer entry point, FAST mode against the oracle over the whole
+    output, then a second large call continuing the stream (closed-form planner over ~105 000 blocks,
+    64-bit index arithmetic in the kernels, > 2^16 workgroups in the exact kernel's grid)."""
+    ch, i, o, q, frames = 2, 44100, 48000, 7, 1 << 24
+    x = orc.lcg_pcm(frames * ch, 2024).reshape(frames, ch)
+    ref = orc.Oracle(ch, i, o, q)
+    r = speexhip.Resampler(ch, i, o, q)
+    for call, part in enumerate((x, x[: frames // 2 + 12345])):
+        cap = int(part.shape[0] * o / i) + 8
+        got, used = r.process(part, cap)
+        want, wu = ref.process(part, cap)
+        assert used == wu and r.position() == ref.position(), call
+        assert_close(got, want, "2^24-frame call %d" % call)
+    r.close()
+    # and bit-exactly on a prefix in EXACT mode (the whole thing would take the exact kernel ~1 s)
+    r = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT)
+    ref = orc.Oracle(ch, i, o, q)
+    got, used = r.process(x[: 1 << 22], 1 << 23)
+    want, wu = ref.process(x[: 1 << 22], 1 << 23)
+    assert used == wu and np.array_equal(got, want)
+    r.close()
