@@ -20,7 +20,7 @@ struct StreamDesc {
   int32_t last0;        // window start of output 0, in V-frames minus (taps-1) offset: see pos()
   uint32_t frac0;       // phase numerator of output 0
   uint32_t k_shift;     // phase_index_of(frac0): canonical phase index of output 0
-  int32_t base_shift;   // last0 - (k_shift*num) div den  (tiled kernel's period origin)
+  int32_t base_shift;   // last0 - (k_shift*num) div den: V-frame where period 0, phase 0 starts
   uint32_t tile_begin;  // first tile of this stream in the launch's flat tile list
   uint32_t hist_frames; // frames in `hist`: taps-1, plus the pending ("magic") frames a filter
                         // change left buffered (reference resample.c:727-782) -- they are input

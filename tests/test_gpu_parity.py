@@ -311,7 +311,7 @@ def test_many_ragged_streams_through_the_descriptor_ring():
         for s in range(S):
             want, wu = refs[s].process(xs[s][: lens[s]], cap)
             assert (used[s], made[s]) == (wu, want.shape[0])
-            assert_close(out[s, : made[s]], want, "persistent s=%d call=%d" % (s, call))
+            assert_close(out[s, : made[s]], want, "ragged s=%d call=%d" % (s, call))
     b.close()
 
 

@@ -1,5 +1,5 @@
 // tools/ubench_fma.hip -- measure fp32 vector FMA issue rates on gfx950 (design input for the
-// tiled kernel): v_fma_f32 vs v_pk_fma_f32, at 1/2/4 waves per SIMD.  Not part of the product.
+// FIR kernels): v_fma_f32 vs v_pk_fma_f32, at 1/2/4 waves per SIMD.  Not part of the product.
 // build: hipcc --offload-arch=gfx950 -O3 tools/ubench_fma.hip -o tools/ubench_fma
 #include <hip/hip_runtime.h>
 #include <cstdio>
