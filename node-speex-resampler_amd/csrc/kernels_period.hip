@@ -292,84 +292,19 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
   }
 }
 
-// Stereo int16, one pass over the groups: the tile's outputs -- frames K = m*den + r of 64
+// Mono int16, one pass over the groups: the tile's outputs -- samples K = m*den + r of 128
 // consecutive periods -- are one contiguous run in HBM, but a lane holds only R consecutive
-// frames of its own period (40 bytes at a 4*den-byte stride), and a store instruction costs one
-// L2 request per lane whatever its width: stores alone run at 2 TB/s that way.  Here the
-// workgroup lays its results out as an image in LDS (the window is dead by then), one row per
-// period, and writes whole rows: 16 bytes per lane, consecutive lanes, full cache lines.
-// Row stride = 2 (mod 4) dwords: the 32 lanes of a half-wave, one row apart, hit 32 distinct
-// banks when they deposit their dwords, and rows stay 8-byte aligned for the read-back.
-template <int R, bool PADDED>
-__device__ __forceinline__ void fir_tile_rows(const PeriodParams &p, const float *__restrict__ rows,
-                                              const StreamDesc &d, float *xs, uint32_t xshift, uint32_t m_lo,
-                                              uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit) {
-  const LaneCtx c = lane_ctx<2, true, PADDED>(p, xshift, m_lo, m_cnt, lane);
-  const uint32_t g0 = zsplit * p.wave_groups;  // this workgroup owns groups [g0, g0 + wave_groups)
-  const uint32_t g = g0 + wave;
-  const bool valid = g < p.groups;
-  f32x2 acc[R];
-#pragma unroll
-  for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
-  if (valid && !(p.skip & 4u)) fir_group<R, 2, PADDED>(p, rows, xs, c, g, 0, p.l4, acc);
-  __syncthreads();  // every wave is done with the window
-  if (p.skip & 8u) return;
-
-  // frames of a row held by this workgroup (a share past the last group holds none)
-  const uint32_t cols = g0 * R < p.den ? min(p.wave_groups * R, p.den - g0 * R) : 0u;
-  const uint32_t stride = p.image_stride;                          // dwords, even, = 2 (mod 4)
-  uint32_t *img = reinterpret_cast<uint32_t *>(xs);
-  if (valid && c.live) {
-    const uint32_t real = min(static_cast<uint32_t>(R), p.den - g * R);  // padding phases of the last group
-    uint32_t *row = img + lane * stride + wave * R;  // R even: 8-byte aligned
-    if constexpr (R % 2 == 0) {
-#pragma unroll
-      for (int i = 0; i < R; i += 2) {
-        const uint32_t a = round_pack_pcm(acc[i].x, acc[i].y), b = round_pack_pcm(acc[i + 1].x, acc[i + 1].y);
-        if (i + 1 < static_cast<int>(real))
-          *reinterpret_cast<uint2 *>(row + i) = make_uint2(a, b);
-        else if (i < static_cast<int>(real))
-          row[i] = a;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < R; i++)
-        if (i < static_cast<int>(real)) row[i] = round_pack_pcm(acc[i].x, acc[i].y);
-    }
-  }
-  __syncthreads();
-
-  // copy-out: wave w takes rows w, w + nw, ...; lane l the dwords [4l, 4l+4) of the row
-  const uint32_t nw = blockDim.x >> 6;
-  g_u32 *out = reinterpret_cast<g_u32 *>(out_ptr<int16_t>(d));
-  for (uint32_t m = wave; m < m_cnt; m += nw) {
-    // canonical index of the row's first frame held here, relative to the call's first output
-    const int64_t k0 = static_cast<int64_t>(m_lo + m) * p.den + g0 * R - d.k_shift;
-    const int64_t lo = k0 < 0 ? -k0 : 0;                                        // first valid column
-    const int64_t hi = min<int64_t>(cols, static_cast<int64_t>(d.n_out) - k0);  // one past the last
-    const uint32_t *row = img + m * stride;
-    for (uint32_t j = 4 * lane; j < cols; j += 256) {
-      const uint2 v01 = *reinterpret_cast<const uint2 *>(row + j);
-      const uint2 v23 = *reinterpret_cast<const uint2 *>(row + j + 2);  // (rows carry 2+ dwords of slack)
-      g_u32 *o = out + (k0 + j);
-      if (static_cast<int64_t>(j) >= lo && static_cast<int64_t>(j) + 4 <= hi) {
-        *(g_u32x4_a4 *)o = u32x4_a4{v01.x, v01.y, v23.x, v23.y};
-      } else {
-        const uint32_t v[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-          if (static_cast<int64_t>(j) + e >= lo && static_cast<int64_t>(j) + e < hi) o[e] = v[e];
-      }
-    }
-  }
-}
-
-// The same for mono int16, where it matters most: a lane's R samples of one period are 20 bytes
-// at a 2*den-byte stride, and per-lane stores alone take longer than the FIR (121 vs 108 us for
-// 32 streams of 44.1k->48k).  Lanes deposit their samples in the image with 2-byte LDS writes,
-// shifted by one sample when the rows start on an odd sample of the output buffer, so that image
-// dwords and output dwords coincide; whole rows then leave as in the stereo case.  Row stride odd
-// (in dwords): the lanes of a half-wave, one row apart, deposit into distinct banks.
+// samples of each of its two periods (20 bytes at a 2*den-byte stride), and a store instruction
+// costs one L2 request per lane whatever its width: per-lane stores alone take longer than the FIR
+// (121 vs 108 us for 32 streams of 44.1k->48k).  Here the workgroup lays its results out as an
+// image in LDS (the window is dead by then), one row per period, and writes whole rows: 16 bytes
+// per lane, consecutive lanes, full cache lines.  Lanes deposit their samples with 2-byte LDS
+// writes, shifted by one sample when the row starts on an odd sample of the output buffer, so that
+// image dwords and output dwords coincide.  Row stride odd (in dwords): the lanes of a half-wave,
+// one row apart, deposit into distinct banks.
+// (The stereo counterpart -- 40-byte pieces per lane -- was built too: stores alone 74 -> 48 us, but
+//  the launch as a whole within noise at every size, 210.8-213.5 vs 212.4-213.5 us at 32 streams and
+//  slower below; removed.)
 template <int R, bool PADDED>
 __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const float *__restrict__ rows,
                                                    const StreamDesc &d, float *xs, uint32_t xshift, uint32_t m_lo,
@@ -479,13 +414,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   if (p.skip & 128u) return;  // diagnostics: prologue + staging only
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
-  if constexpr (ONE_GROUP && CT == 2 && sizeof(T) == 2) {
-    // whole-row stores need dword-aligned frames (uniform per stream)
-    if (p.image_stride != 0 && (reinterpret_cast<uintptr_t>(d.out) & 3u) == 0) {
-      fir_tile_rows<R, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
-      return;
-    }
-  }
   if constexpr (ONE_GROUP && CT == 1 && sizeof(T) == 2) {
     if (p.image_stride != 0) {
       fir_tile_rows_mono<R, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
@@ -612,8 +540,6 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
     const size_t pad_floats = static_cast<size_t>(t.pad) * (lane_periods + t.tail_frames / f.num + 2);
     size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + 4) * channels + pad_floats) * 4 +
                    kSlack * 4;
-    // stereo: the same LDS may later hold the tile's output image (one packed s16 pair per dword)
-    if (t.ct == 2 && t.cgroups == 1) bytes = std::max(bytes, static_cast<size_t>(lane_periods) * f.den * 4);
     return bytes;
   };
   // Periods per tile: all the lanes of a wave if that leaves room for TWO workgroups per CU (one
@@ -741,22 +667,8 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   p.wrap_step = f.num % 4 == 0 ? f.num / 4 : 0x40000000u;
   p.period_magic = period_magic_of(f.num * channels);
   p.history_block = max_periods == 0 ? 0 : tiles;
-  // Whole-row stores through an LDS image (fir_tile_rows): stereo int16, one pass over the
-  // groups, image within the window's LDS.  Its two extra barriers only pay when the launch runs
-  // for several generations of workgroups (measured at sustained clocks: 32 streams 216 -> 212 us,
-  // but 4 streams 33.9 -> 35.1 and one stream 13.7 -> 14.9; stores alone 74 -> 48 us).
-  // (Also tried against lock-step between the two workgroups of a CU: delaying the first-generation
-  //  workgroup in the CU's odd slot (HW_ID.TG_ID) by half a tile -- no effect, they drift apart
-  //  on their own.)
   static const int env_rows = std::getenv("SPEEXHIP_ROWS") ? std::atoi(std::getenv("SPEEXHIP_ROWS")) : -1;
-  const bool many_generations = static_cast<uint64_t>(tiles) * n_streams * splits >= 3ull * resident;
   p.image_stride = 0;
-  if ((env_rows > 0 || (env_rows < 0 && many_generations)) && !float_io && t.ct == 2 &&
-      t.cgroups == 1 && wave_groups * splits >= t.groups) {
-    uint32_t stride = (wave_groups * kR + 2 + 1) & ~1u;  // >= 2 dwords of slack, even
-    if (stride % 4 == 0) stride += 2;
-    if (static_cast<size_t>(stride) * t.lane_periods * 4 + 16 <= t.window_bytes) p.image_stride = stride;
-  }
   // mono int16 (fir_tile_rows_mono): per-lane stores of 20-byte pieces cost more than the FIR, so the
   // image pays as soon as the launch fills the chip (44.1k->48k: 8 streams 52.7 -> 46.8 us, 32 streams
   // 159.6 -> 137.6 us; but one stream 16.6 -> 27.4 us: its few waves copy 16 rows each, in series)

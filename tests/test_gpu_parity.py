@@ -574,8 +574,8 @@ def test_window_layout_variants_of_the_period_kernel():
     """Every LDS layout decision of the period kernel on its own ratio: bank padding with one and
     with several period boundaries per group (num % 4 == 0), fewer periods per tile so that two
     workgroups share a CU, partly filled waves for very wide windows (num = 320, 441, 640), odd
-    channel counts, a split tile with staging helper waves, and whole-row stores (>= 3 generations of
-    workgroups).  fast_path must stay 2 and every sample within +-1 LSB, multi-call, history equal."""
+    channel counts (two periods per lane) and a split tile with staging helper waves.  fast_path must
+    stay 2 and every sample within +-1 LSB, multi-call, history equal."""
     cases = [(2, 48000, 44100, 5), (2, 48000, 44100, 10), (1, 48000, 44100, 7), (4, 48000, 44100, 5),
              (6, 44100, 48000, 7), (2, 96000, 44100, 7), (2, 32000, 44100, 7), (2, 44100, 32000, 7),
              (3, 48000, 44100, 4), (2, 11025, 48000, 6), (2, 48000, 11025, 3), (2, 44100, 8000, 5),
@@ -595,9 +595,9 @@ def test_window_layout_variants_of_the_period_kernel():
         r.close()
 
 
-def test_many_generation_launch_uses_whole_row_stores_correctly():
-    """40 stereo streams x 400k frames: > 3 generations of workgroups, so the outputs leave through the
-    LDS image (whole-row stores); ragged lengths put partial rows and partial tiles at both ends."""
+def test_many_generation_launch_with_ragged_ends():
+    """40 stereo streams x 400k frames: several generations of workgroups on every CU; ragged lengths
+    put partial periods and partial tiles at both ends, the second call starts mid-period."""
     import torch
     ch, i, o, q, S, frames = 2, 44100, 48000, 7, 40, 400000
     cap = int(frames * o / i) + 16
@@ -614,13 +614,13 @@ def test_many_generation_launch_uses_whole_row_stores_correctly():
         out = d_out.cpu().numpy()
         for s in (0, 1, 17, 39):
             if call == 0:
-                refs = getattr(test_many_generation_launch_uses_whole_row_stores_correctly, "refs", {})
+                refs = getattr(test_many_generation_launch_with_ragged_ends, "refs", {})
                 refs[s] = orc.Oracle(ch, i, o, q)
-                test_many_generation_launch_uses_whole_row_stores_correctly.refs = refs
-            ref = test_many_generation_launch_uses_whole_row_stores_correctly.refs[s]
+                test_many_generation_launch_with_ragged_ends.refs = refs
+            ref = test_many_generation_launch_with_ragged_ends.refs[s]
             want, wu = ref.process(xs[s, : lens[s]], cap)
             assert (used[s], made[s]) == (wu, want.shape[0]), (call, s)
-            assert_close(out[s, : made[s]], want, "rows path call %d stream %d" % (call, s))
+            assert_close(out[s, : made[s]], want, "call %d stream %d" % (call, s))
     b.close()
 
 
@@ -680,9 +680,9 @@ def test_mono_rows_path_with_odd_and_even_starts():
 
 
 def test_forced_image_stores_on_every_layout():
-    """The LDS-image store paths are normally chosen only for launches that fill the chip; force them
-    (SPEEXHIP_ROWS=1, read once per process) on the small multi-call layout cases, where tiles are split
-    into shares and some shares own no phase group at all."""
+    """The mono LDS-image store path is normally chosen only for launches that fill the chip and for an
+    even den; force it (SPEEXHIP_ROWS=1, read once per process) on the small multi-call cases, where
+    tiles are split into shares, some shares own no phase group at all, and den may be odd."""
     import subprocess
     import sys
     env = dict(os.environ, SPEEXHIP_ROWS="1")
