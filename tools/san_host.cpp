@@ -1,0 +1,38 @@
+// tools/san_host.cpp -- the host-only half of the product (filter_design.cpp, stream_plan.cpp) under ASan + UBSan:
+// every rate pair of a grid incl. absurd ones, random positions / pending frames / capacities up to 2^32.
+// Built and run by tests/test_cpu_sanitizers.py (GPU sanitizers are not available on the pool).
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include "filter_design.h"
+#include "stream_plan.h"
+using namespace speexhip;
+int main() {
+  std::mt19937 rng(1);
+  const uint32_t rates[] = {8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 192000, 1, 7, 4000000};
+  long plans = 0, filters = 0;
+  for (uint32_t a : rates) for (uint32_t b : rates) for (int q = 0; q <= 10; q += 5) {
+    FilterSpec f;
+    int rc = design_filter(a, b, q, &f, (uint64_t)a * b < 5000000000ull);  // tables only for sane sizes
+    if (rc != 0) continue;
+    filters++;
+    if (!f.table.empty() && f.den < 2000) {
+      std::vector<double> row(f.taps);
+      for (uint32_t ph = 0; ph < f.den; ph += (f.den / 7 + 1)) phase_taps(f, ph, row.data());
+    }
+    for (int k = 0; k < 200; k++) {
+      StreamPos p; p.last = (int32_t)(rng() % (f.taps + 5)); p.frac = rng() % f.den; p.magic = (rng() % 4 == 0) ? rng() % 300 : 0;
+      EntryRules r; r.float_entry = rng() & 1; r.block_in = 160 + (rng() % 3 == 0 ? rng() % 500 : 0);
+      uint32_t in = rng() % 3 ? rng() % 5000 : rng(); uint32_t cap = rng() % 3 ? rng() % 6000 : rng();
+      CallPlan c = plan_call(f.num, f.den, in, cap, p, r);
+      if (c.consumed > in || c.produced > cap || c.end.frac >= f.den) { printf("BAD plan\n"); return 1; }
+      (void)phase_index_of(f.num, f.den, p.frac);
+      (void)produced_closed_form(f.num, f.den, in, cap, p);
+      plans++;
+    }
+    for (uint32_t m = 0; m < 400; m += 37) { Realign g = realign_history(f.taps, f.taps + 8 * (rng() % 40), m); (void)g; g = realign_history(f.taps + 8 * (rng() % 40), f.taps, m); (void)g; }
+    uint32_t fr = rng() % f.den; (void)scale_phase(&fr, 1 + rng() % 100000, f.den);
+  }
+  printf("sanitizer run ok: %ld filters, %ld plans\n", filters, plans);
+  return 0;
+}
