@@ -13,17 +13,22 @@ int main() {
   long plans = 0, filters = 0;
   for (uint32_t a : rates) for (uint32_t b : rates) for (int q = 0; q <= 10; q += 5) {
     FilterSpec f;
-    int rc = design_filter(a, b, q, &f, (uint64_t)a * b < 5000000000ull);  // tables only for sane sizes
+    int rc = design_filter(a, b, q, &f, false);  // geometry first ...
+    if (rc != 0) continue;
+    if (f.table_len <= 20000) rc = design_filter(a, b, q, &f, true);  // ... tables where they are small
     if (rc != 0) continue;
     filters++;
     if (!f.table.empty() && f.den < 2000) {
       std::vector<double> row(f.taps);
       for (uint32_t ph = 0; ph < f.den; ph += (f.den / 7 + 1)) phase_taps(f, ph, row.data());
     }
-    for (int k = 0; k < 200; k++) {
+    for (int k = 0; k < 40; k++) {
       StreamPos p; p.last = (int32_t)(rng() % (f.taps + 5)); p.frac = rng() % f.den; p.magic = (rng() % 4 == 0) ? rng() % 300 : 0;
       EntryRules r; r.float_entry = rng() & 1; r.block_in = 160 + (rng() % 3 == 0 ? rng() % 500 : 0);
-      uint32_t in = rng() % 3 ? rng() % 5000 : rng(); uint32_t cap = rng() % 3 ? rng() % 6000 : rng();
+      // (full-range lengths only where whole blocks fast-forward in closed form; extreme up-sampling
+      //  walks 160-frame blocks one by one and would dominate the run time)
+      const uint32_t big = f.num >= f.den ? rng() : rng() % (1u << 20);
+      uint32_t in = rng() % 3 ? rng() % 5000 : big; uint32_t cap = rng() % 3 ? rng() % 6000 : rng();
       CallPlan c = plan_call(f.num, f.den, in, cap, p, r);
       if (c.consumed > in || c.produced > cap || c.end.frac >= f.den) { printf("BAD plan\n"); return 1; }
       (void)phase_index_of(f.num, f.den, p.frac);
