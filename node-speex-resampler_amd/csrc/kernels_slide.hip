@@ -1,4 +1,4 @@
-// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6, num <= 4, and n:1 up to 6:1):
+// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6, num <= 4, and n:1 for n = 5, 6, 8, 12):
 // integer up-sampling 24k->48k, 16k->48k, 8k->48k, same-rate, 2:1 / 3:1 / 4:1 decimation, 3:2,
 // 2:3 ... (BASELINE configs[2]; the reference picks resampler_basic_direct_* for
 // most of these, deps/speex/resample.c:331-435).  +-1 LSB.
@@ -175,10 +175,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   const bool dense = PAIR_CH ? (C == 2) : (C == 1 && p.den == 2u * NP);
   g_i16 *o0 = out_ptr<int16_t>(d) + (static_cast<int64_t>(K0) - static_cast<int64_t>(d.k_shift)) * C;
   if (dense && inside && (reinterpret_cast<uintptr_t>(o0) & 3u) == 0) {
-    static_assert((P * NP) % 4 == 0, "pairs per lane come in groups of 4");
+    static_assert((P * NP) % 2 == 0, "pairs per lane come in groups of 2 or 4");
+    if constexpr ((P * NP) % 4 == 0) {
 #pragma unroll
-    for (int q = 0; q < P * NP; q += 4)
-      *(g_u32x4_a4 *)(o0 + 2 * q) = u32x4_a4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+      for (int q = 0; q < P * NP; q += 4)
+        *(g_u32x4_a4 *)(o0 + 2 * q) = u32x4_a4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+    } else {
+      typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+      typedef __attribute__((address_space(1))) u32x2_a4 g_u32x2_a4;
+#pragma unroll
+      for (int q = 0; q < P * NP; q += 2) *(g_u32x2_a4 *)(o0 + 2 * q) = u32x2_a4{v[q], v[q + 1]};
+    }
     return;
   }
 #pragma unroll
@@ -242,6 +249,8 @@ const SlideShape kShapes[] = {
     {4, 1, true, 4}, {4, 1, false, 4},
     // 5:1 and 6:1 decimation (48k -> 8k, 96k -> 16k): a 42-frame register window, 4 waves per SIMD
     {5, 1, true, 4}, {5, 1, false, 4}, {6, 1, true, 4}, {6, 1, false, 4},
+    // 8:1 and 12:1 (192k -> 24k / 16k, 96k -> 12k / 8k): two periods per lane, 24- / 36-frame window
+    {8, 1, true, 2}, {8, 1, false, 2}, {12, 1, true, 2}, {12, 1, false, 2},
 };
 }  // namespace
 
@@ -353,6 +362,10 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   SPEEXHIP_SLIDE_CASE(4, 5, 1, false)
   SPEEXHIP_SLIDE_CASE(4, 6, 1, true)
   SPEEXHIP_SLIDE_CASE(4, 6, 1, false)
+  SPEEXHIP_SLIDE_CASE(2, 8, 1, true)
+  SPEEXHIP_SLIDE_CASE(2, 8, 1, false)
+  SPEEXHIP_SLIDE_CASE(2, 12, 1, true)
+  SPEEXHIP_SLIDE_CASE(2, 12, 1, false)
 #undef SPEEXHIP_SLIDE_CASE
   return hipErrorInvalidValue;
 }

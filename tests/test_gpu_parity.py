@@ -348,11 +348,15 @@ def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
         r.close()
 
 
-def test_five_and_six_to_one_decimation_take_the_slide_kernel():
-    """48k -> 8k, 96k -> 16k (6:1) and 40k -> 8k (5:1): telephony down-sampling runs the small-ratio
-    fast kernel (42-frame register window), stereo (channel pairs) and mono (phase pairs)."""
+def test_n_to_one_decimation_takes_the_slide_kernel():
+    """48k -> 8k, 96k -> 16k (6:1), 40k -> 8k (5:1), 192k -> 24k (8:1), 96k -> 8k / 192k -> 16k (12:1):
+    integer down-sampling runs the small-ratio fast kernel, stereo (channel pairs) and mono (phase
+    pairs), with filters of up to 3072 taps."""
     for (ch, i, o, q) in [(1, 48000, 8000, 5), (2, 48000, 8000, 7), (2, 96000, 16000, 3), (1, 40000, 8000, 10),
-                          (2, 40000, 8000, 4), (3, 48000, 8000, 6)]:
+                          (2, 40000, 8000, 4), (3, 48000, 8000, 6),
+                          # 8:1 and 12:1: the long decimation filters of 96k / 192k sources (1024 - 3072 taps)
+                          (2, 192000, 24000, 7), (1, 96000, 12000, 10), (2, 96000, 8000, 5), (1, 192000, 16000, 10),
+                          (4, 192000, 16000, 3)]:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
         assert r.info()["fast_path"] == 3, (ch, i, o, q)
