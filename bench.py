@@ -2,21 +2,38 @@
 """bench.py -- throughput of the resampler hot path on N MI355X GPUs of one node.
 
 A "step" is one pass of the hot path over one batch of synthetic input: every stream owned by
-a rank resamples its next chunk (default: BASELINE.json configs[1] -- 44100->48000 Hz, 2 ch
-int16, q=7, one 2^20-frame chunk per stream per step, ONE stream per GPU).  Inputs and outputs
-are resident in HBM when the timed region starts; the streams are stateful (each step continues
-the previous one, as processChunk calls do).  One process per GPU; no data-path collective
-(streams are independent): torch.distributed (RCCL) only carries the barrier, the MAX of the
-elapsed times and a checksum/sample-count SUM.
+a rank resamples its next chunk.  Default workload = BASELINE.json configs[1]: 44100->48000 Hz,
+2 ch int16, q=7, one 2^20-frame chunk per stream per step, ONE stream per GPU (weak scaling:
+the per-GPU workload stays fixed as N grows).  `--total-streams T` is BASELINE.json configs[4]:
+T independent streams in the whole job, stream s on rank s % N (strong scaling; T = 256 gives
+32 streams per GPU at N = 8).  Inputs and outputs are resident in HBM when the timed region
+starts; the streams are stateful (each step continues the previous one, as processChunk calls
+do).  One process per GPU; no data-path collective (streams are independent): torch.distributed
+(RCCL) only carries the barrier, the MAX of the elapsed times and a checksum/sample-count SUM.
+
+Launch: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the
+driver's form; WORLD_SIZE must equal N), or plainly as `python bench.py --gpus N`: with no
+WORLD_SIZE in the environment and N > 1 this process starts N children itself, one per GPU,
+BEFORE anything touches a GPU, relays rank 0's line and exits with their status.
+
+Timing: W untimed warmup steps, then R repetitions (default 5) of EXACTLY K steps, each
+repetition bracketed by a barrier + torch.cuda.synchronize() on both sides, MAX over ranks per
+repetition; `ms_per_step`/`value` are the MEDIAN repetition (min and max are in the line too):
+K steps of a 13 us kernel are over in a fraction of a millisecond, and one such region swings
+by 10 % with launch-train edge effects.
 
 Prints ONE JSON line on rank 0 (contract in the task description): value = whole-job input
-Msamples/s, plus "roofline" (algorithmic HBM bytes per launch / measured launch time vs the
-8 TB/s HBM peak) and, at N=1, "cpu_baseline" (the reference's own C timed on the host cores).
+Msamples/s, plus "roofline" (algorithmic HBM bytes per launch / launch time measured with HIP
+events on the launch stream, vs the 8 TB/s HBM peak), "parity" (first chunk of up to four
+streams checked against the CPU oracle) and, at N=1, "cpu_baseline" (the reference's own C
+timed on the host cores).
 """
 import argparse
 import json
 import math
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -34,6 +51,7 @@ CONFIG_LABEL = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "c
                 "f3": "SURVEY F3 (direct_single)"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
+PMC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
 def wrapper_capacity(chunk_bytes, in_rate, out_rate, channels):
@@ -50,28 +68,67 @@ def lcg_pcm(n, seed):
     return (s >> np.uint32(16)).astype(np.uint16).view(np.int16)
 
 
-def cpu_baseline(cfg, frames, gpu_first_chunk=None, budget_s=12.0, max_chunks=32):
-    """The CPU leg (the ONLY place bench.py touches oracle/): time the CPU path on this box's host
-    cores on a bounded sample of the same workload -- oracle/_ref (the reference's own C, kind
-    "reference") when present, else the restatement ("port") -- and, since its warm-up chunk is
-    the very chunk the GPU processed first, use it as the checker of that chunk (parity)."""
-    import numpy as np
+def shard_streams(total_streams, world, rank):
+    """Global stream ids owned by `rank` (the rule of dist_util.shard_streams, restated here so
+    that the launcher half of this file needs no torch import)."""
+    return [s for s in range(total_streams) if s % world == rank]
+
+
+def _oracle_engine(cfg):
+    """The CPU checker (the ONLY place bench.py touches oracle/): oracle/_ref -- the reference's
+    own C, kind "reference" -- when it is built, else the restatement ("port")."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     ch, fi, fo, q = cfg
     kind = "reference" if orc.have_reference() else "port"
-    eng = (orc.Reference if kind == "reference" else orc.Oracle)(ch, fi, fo, q)
+    return (orc.Reference if kind == "reference" else orc.Oracle)(ch, fi, fo, q), kind
+
+
+def parity_block(cfg, frames, first_chunks, float_io):
+    """First chunk of each sampled stream against the CPU oracle: +-1 LSB (int16) and equal
+    counters; the float entry point within 4e-6 of full scale.  first_chunks: list of
+    (global stream id, output array, consumed, produced)."""
+    import numpy as np
+    ch, fi, fo, q = cfg
+    worst, mism, n, counters, checked = 0.0, 0, 0, True, []
+    for sid, got, used, made in first_chunks:
+        eng, kind = _oracle_engine(cfg)
+        x = lcg_pcm(frames * ch, 12345 + sid).reshape(frames, ch)
+        cap = wrapper_capacity(x.size * 2, fi, fo, ch)
+        if float_io:
+            want, want_used = eng.process_float(x.astype(np.float32) / np.float32(32768.0), cap)
+            diff = np.abs(got.astype(np.float64) - want.astype(np.float64)) if got.shape == want.shape else None
+        else:
+            want, want_used = eng.process(x, cap)
+            diff = np.abs(got.astype(np.int32) - want.astype(np.int32)) if got.shape == want.shape else None
+        counters = counters and used == want_used and made == want.shape[0] and diff is not None
+        if diff is not None:
+            worst = max(worst, float(diff.max()))
+            mism += int((diff != 0).sum())
+            n += diff.size
+        checked.append(sid)
+    blk = {"checker": "oracle/_ref (reference's native C)" if kind == "reference" else "oracle port",
+           "streams_checked": checked, "checked_frames_per_stream": int(first_chunks[0][3]),
+           "counters_equal": bool(counters)}
+    if float_io:
+        blk["max_abs_diff"] = worst
+        blk["tolerance"] = 4e-6
+        ok = counters and worst <= 4e-6
+    else:
+        blk["max_abs_diff_lsb"] = int(worst)
+        blk["mismatch_rate"] = mism / max(n, 1)
+        blk["tolerance_lsb"] = 1
+        ok = counters and worst <= 1
+    return blk, ok
+
+
+def cpu_baseline(cfg, frames, budget_s=12.0, max_chunks=32):
+    """Time the CPU path on this box's host cores on a bounded sample of the same workload."""
+    eng, kind = _oracle_engine(cfg)
+    ch, fi, fo, q = cfg
     x = lcg_pcm(frames * ch, 12345).reshape(frames, ch)
     cap = wrapper_capacity(x.size * 2, fi, fo, ch)
-    want, want_used = eng.process(x, cap)  # warm-up chunk == the GPU's first chunk
-    parity = None
-    if gpu_first_chunk is not None:
-        got, used, made = gpu_first_chunk
-        diff = np.abs(got.astype(np.int32) - want.astype(np.int32)) if got.shape == want.shape else None
-        parity = {"checked_frames": int(want.shape[0]),
-                  "max_abs_diff_lsb": int(diff.max()) if diff is not None else -1,
-                  "mismatch_rate": float((diff != 0).mean()) if diff is not None else 1.0,
-                  "counters_equal": bool(used == want_used and made == want.shape[0])}
+    eng.process(x, cap)  # warm-up chunk
     t0 = time.perf_counter()
     chunks = 0
     while chunks < max_chunks and (time.perf_counter() - t0) < budget_s:
@@ -80,18 +137,27 @@ def cpu_baseline(cfg, frames, gpu_first_chunk=None, budget_s=12.0, max_chunks=32
     dt = time.perf_counter() - t0
     return {"value": round(chunks * frames * ch / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
             "kind": kind,
+            "what": ("the reference's deps/speex/resample.c compiled natively (gcc -O2, oracle/_ref), NOT the "
+                     "shipped WASM build (SURVEY measured the WASM 4x slower)") if kind == "reference"
+            else "oracle/speex_oracle.c (bit-exact C restatement)",
             "sample": "%d chunks of %d frames x %d ch, same rates/quality, 1 thread, %.1f s" % (
-                chunks, frames, ch, dt)}, parity
+                chunks, frames, ch, dt)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the K-step timed region; the median is reported")
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--custom", default=None, help="channels,in_rate,out_rate,quality (overrides --config)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "1")), help="independent streams per GPU (configs[4] uses 32)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "1")),
+                    help="independent streams PER GPU (weak scaling)")
+    ap.add_argument("--total-streams", type=int, default=int(os.environ.get("BENCH_TOTAL_STREAMS", "0")),
+                    help="independent streams in the WHOLE JOB, stream s on rank s %% N (strong scaling; "
+                         "256 = BASELINE configs[4]); overrides --streams")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
     ap.add_argument("--io", default="int16", choices=["int16", "float"],
@@ -102,15 +168,66 @@ def main():
                          "launch train run 20-30 %% slower), and W steps of a 15 us kernel are over before that")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start N ranks, one per
+    GPU, as CHILD processes (this process has not touched a GPU and never will), relay rank 0's
+    JSON line, fail if any rank fails."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, WORLD_SIZE=str(args.gpus), RANK=str(r), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # the others would wait for it at the rendezvous forever
+                    q.terminate()
+        time.sleep(0.05)
+    out = procs[0].stdout.read().decode()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank exited with status %d (%d ranks requested)\n" % (rc, args.gpus))
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     import numpy as np
     import torch
     import dist_util
     import speexhip
 
+    world, rank, local = dist_util.env_world()
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, "
+                 "or without WORLD_SIZE (bench.py then starts the ranks itself)" % (args.gpus, world, args.gpus))
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev:
+        sys.exit("bench.py: rank %d needs GPU %d but this node shows %d GPU(s)" % (rank, local, n_dev))
     world, rank, local = dist_util.init("nccl")
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -120,7 +237,14 @@ def main():
         cfg = tuple(int(v) for v in args.custom.split(","))
         CONFIG_LABEL[args.config] = "custom"
     ch, fi, fo, q = cfg
-    S, F = args.streams, args.frames
+    F = args.frames
+    strong = args.total_streams > 0
+    mine = shard_streams(args.total_streams, world, rank) if strong else [rank * args.streams + s
+                                                                         for s in range(args.streams)]
+    S = len(mine)
+    if S == 0:
+        sys.exit("bench.py: rank %d owns no stream (--total-streams %d over %d ranks)" % (rank, args.total_streams, world))
+    streams_total = args.total_streams if strong else args.streams * world
     cap = wrapper_capacity(F * ch * 2, fi, fo, ch)
     mode = speexhip.MODE_EXACT if args.mode == "exact" else speexhip.MODE_FAST
     batch = speexhip.Batch(S, ch, fi, fo, q, mode=mode)
@@ -133,7 +257,7 @@ def main():
     es = 4 if fio else 2
     in_bytes, out_bytes = S * F * ch * es, S * cap * ch * es
     nbuf = max(2, min(256, int(math.ceil(600e6 / (in_bytes + out_bytes)))))
-    base = np.stack([lcg_pcm(F * ch, 12345 + rank * S + s).reshape(F, ch) for s in range(S)])
+    base = np.stack([lcg_pcm(F * ch, 12345 + sid).reshape(F, ch) for sid in mine])
     d_base = torch.from_numpy(base).to(dev)
     if fio:
         d_base = d_base.to(torch.float32) / 32768.0
@@ -147,10 +271,13 @@ def main():
         return batch.process_device(d_in[b].data_ptr(), F * ch, F, d_out[b].data_ptr(), cap * ch, cap, sp,
                                     float_io=fio)
 
-    # first chunk (outside the timed region); kept for the CPU leg's parity check
+    # first chunk (outside the timed region); up to four streams of rank 0 are kept for the checker
     used, made = step(0)
     torch.cuda.synchronize()
-    first_chunk = (d_out[0][0, : made[0]].cpu().numpy(), used[0], made[0]) if rank == 0 and not fio else None
+    first_chunks = []
+    if rank == 0 and not args.no_parity:
+        for j in sorted(set([0, S // 3, (2 * S) // 3, S - 1])):
+            first_chunks.append((mine[j], d_out[0][j, : made[j]].cpu().numpy(), used[j], made[j]))
     # checksum of the first step's outputs (all streams of this rank): deterministic, unlike the
     # buffers after a time-based preheat
     first_sum = int((d_out[0] * (32768.0 if fio else 1)).to(torch.int64).sum().item())
@@ -165,74 +292,108 @@ def main():
     for i in range(args.warmup):
         step(i + 1)
     torch.cuda.synchronize()
-    dist_util.barrier(dev)
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # R repetitions of exactly K steps; each is bracketed by barrier + synchronize on both sides
+    reps = max(1, args.reps)
+    wall, gpu = [], []
     consumed = produced = 0
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.steps):
-        u, m = step(args.warmup + 1 + i)
-        consumed += sum(u)
-        produced += sum(m)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dist_util.barrier(dev)
-    gpu_ms = ev0.elapsed_time(ev1)
+    it = args.warmup + 1
+    for r in range(reps):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist_util.barrier(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for i in range(args.steps):
+            u, m = step(it)
+            it += 1
+            if r == 0:
+                consumed += sum(u)
+                produced += sum(m)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        dist_util.barrier(dev)
+        wall.append(dist_util.reduce_scalar(elapsed, "max", dev))
+        gpu.append(ev0.elapsed_time(ev1))
 
-    elapsed_max = dist_util.reduce_scalar(elapsed, "max", dev)
     total_in_samples = dist_util.reduce_int(args.steps * S * F * ch, dev)
     total_out_samples = dist_util.reduce_int(produced * ch, dev)
     checksum = dist_util.reduce_int(first_sum, dev)
 
+    rc = 0
     if rank == 0:
-        value = total_in_samples / elapsed_max / 1e6
+        elapsed_med = statistics.median(wall)
+        value = total_in_samples / elapsed_med / 1e6
         # dominant kernel = the one launch per step; algorithmic bytes per launch:
-        # 2*ch*consumed read + 2*ch*produced written, per stream, per call
-        launch_ms = gpu_ms / args.steps
+        # 2*ch*consumed read + 2*ch*produced written, per stream, per call (rank 0's launch)
+        launch_ms = statistics.median(gpu) / args.steps
         alg_bytes = (consumed + produced) * ch * es / args.steps
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         flops = 2.0 * info["filt_len"] * produced * ch / args.steps  # minimal form, 2*N per output
         tfl = flops / (launch_ms * 1e-3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("%s_s%d_%s" % (args.config, S, args.mode))
+                    traffic = json.load(f).get("%s_s%d_%s%s" % (args.config, S, args.mode, "_float" if fio else ""))
             except Exception:
                 traffic = None
+        ms_per_step = elapsed_med / args.steps * 1e3
+        assert launch_ms <= ms_per_step * 1.001, (launch_ms, ms_per_step)  # the launches fit in the wall time
         line = {
             "metric": "input Msamples/s int16 %d->%d q=%d %dch (whole job)" % (fi, fo, q, ch),
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "%s per GPU x %d stream(s): %d->%d Hz, %dch int16, "
-                                   "q=%d, %d-frame chunk per stream per step" % (CONFIG_LABEL[args.config], S, fi,
-                                                                                 fo, ch, q, F),
-                       "streams_per_gpu": S, "frames_per_chunk": F, "mode": args.mode, "io": args.io,
-                       "preheat_ms": args.preheat_ms,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s%s: %d->%d Hz, %dch %s, q=%d, %d-frame chunk per stream per step; %s" % (
+                           CONFIG_LABEL[args.config],
+                           " as BASELINE configs[4] (sharded streams)" if strong and args.config == "cfg2" else "",
+                           fi, fo, ch, args.io, q, F,
+                           ("%d streams in the job, stream s on rank s %% %d" % (streams_total, world)) if strong
+                           else ("%d stream(s) per GPU" % args.streams)),
+                       "streams_total": streams_total, "streams_per_gpu": S, "frames_per_chunk": F,
+                       "mode": args.mode, "io": args.io, "preheat_ms": args.preheat_ms,
                        "kernel": speexhip.KERNEL_NAMES[info["kernel"]], "fast_path": info["fast_path"],
-                       "filt_len": info["filt_len"], "parallelism": "streams sharded, %d rank(s)" % world},
-            "output_msamples_per_s": round(total_out_samples / elapsed_max / 1e6, 1),
+                       "filt_len": info["filt_len"],
+                       "accumulate": "f32 FMA chain (reference: %s)" % (
+                           "f64 sums of f32 products" if info["kernel"] in (1, 3) else "f32") if args.mode == "fast"
+                       else "as the reference",
+                       "parallelism": "independent streams sharded over %d rank(s), no data-path collective" % world},
+            "timing": {"reps": reps, "ms_per_step_median": round(ms_per_step, 5),
+                       "ms_per_step_min": round(min(wall) / args.steps * 1e3, 5),
+                       "ms_per_step_max": round(max(wall) / args.steps * 1e3, 5),
+                       "region": "each repetition = exactly `steps` steps between barrier+synchronize pairs, "
+                                 "MAX over ranks; value uses the median repetition"},
+            "output_msamples_per_s": round(total_out_samples / elapsed_med / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "launch_us": round(launch_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "traffic_source": ("%s (static: rocprofv3 PMC passes of this workload, tools/gpu_profile.sh; "
+                                            "not measured in this run)" % PMC_FILE) if traffic is not None else None,
+                         "launch_us": round(launch_ms * 1e3, 3),
+                         "launch_us_min": round(min(gpu) / args.steps * 1e3, 3),
+                         "launch_us_max": round(max(gpu) / args.steps * 1e3, 3),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "read_only_frac": round(consumed * ch * es / args.steps / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "note": "fp32 vector-ALU bound, not HBM bound (SURVEY F4); see valu"},
             "valu": {"achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tfl / VALU_PEAK_TFLOPS, 4), "flops_per_launch": int(flops)},
             "checksum": checksum,
         }
+        if first_chunks:
+            line["parity"], ok = parity_block(cfg, F, first_chunks, fio)
+            if not ok:
+                rc = 3
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], parity = cpu_baseline(cfg, F, None if args.no_parity else first_chunk)
-            if parity is not None:
-                line["parity"] = parity
-                assert parity["counters_equal"] and 0 <= parity["max_abs_diff_lsb"] <= 1, parity
+            line["cpu_baseline"] = cpu_baseline(cfg, F)
         print(json.dumps(line), flush=True)
+        if rc:
+            sys.stderr.write("bench.py: PARITY FAILED: %s\n" % json.dumps(line["parity"]))
     batch.close()
     dist_util.finish()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

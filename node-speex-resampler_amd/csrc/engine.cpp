@@ -19,6 +19,32 @@ bool hip_failed(hipError_t e, const char *what) {
     if (hip_failed((expr), #expr)) return SPEEXHIP_ERR_DEVICE;   \
   } while (0)
 
+// Every entry point runs on the batch's own device whatever the calling thread's current one is,
+// and leaves the thread's current device as it found it.
+class DeviceScope {
+ public:
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = device;
+    if (prev_ != device) err_ = hipSetDevice(device);
+  }
+  ~DeviceScope() {
+    if (prev_ != device_now()) (void)hipSetDevice(prev_);
+  }
+  hipError_t error() const { return err_; }
+
+ private:
+  static int device_now() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+  }
+  int prev_ = 0;
+  hipError_t err_ = hipSuccess;
+};
+#define ON_DEVICE()                 \
+  DeviceScope device_scope(device_); \
+  HIP_TRY(device_scope.error())
+
 const size_t kLdsBudget = 150 * 1024;  // of the CU's 160 KiB
 const size_t kDirectCopyBytes = 256 * 1024;  // host buffers at least this big skip the pinned bounce buffer
 }  // namespace
@@ -132,7 +158,7 @@ int Batch::install_filter(const std::vector<float> &hist, uint32_t hist_frames_c
 }
 
 int Batch::fetch_history(std::vector<float> *host) {
-  HIP_TRY(hipSetDevice(device_));
+  ON_DEVICE();
   HIP_TRY(hipDeviceSynchronize());  // every enqueued call has left its history
   host->assign(hist_elems_ * n_streams_, 0.f);
   if (!host->empty())
@@ -143,6 +169,7 @@ int Batch::fetch_history(std::vector<float> *host) {
 // Switch every stream to the filter `next` (already designed): the tail of update_filter(),
 // resample.c:703-782, per stream, on the host -- this is rare control-plane work.
 int Batch::adopt_filter(const FilterSpec &next) {
+  ON_DEVICE();
   std::vector<float> old;
   int rc = fetch_history(&old);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
@@ -211,6 +238,7 @@ int Batch::skip_zeros() {  // resample.c:1200-1206
 }
 
 int Batch::reset_mem() {  // resample.c:1208-1220
+  ON_DEVICE();
   std::vector<float> h;
   int rc = fetch_history(&h);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
@@ -233,6 +261,8 @@ int Batch::reset_mem() {  // resample.c:1208-1220
 }
 
 Batch::~Batch() {
+  DeviceScope device_scope(device_);
+  if (order_ev_) (void)hipEventDestroy(order_ev_);
   if (own_stream_) (void)hipStreamSynchronize(own_stream_);
   (void)hipFree(d_table_);
   (void)hipFree(d_hist_[0]);
@@ -288,6 +318,7 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
 
 int Batch::history(uint32_t s, float *dst) {
   if (s >= n_streams_) return SPEEXHIP_ERR_INVALID_ARG;
+  ON_DEVICE();
   HIP_TRY(hipDeviceSynchronize());
   const size_t n = static_cast<size_t>(filter_.taps - 1 + pos_[s].magic) * channels_;
   if (n)
@@ -297,6 +328,7 @@ int Batch::history(uint32_t s, float *dst) {
 
 int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len, void *d_out,
                           uint64_t out_stride, uint32_t *out_len, bool float_io, hipStream_t stream) {
+  ON_DEVICE();
   // the int16 entry point emits at most 1024 outputs per 160-frame block (its stack buffer,
   // resample.c:982-991); the float entry point has no such cap (resample.c:943)
   EntryRules rules;
@@ -363,6 +395,16 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
   }
 
   if (any_work) {
+    // Calls on one batch are ordered (each reads the history the previous one left and the
+    // ping-pong buffers alternate): a call enqueued on another stream than the previous one
+    // waits for it on the device.
+    if (have_last_stream_ && stream != last_stream_) {
+      if (order_ev_ == nullptr) HIP_TRY(hipEventCreateWithFlags(&order_ev_, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(order_ev_, last_stream_));
+      HIP_TRY(hipStreamWaitEvent(stream, order_ev_, 0));
+    }
+    last_stream_ = stream;
+    have_last_stream_ = true;
     const StreamDesc *d_descs = nullptr;
     if (!packed) {
       StreamDesc *dst = d_ring_ + static_cast<size_t>(slot) * n_streams_;
@@ -419,7 +461,7 @@ int Batch::ensure_stage(size_t in_bytes, size_t out_bytes) {
 
 int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io) {
   if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
-  HIP_TRY(hipSetDevice(device_));
+  ON_DEVICE();
   const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
   const uint32_t frames = *in_len;
   // only as many output frames as this call can produce need a device buffer
@@ -465,7 +507,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
 int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_t *in_len, void *out,
                                uint32_t *out_len, bool float_io) {
   if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
-  HIP_TRY(hipSetDevice(device_));
+  ON_DEVICE();
   const size_t fb = (float_io ? sizeof(float) : sizeof(int16_t)) * channels_;  // bytes per frame
   EntryRules rules;
   rules.block_in = block_in();

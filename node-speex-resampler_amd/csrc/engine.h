@@ -100,6 +100,11 @@ class Batch {
   bool ring_busy_[kRing] = {};
   int ring_next_ = 0;
 
+  // stream of the previous launch (calls on different streams are chained with an event)
+  hipStream_t last_stream_ = nullptr;
+  bool have_last_stream_ = false;
+  hipEvent_t order_ev_ = nullptr;
+
   // host-buffer path (single stream)
   hipStream_t own_stream_ = nullptr;
   char *d_stage_in_ = nullptr, *d_stage_out_ = nullptr;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <vector>
@@ -10,6 +11,34 @@
 #include "filter_design.h"
 
 namespace speexhip {
+
+// Kernel attributes (the opt-in for more than 64 KiB of dynamic LDS) are per DEVICE: set them the
+// first time a kernel is launched on each device of the process.  `seen` = one bit per device id;
+// two threads racing on a first use both set the (idempotent) attribute before either launches.
+template <typename K>
+inline void opt_in_lds_on_this_device(K kern, std::atomic<uint64_t> &seen) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (seen.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  seen.fetch_or(bit, std::memory_order_release);
+}
+
+// compute units of the calling thread's current device (cached per device id)
+inline uint32_t device_compute_units() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int n = cached[dev & 63].load(std::memory_order_relaxed);
+  if (n == 0) {
+    n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cached[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return static_cast<uint32_t>(n);
+}
 
 // ---- bit-exact kernels (kernels_exact.hip) -------------------------------------------------
 struct ExactGeometry {

@@ -219,17 +219,13 @@ hipError_t launch_k(const ExactParams &p, const StreamDesc *d_descs, const DescP
   DescPack empty;
   if (pack != nullptr) {
     auto kern = resample_exact<KIND, CT, STAGED, true, T>;
-    // once per kernel (thread-safe static init): allow the full 160 KiB of dynamic LDS
-    static const hipError_t lds_opt_in = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)lds_opt_in;
+    static std::atomic<uint64_t> seen{0};  // allow the full 160 KiB of dynamic LDS, once per device
+    opt_in_lds_on_this_device(kern, seen);
     hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, nullptr, *pack);
   } else {
     auto kern = resample_exact<KIND, CT, STAGED, false, T>;
-    // once per kernel (thread-safe static init): allow the full 160 KiB of dynamic LDS
-    static const hipError_t lds_opt_in = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)lds_opt_in;
+    static std::atomic<uint64_t> seen{0};
+    opt_in_lds_on_this_device(kern, seen);
     memset(&empty, 0, sizeof(empty));
     hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, d_descs, empty);
   }

@@ -424,23 +424,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
                                         blockIdx.z, gridDim.z);
 }
 
-template <typename K>
-void opt_in_lds(K kern) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
-}
-
 template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
-  static const bool once = [] {  // thread-safe static init: calls may come from several host threads
-    opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, true, T>);
-    opt_in_lds(resample_period<R, CT, ONE_GROUP, PADDED, false, T>);
-    return true;
-  }();
-  (void)once;
+  static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
+  if (pack != nullptr)
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T>, seen_packed);
+  else
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T>, seen_ring);
   if (pack != nullptr)
     hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, nullptr, *pack);
@@ -618,12 +611,7 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
     max_periods = std::max<uint32_t>(max_periods, static_cast<uint32_t>((k_end + f.den - 1) / f.den));
   }
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
-  static const int device_cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n;
-  }();
-  const uint32_t resident = 2 * static_cast<uint32_t>(device_cus);  // two workgroups fit per CU
+  const uint32_t resident = 2 * device_compute_units();  // two workgroups fit per CU
   // One workgroup per (tile, stream); the hardware dispatcher refills a CU the moment a workgroup
   // retires.  (A persistent walk of the tile list with the next tile's window prefetched into
   // registers lived here until round 1's last measurements at sustained clocks: 7 % slower at 32

@@ -218,14 +218,11 @@ hipError_t launch_up(const SlideParams &p, const StreamDesc *d_descs, const Desc
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
-  static const bool once = [] {  // thread-safe static init: calls may come from several host threads
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, true, T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(resample_slide<P, NUM, NP, PAIR_CH, false, T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return true;
-  }();
-  (void)once;
+  static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
+  if (pack != nullptr)
+    opt_in_lds_on_this_device(resample_slide<P, NUM, NP, PAIR_CH, true, T>, seen_packed);
+  else
+    opt_in_lds_on_this_device(resample_slide<P, NUM, NP, PAIR_CH, false, T>, seen_ring);
   if (pack != nullptr)
     hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, true, T>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, nullptr, *pack);

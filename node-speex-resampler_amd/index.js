@@ -33,6 +33,17 @@ class SpeexResampler {
     this.quality = quality;
     this._resamplerPtr = undefined; // native handle (the reference keeps a WASM pointer here)
     this._outBufferSize = -1;       // bytes; grow-only, drives the capacity rule below
+    this._inFlight = 0;             // processChunkAsync calls not yet settled (extension)
+  }
+
+  // The reference's calls are synchronous and a state must not be used concurrently
+  // (src/index.ts:50-116).  While a processChunkAsync call of this instance is running on a pool
+  // thread, a synchronous call would interleave with it in an order the caller cannot know, so it
+  // is refused; await the pending promise(s) first.
+  _refuseWhileAsyncPending(what) {
+    if (this._inFlight > 0) {
+      throw new Error(what + ' called while a processChunkAsync call of this instance is pending; await it first');
+    }
   }
 
   /**
@@ -42,6 +53,7 @@ class SpeexResampler {
     if (!speexModule) {
       throw new Error('You need to wait for SpeexResampler.initPromise before calling this method');
     }
+    this._refuseWhileAsyncPending('processChunk');
     // reference src/index.ts:55-57 (channels === 0 gives NaN !== 0 and lands here too)
     if (chunk.length % (this.channels * Uint16Array.BYTES_PER_ELEMENT) !== 0) {
       throw new Error('Chunk length should be a multiple of channels * 2 bytes');
@@ -103,6 +115,7 @@ class SpeexResampler {
    * (the capacity rule is applied per original chunk).
    */
   processChunks(chunks) {
+    this._refuseWhileAsyncPending('processChunks');
     const inFrames = [];
     const caps = [];
     for (const chunk of chunks) {
@@ -126,8 +139,10 @@ class SpeexResampler {
       return Promise.reject(e);
     }
     const run = () => speexModule.processAsync(this._resamplerPtr, chunk, args[0], args[1]);
+    this._inFlight++;
+    const settle = () => { this._inFlight--; };
     const p = (this._pending || Promise.resolve()).then(run, run);
-    this._pending = p.catch(() => {});
+    this._pending = p.then(settle, settle);
     return p;
   }
 
@@ -137,26 +152,35 @@ class SpeexResampler {
    * state as processChunk; same grow-only capacity rule (in bytes of float32).
    */
   processChunkFloat(chunk) {
+    this._refuseWhileAsyncPending('processChunkFloat');
     const [f, cap] = this._prepare(chunk, Float32Array.BYTES_PER_ELEMENT);
     return speexModule.processFloat(this._resamplerPtr, chunk, f, cap);
   }
 
   /** Mid-stream control (SURVEY 8f row N3; speex_resampler_set_rate / set_quality / ...). */
   setRate(inRate, outRate) {
+    this._refuseWhileAsyncPending('setRate');
     if (this._resamplerPtr) speexModule.setRate(this._resamplerPtr, inRate >>> 0, outRate >>> 0);
     this.inRate = inRate;
     this.outRate = outRate;
   }
 
   setQuality(quality) {
+    this._refuseWhileAsyncPending('setQuality');
     if (this._resamplerPtr) speexModule.setQuality(this._resamplerPtr, quality | 0);
     this.quality = quality;
   }
 
   /** Start half a filter in, so the stream does not begin with the filter's ramp-up. */
-  skipZeros() { speexModule.skipZeros(this._ensureNative()); }
+  skipZeros() {
+    this._refuseWhileAsyncPending('skipZeros');
+    speexModule.skipZeros(this._ensureNative());
+  }
 
-  resetMem() { speexModule.resetMem(this._ensureNative()); }
+  resetMem() {
+    this._refuseWhileAsyncPending('resetMem');
+    speexModule.resetMem(this._ensureNative());
+  }
 
   /** Frames of delay the filter adds, counted at the input rate / at the output rate. */
   get inputLatency() { return speexModule.getLatency(this._ensureNative())[0]; }
@@ -168,6 +192,7 @@ class SpeexResampler {
    * and returns what comes out -- the response to the last real input frames.
    */
   flush() {
+    this._refuseWhileAsyncPending('flush');
     const ptr = this._ensureNative();
     const frames = speexModule.getLatency(ptr)[0];
     const cap = Math.ceil(frames * this.outRate / this.inRate) + 1;
@@ -176,6 +201,7 @@ class SpeexResampler {
 
   /** Release the GPU state now (otherwise it goes with garbage collection). */
   destroy() {
+    this._refuseWhileAsyncPending('destroy');
     if (this._resamplerPtr) speexModule.destroy(this._resamplerPtr);
     this._resamplerPtr = undefined;
     this._outBufferSize = -1;

@@ -53,15 +53,33 @@ static Handle *unwrap_handle(napi_env env, napi_value v) {
   return (Handle *)p;
 }
 
-static SpeexHipResamplerState *unwrap(napi_env env, napi_value v) {
+/* Every entry point that touches a state holds the handle's lock from before it reads anything of
+ * the state until it is done with it: a processAsync job on a libuv pool thread may be running the
+ * same state, and everything below -- counters (peek), filter data (setRate frees and rebuilds
+ * device tables), even the st pointer (destroy) -- changes under such a job.  Returns the state
+ * with the lock HELD, or NULL (exception pending, lock released). */
+static SpeexHipResamplerState *lock_state(napi_env env, napi_value v, Handle **hp) {
   Handle *h = unwrap_handle(env, v);
   if (h == NULL) return NULL;
+  pthread_mutex_lock(&h->lock);
   if (h->st == NULL) {
+    pthread_mutex_unlock(&h->lock);
     napi_throw_error(env, NULL, speexhip_resampler_strerror(SPEEXHIP_ERR_BAD_STATE));
     return NULL;
   }
+  *hp = h;
   return h->st;
 }
+#define UNLOCK(h) pthread_mutex_unlock(&(h)->lock)
+/* NAPI_OK for use while the lock is held */
+#define NAPI_OK_LOCKED(h, call)                                     \
+  do {                                                              \
+    if ((call) != napi_ok) {                                        \
+      UNLOCK(h);                                                    \
+      napi_throw_error(env, NULL, "speexhip N-API failure: " #call); \
+      return NULL;                                                  \
+    }                                                               \
+  } while (0)
 
 /* init(channels, inRate, outRate, quality) -> handle; throws Error(strerror(code)) like
  * src/index.ts:63-65 */
@@ -125,8 +143,6 @@ static napi_value process_common(napi_env env, napi_callback_info info, size_t s
   size_t argc = 4;
   napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  Handle *h = unwrap_handle(env, argv[0]);
-  if (h == NULL || unwrap(env, argv[0]) == NULL) return NULL;
   void *in_data = NULL;
   size_t in_bytes = 0;
   if (!buffer_or_null(env, argv[1], &in_data, &in_bytes)) {
@@ -136,31 +152,35 @@ static napi_value process_common(napi_env env, napi_callback_info info, size_t s
   uint32_t in_len = 0, out_len = 0;
   NAPI_OK(napi_get_value_uint32(env, argv[2], &in_len));
   NAPI_OK(napi_get_value_uint32(env, argv[3], &out_len));
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
+  if (st == NULL) return NULL;
   SpeexHipInfo si;
-  speexhip_resampler_get_info(h->st, &si);
+  speexhip_resampler_get_info(st, &si);
   const size_t frame_bytes = (size_t)si.nb_channels * sample_bytes;
   if (in_data != NULL && (size_t)in_len * frame_bytes > in_bytes) {
+    UNLOCK(h);
     napi_throw_range_error(env, NULL, "input frame count exceeds the chunk");
     return NULL;
   }
   /* the counters are known before any GPU work: size the result exactly and let the library write
-   * straight into it (one copy instead of three) */
+   * straight into it (one copy instead of three).  peek and the call see the same state: the lock
+   * is held from before the peek until the call has returned. */
   uint32_t will_use = 0, will_make = 0;
-  speexhip_resampler_peek(h->st, in_len, out_len, sample_bytes == 4, &will_use, &will_make);
+  speexhip_resampler_peek(st, in_len, out_len, sample_bytes == 4, &will_use, &will_make);
   napi_value out;
   void *dst = NULL;
-  NAPI_OK(napi_create_buffer(env, (size_t)will_make * frame_bytes, &dst, &out));
+  NAPI_OK_LOCKED(h, napi_create_buffer(env, (size_t)will_make * frame_bytes, &dst, &out));
   uint64_t nowhere = 0;
   if (dst == NULL) dst = &nowhere; /* empty Buffer: nothing will be written, but NULL means "no buffer" */
   /* out_len stays the caller's capacity (a smaller one could end the call's block loop early and
    * leave trailing input unconsumed); the library writes exactly will_make frames */
-  pthread_mutex_lock(&h->lock);
   int rc = sample_bytes == 2
-               ? speexhip_resampler_process_interleaved_int(h->st, (const int16_t *)in_data, &in_len,
+               ? speexhip_resampler_process_interleaved_int(st, (const int16_t *)in_data, &in_len,
                                                             (int16_t *)dst, &out_len)
-               : speexhip_resampler_process_interleaved_float(h->st, (const float *)in_data, &in_len,
+               : speexhip_resampler_process_interleaved_float(st, (const float *)in_data, &in_len,
                                                               (float *)dst, &out_len);
-  pthread_mutex_unlock(&h->lock);
+  UNLOCK(h);
   if (rc != 0 || out_len != will_make) {
     napi_throw_error(env, NULL, speexhip_resampler_strerror(rc != 0 ? rc : SPEEXHIP_ERR_BAD_STATE));
     return NULL;
@@ -177,12 +197,13 @@ static napi_value ProcessChunks(napi_env env, napi_callback_info info) {
   size_t argc = 4;
   napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  Handle *h = unwrap_handle(env, argv[0]);
-  if (h == NULL || unwrap(env, argv[0]) == NULL) return NULL;
   uint32_t n = 0;
   NAPI_OK(napi_get_array_length(env, argv[1], &n));
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
+  if (st == NULL) return NULL;
   SpeexHipInfo si;
-  speexhip_resampler_get_info(h->st, &si);
+  speexhip_resampler_get_info(st, &si);
   const size_t frame_bytes = (size_t)si.nb_channels * 2;
   const int16_t **ptrs = (const int16_t **)calloc(n ? n : 1, sizeof(*ptrs));
   uint32_t *in_len = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
@@ -212,11 +233,10 @@ static napi_value ProcessChunks(napi_env env, napi_callback_info info) {
     if (tmp == NULL) fail = speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED);
   }
   if (fail == NULL) {
-    pthread_mutex_lock(&h->lock);
-    int rc = speexhip_resampler_process_chunks_int(h->st, n, ptrs, in_len, tmp, out_len);
-    pthread_mutex_unlock(&h->lock);
+    int rc = speexhip_resampler_process_chunks_int(st, n, ptrs, in_len, tmp, out_len);
     if (rc != 0) fail = speexhip_resampler_strerror(rc);
   }
+  UNLOCK(h);
   if (fail == NULL && napi_create_array_with_length(env, n, &result) == napi_ok) {
     size_t off = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -297,8 +317,6 @@ static napi_value ProcessAsync(napi_env env, napi_callback_info info) {
   size_t argc = 4;
   napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  Handle *h = unwrap_handle(env, argv[0]);
-  if (h == NULL || unwrap(env, argv[0]) == NULL) return NULL;
   void *in_data = NULL;
   size_t in_bytes = 0;
   if (!buffer_or_null(env, argv[1], &in_data, &in_bytes)) {
@@ -308,8 +326,12 @@ static napi_value ProcessAsync(napi_env env, napi_callback_info info) {
   uint32_t in_len = 0, out_len = 0;
   NAPI_OK(napi_get_value_uint32(env, argv[2], &in_len));
   NAPI_OK(napi_get_value_uint32(env, argv[3], &out_len));
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
+  if (st == NULL) return NULL;
   SpeexHipInfo si;
-  speexhip_resampler_get_info(h->st, &si);
+  speexhip_resampler_get_info(st, &si); /* only the channel count is used: it never changes */
+  UNLOCK(h);
   if (in_data != NULL && (size_t)in_len * si.nb_channels * 2 > in_bytes) {
     napi_throw_range_error(env, NULL, "input frame count exceeds the chunk");
     return NULL;
@@ -346,42 +368,54 @@ static napi_value SetRate(napi_env env, napi_callback_info info) {
   size_t argc = 5;
   napi_value argv[5];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
   if (st == NULL) return NULL;
   uint32_t v[4] = {0, 0, 0, 0};
-  for (size_t i = 1; i < argc && i < 5; i++) NAPI_OK(napi_get_value_uint32(env, argv[i], &v[i - 1]));
+  for (size_t i = 1; i < argc && i < 5; i++) NAPI_OK_LOCKED(h, napi_get_value_uint32(env, argv[i], &v[i - 1]));
   /* (handle, inRate, outRate) or (handle, ratioNum, ratioDen, inRate, outRate) */
-  return control_result(env, argc >= 5 ? speexhip_resampler_set_rate_frac(st, v[0], v[1], v[2], v[3])
-                                       : speexhip_resampler_set_rate(st, v[0], v[1]));
+  const int rc = argc >= 5 ? speexhip_resampler_set_rate_frac(st, v[0], v[1], v[2], v[3])
+                           : speexhip_resampler_set_rate(st, v[0], v[1]);
+  UNLOCK(h);
+  return control_result(env, rc);
 }
 
 static napi_value SetQuality(napi_env env, napi_callback_info info) {
   size_t argc = 2;
   napi_value argv[2];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
   if (st == NULL) return NULL;
   int32_t q = 0;
-  NAPI_OK(napi_get_value_int32(env, argv[1], &q));
-  return control_result(env, speexhip_resampler_set_quality(st, q));
+  NAPI_OK_LOCKED(h, napi_get_value_int32(env, argv[1], &q));
+  const int rc = speexhip_resampler_set_quality(st, q);
+  UNLOCK(h);
+  return control_result(env, rc);
 }
 
 static napi_value SkipZeros(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
   if (st == NULL) return NULL;
-  return control_result(env, speexhip_resampler_skip_zeros(st));
+  const int rc = speexhip_resampler_skip_zeros(st);
+  UNLOCK(h);
+  return control_result(env, rc);
 }
 
 static napi_value ResetMem(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
   if (st == NULL) return NULL;
-  return control_result(env, speexhip_resampler_reset_mem(st));
+  const int rc = speexhip_resampler_reset_mem(st);
+  UNLOCK(h);
+  return control_result(env, rc);
 }
 
 static napi_value pair_u32(napi_env env, uint32_t a, uint32_t b) {
@@ -399,31 +433,39 @@ static napi_value GetLatency(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
   if (st == NULL) return NULL;
-  return pair_u32(env, (uint32_t)speexhip_resampler_get_input_latency(st),
-                  (uint32_t)speexhip_resampler_get_output_latency(st));
+  const uint32_t in_lat = (uint32_t)speexhip_resampler_get_input_latency(st);
+  const uint32_t out_lat = (uint32_t)speexhip_resampler_get_output_latency(st);
+  UNLOCK(h);
+  return pair_u32(env, in_lat, out_lat);
 }
 
 static napi_value SetMode(napi_env env, napi_callback_info info) {
   size_t argc = 2;
   napi_value argv[2];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
   if (st == NULL) return NULL;
   int32_t mode = 0;
-  NAPI_OK(napi_get_value_int32(env, argv[1], &mode));
-  return control_result(env, speexhip_resampler_set_mode(st, mode));
+  NAPI_OK_LOCKED(h, napi_get_value_int32(env, argv[1], &mode));
+  const int rc = speexhip_resampler_set_mode(st, mode);
+  UNLOCK(h);
+  return control_result(env, rc);
 }
 
 static napi_value GetInfo(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
   if (st == NULL) return NULL;
   SpeexHipInfo si;
   speexhip_resampler_get_info(st, &si);
+  UNLOCK(h);
   napi_value obj, v;
   NAPI_OK(napi_create_object(env, &obj));
 #define PUT_U32(name)                                     \
@@ -445,10 +487,12 @@ static napi_value GetRate(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  SpeexHipResamplerState *st = unwrap(env, argv[0]);
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
   if (st == NULL) return NULL;
   uint32_t a = 0, b = 0;
   speexhip_resampler_get_rate(st, &a, &b);
+  UNLOCK(h);
   return pair_u32(env, a, b);
 }
 

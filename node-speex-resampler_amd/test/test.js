@@ -149,6 +149,52 @@ async function extensionsTest() {
   const rejected = await new SpeexResampler(2, 44100, 48000).processChunkAsync(Buffer.alloc(7)).then(() => null, (e) => e.message);
   assert(rejected === 'Chunk length should be a multiple of channels * 2 bytes', 'async length check');
 
+  // A synchronous call while an asynchronous one is pending: the class refuses it (message names
+  // the cure); the addon itself -- reached directly, as a misbehaving caller could -- serialises
+  // the two calls on the handle's lock: both return, every byte belongs to one of the two possible
+  // orders, nothing is written past a Buffer (the result Buffer is sized under the same lock that
+  // the call holds).
+  {
+    const big = lcg(1 << 18, 2, 77), small = lcg(1000, 2, 78);
+    const r = mk(1);
+    const p = r.processChunkAsync(big);
+    let refused = null;
+    try { r.processChunk(small); } catch (e) { refused = e.message; }
+    assert(refused !== null && refused.indexOf('processChunkAsync call of this instance is pending') > 0, 'sync call during async must be refused');
+    for (const f of [() => r.setRate(44100, 32000), () => r.setQuality(3), () => r.flush(), () => r.destroy()]) {
+      let m = null;
+      try { f(); } catch (e) { m = e.message; }
+      assert(m !== null && m.indexOf('pending') > 0, 'control call during async must be refused');
+    }
+    const first = await p;
+    const second = r.processChunk(small);           // accepted again once settled
+    const ref = mk(1);
+    assert(first.equals(ref.processChunk(big)) && second.equals(ref.processChunk(small)), 'order after the refusal');
+
+    for (let round = 0; round < 8; round++) {
+      const a = mk(1), order1 = mk(1), order2 = mk(1);
+      const capBig = Math.ceil(big.length * 48000 / 44100 / 4), capSmall = Math.ceil(small.length * 48000 / 44100 / 4);
+      const pa = addon.processAsync(a._resamplerPtr, big, big.length / 4, capBig);
+      const sync = addon.process(a._resamplerPtr, small, small.length / 4, capSmall);   // races the pool thread
+      addon.getInfo(a._resamplerPtr); addon.getLatency(a._resamplerPtr);
+      const asyncOut = await pa;
+      const b1 = addon.process(order1._resamplerPtr, big, big.length / 4, capBig);
+      const s1 = addon.process(order1._resamplerPtr, small, small.length / 4, capSmall);
+      const s2 = addon.process(order2._resamplerPtr, small, small.length / 4, capSmall);
+      const b2 = addon.process(order2._resamplerPtr, big, big.length / 4, capBig);
+      const asyncFirst = asyncOut.equals(b1) && sync.equals(s1), syncFirst = asyncOut.equals(b2) && sync.equals(s2);
+      assert(asyncFirst || syncFirst, `racing sync/async calls on one handle: bytes match neither order (round ${round})`);
+      const ia = addon.getInfo(a._resamplerPtr), io = addon.getInfo((asyncFirst ? order1 : order2)._resamplerPtr);
+      assert(ia.last_sample === io.last_sample && ia.samp_frac_num === io.samp_frac_num, 'racing calls: state');
+      // control call racing an async call: must not crash or corrupt (it lands before or after)
+      const pc = addon.processAsync(a._resamplerPtr, big, big.length / 4, capBig);
+      addon.setQuality(a._resamplerPtr, 3 + (round % 5));
+      assert((await pc).length > 0, 'async call racing setQuality');
+      for (const x of [a, order1, order2]) x.destroy();
+    }
+    console.log('sync/async race on one handle: serialised, bytes match one of the two orders');
+  }
+
   // N1: the Transform options leave the bytes alone
   const pcm = lcg(44100, 2, 31337);
   const parts = [];

@@ -242,37 +242,35 @@ def test_planner_and_realignment_match_the_reference_control_scripts(golden):
     assert checked == 960
 
 
-def test_committed_bench_lines_keep_the_driver_contract():
-    """profiles/r01_bench_lines.jsonl holds the JSON lines bench.py printed on the GPU box.  The default
-    one (BASELINE configs[1], one stream) must carry every key the driver's contract names, with the
-    roofline and cpu_baseline objects; the others at least metric/value/roofline.  (bench.py itself
-    needs a GPU; this keeps the evidence and the contract from drifting apart unnoticed.)"""
-    import json
-    path = os.path.join(ROOT, "profiles", "r01_bench_lines.jsonl")
-    lines = [json.loads(l) for l in open(path) if l.strip()]
-    assert len(lines) >= 6
-    default = [d for d in lines if d["config"]["streams_per_gpu"] == 1 and d["config"]["mode"] == "fast" and
-               d["config"]["io"] == "int16" and "configs[1]" in d["config"]["workload"]]
-    assert len(default) == 1
-    d = default[0]
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert key in d, key
-    assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["n_gpus"] == 1
-    assert "workload" in d["config"] and "model" not in d["config"]
-    r = d["roofline"]
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # traffic (PMC) must be at least the algorithmic bytes and not wildly above them
-    assert r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 2 * r["algorithmic_bytes_per_launch"]
-    c = d["cpu_baseline"]
-    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c)
-    assert c["kind"] == "reference" and c["cores"] == 1 and c["unit"] == "Msamples/s" and c["value"] > 0
-    assert d["parity"]["max_abs_diff_lsb"] <= 1 and d["parity"]["counters_equal"] is True
-    # value is whole-job input samples per second: consistent with ms_per_step and the chunk size
-    per_step = d["config"]["frames_per_chunk"] * 2 * d["config"]["streams_per_gpu"]
-    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
-    for other in lines:
-        assert other["value"] > 0 and 0 < other["roofline"]["frac"] < 1 and other["metric"].startswith("input Msamples/s")
+def test_bench_launcher_fails_loudly_without_the_gpus_it_was_asked_for():
+    """`python bench.py --gpus 2` with no rendezvous in the environment starts two ranks itself
+    (before anything touches a GPU).  On a box without two GPUs every rank must exit non-zero with
+    a message, the launcher must report it, and NO JSON line may appear -- never a silent 1-GPU
+    number labelled as N GPUs.  A WORLD_SIZE that contradicts --gpus is refused too."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "metric" not in r.stdout
+    assert "needs GPU" in r.stderr and "2 ranks requested" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "metric" not in r.stdout
+
+
+def test_bench_stream_sharding_matches_dist_util():
+    """bench.py restates the sharding rule for its torch-free launcher half; BASELINE configs[4]:
+    256 streams over 8 ranks = 32 each."""
+    import importlib.util
+    import dist_util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for total, world in ((256, 8), (256, 4), (256, 2), (256, 1), (5, 2), (7, 8)):
+        parts = [bench.shard_streams(total, world, r) for r in range(world)]
+        assert parts == [dist_util.shard_streams(total, world, r) for r in range(world)]
+    assert all(len(bench.shard_streams(256, 8, r)) == 32 for r in range(8))
+    a = bench.parse_args(["--gpus", "8", "--total-streams", "256"])
+    assert (a.gpus, a.total_streams, a.steps, a.reps) == (8, 256, 200, 5)

@@ -22,7 +22,7 @@ from golden_util import ROOT, drive, make_input, sha1
 pytestmark = pytest.mark.gpu
 
 TOL_LSB = 1            # north star: +-1 LSB vs the reference
-MISMATCH_RATE = 1e-2   # measured (tools/num_check.py, cfg2, 2^20 frames): 4.4e-4 (tonal input) .. 2.6e-3
+MISMATCH_RATE = 5e-3   # measured (tools/num_check.py, cfg2, 2^20 frames): 4.4e-4 (tonal input) .. 2.6e-3
                        # (full-scale white noise); up to 3.1e-3 on other ratios.  The rate is ~E|fp32
                        # re-association error| in LSB; every differing sample differs by exactly 1
 
@@ -312,6 +312,46 @@ def test_many_ragged_streams_through_the_descriptor_ring():
             want, wu = refs[s].process(xs[s][: lens[s]], cap)
             assert (used[s], made[s]) == (wu, want.shape[0])
             assert_close(out[s, : made[s]], want, "ragged s=%d call=%d" % (s, call))
+    b.close()
+
+
+def test_configs4_per_gpu_share_32_streams_at_full_size():
+    """BASELINE.json configs[4] as one GPU sees it at N = 8: 32 independent stereo streams
+    44.1k->48k q7, one 2^20-frame chunk each per call, through the batched device-pointer entry
+    (one launch, descriptors through the ring).  Two consecutive calls (the second starts from a
+    non-trivial position and a full history); six streams checked against the oracle: +-1 LSB,
+    counters, position, history; the other streams through a property (distinct inputs give
+    distinct outputs of the same length)."""
+    import torch
+    ch, i, o, q, S, frames = 2, 44100, 48000, 7, 32, 1 << 20
+    cap, _ = orc.wrapper_capacity(frames * ch * 2, i, o, ch)
+    xs = [np.stack([orc.lcg_pcm(frames * ch, 12345 + 100 * call + s).reshape(frames, ch) for s in range(S)])
+          for call in range(2)]
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    b = speexhip.Batch(S, ch, i, o, q)
+    assert b.info()["fast_path"] == 2
+    check = [0, 5, 13, 21, 30, 31]
+    refs = {s: orc.Oracle(ch, i, o, q) for s in check}
+    for call in range(2):
+        d_in = torch.from_numpy(xs[call]).cuda()
+        used, made = b.process_device(d_in.data_ptr(), frames * ch, frames, d_out.data_ptr(), cap * ch, cap,
+                                      torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        assert len(set(made)) == 1 and len(set(used)) == 1
+        sums = set()
+        for s in range(S):
+            sums.add(int(out[s, : made[s]].astype(np.int64).sum()))
+        assert len(sums) == S
+        for s in check:
+            want, wu = refs[s].process(xs[call][s], cap)
+            assert (used[s], made[s]) == (wu, want.shape[0]), (call, s)
+            assert_close(out[s, : made[s]], want, "configs[4] share, call %d stream %d" % (call, s))
+            inf = b.info(s)
+            assert (inf["last_sample"], inf["samp_frac_num"]) == refs[s].position()
+            h = b.lines(s)
+            for c in range(ch):
+                assert np.array_equal(h[:, c], refs[s].history(c)), (call, s, c)
     b.close()
 
 
