@@ -42,10 +42,10 @@ struct PerLoad {
 // i.e. reference resample.c:898-899 (and :914-919 for pending frames) applied once over the
 // whole call.
 template <typename T>
-__device__ __forceinline__ void roll_history(uint32_t channels, const StreamDesc &d) {
+__device__ __forceinline__ void roll_history(uint32_t channels, const StreamDesc &d, uint32_t nthr) {
   const uint32_t hist_frames = d.hist_frames;
   const uint32_t total = d.hist_keep * channels;
-  for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+  for (uint32_t i = threadIdx.x; i < total; i += nthr) {
     const uint32_t h = i / channels, c = i - h * channels;
     const int64_t v = static_cast<int64_t>(d.consumed) + h;
     float s;
@@ -88,6 +88,7 @@ struct WindowGeom {
                                // kernel) counted from the window's first frame
   uint32_t period_magic;       // ceil(2^32 / period_elems): n / period_elems == umulhi(n, magic) for
                                // the n < 2^17 that index an LDS image (host: period_magic_of)
+  uint32_t nthr;               // lanes of the workgroup (kernel argument, not g.nthr: see device_types.h)
 };
 
 // host + device: the multiplier above (exact for n * (magic*d - 2^32) < 2^32, i.e. n < 2^32 / d)
@@ -98,10 +99,11 @@ __host__ __device__ inline uint32_t period_magic_of(uint32_t d) {
 template <typename T>
 __device__ __forceinline__ WindowGeom window_geom(const StreamDesc &d, uint32_t channels,
                                                   uint32_t num, uint32_t tail_frames, uint32_t m_lo,
-                                                  uint32_t m_cnt, uint32_t pad = 0, uint32_t period_magic = 0,
-                                                  uint32_t pad_every = 0) {
+                                                  uint32_t m_cnt, uint32_t nthr, uint32_t pad = 0,
+                                                  uint32_t period_magic = 0, uint32_t pad_every = 0) {
   constexpr int GS = PerLoad<T>::value;
   WindowGeom w;
+  w.nthr = nthr;
   w.pad = pad;
   w.period_elems = pad_every ? pad_every : num * channels;  // floats between two paddings
   w.period_magic = period_magic;
@@ -142,7 +144,7 @@ template <int UNR, typename T>
 __device__ __forceinline__ void window_fetch(const WindowGeom &g, u32x4 (&w)[UNR]) {
 #pragma unroll
   for (int u = 0; u < UNR; u++) {
-    const uint32_t unit = u * blockDim.x + threadIdx.x;
+    const uint32_t unit = u * g.nthr + threadIdx.x;
     // clamped, never branched around: all UNR loads stay in flight
     w[u] = g.n_wide ? load_group<T>(g, min(unit, g.n_wide - 1)) : u32x4{0u, 0u, 0u, 0u};
   }
@@ -209,29 +211,29 @@ __device__ __forceinline__ void window_commit(float *xs, const StreamDesc &d, co
   constexpr int GS = PerLoad<T>::value;
 #pragma unroll
   for (int u = 0; u < UNR; u++) {
-    const uint32_t unit = u * blockDim.x + threadIdx.x;
+    const uint32_t unit = u * g.nthr + threadIdx.x;
     if (unit < g.n_wide) commit_group<T>(xs, g, GS * (g.u_begin + unit), w[u]);
   }
   // groups beyond the prefetched UNR per lane (small workgroups, very wide windows): further
   // rounds of UNR loads in flight at a time
-  for (uint32_t base = UNR * blockDim.x; base < g.n_wide; base += UNR * blockDim.x) {
+  for (uint32_t base = UNR * g.nthr; base < g.n_wide; base += UNR * g.nthr) {
     u32x4 v[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
-      const uint32_t unit = base + u * blockDim.x + threadIdx.x;
+      const uint32_t unit = base + u * g.nthr + threadIdx.x;
       v[u] = load_group<T>(g, min(unit, g.n_wide - 1));
     }
 #pragma unroll
     for (int u = 0; u < UNR; u++) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
-      const uint32_t unit = base + u * blockDim.x + threadIdx.x;
+      const uint32_t unit = base + u * g.nthr + threadIdx.x;
       if (unit < g.n_wide) commit_group<T>(xs, g, GS * (g.u_begin + unit), v[u]);
     }
   }
-  for (uint32_t j = threadIdx.x; j < g.head_end; j += blockDim.x)
+  for (uint32_t j = threadIdx.x; j < g.head_end; j += g.nthr)
     xs[g.pad ? padded_pos(g, j) : j] = rel_sample<T>(d, g.q_base + j, g.hist_elems, g.in_elems);
-  for (uint32_t j = g.tail_begin + threadIdx.x; j < g.total; j += blockDim.x)
+  for (uint32_t j = g.tail_begin + threadIdx.x; j < g.total; j += g.nthr)
     xs[g.pad ? padded_pos(g, j) : j] = rel_sample<T>(d, g.q_base + j, g.hist_elems, g.in_elems);
 }
 

@@ -52,6 +52,8 @@ struct SlideParams {
   uint32_t blocks_per_tile; // ... per workgroup
   uint32_t row_stride;      // floats between LDS rows (P frames + bank padding)
   uint32_t row_magic;       // ceil(2^32 / floats per row): division-free row index while staging
+  uint32_t threads;         // lanes per workgroup (a kernel argument: blockDim.x would be fetched from the
+                            // dispatch packet with a vector load that drains the staging loads in flight)
   uint32_t skip;            // diagnostics only
 };
 
@@ -72,6 +74,8 @@ struct PeriodParams {
   uint32_t pad;           // LDS bank padding: floats inserted after every period of the window
   uint32_t wrap_step;     // iterations between two period boundaries of a group's window (num/4)
   uint32_t period_magic;  // ceil(2^32 / (num*channels)): division-free period index in the padded image
+  uint32_t threads;       // lanes per workgroup (see SlideParams::threads)
+  uint32_t prio;          // bit 0: prologue + staging at raised wave priority; bit 1: the stores too
   uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP), 0 in normal operation
 };
 

@@ -121,8 +121,9 @@ int Batch::install_filter(const std::vector<float> &hist, uint32_t hist_frames_c
   (void)hipFree(d_hist_[0]);
   (void)hipFree(d_hist_[1]);
   (void)hipFree(d_period_rows_);
+  (void)hipFree(d_period_fine_rows_);
   (void)hipFree(d_slide_rows_);
-  d_table_ = d_hist_[0] = d_hist_[1] = d_period_rows_ = d_slide_rows_ = nullptr;
+  d_table_ = d_hist_[0] = d_hist_[1] = d_period_rows_ = d_period_fine_rows_ = d_slide_rows_ = nullptr;
   line_ = std::max(line_, filter_.taps - 1 + kBlockIn);  // grow-only, resample.c:709-720
 
   HIP_TRY(hipMalloc(&d_table_, sizeof(float) * filter_.table_len));
@@ -144,6 +145,18 @@ int Batch::install_filter(const std::vector<float> &hist, uint32_t hist_frames_c
     build_period_rows(filter_, period_, &rows);
     HIP_TRY(hipMalloc(&d_period_rows_, rows.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(d_period_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  period_fine_ = PeriodPlan();
+  if (period_.usable && period_.r == 10) {
+    static const bool no_fine = std::getenv("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
+    period_fine_ = plan_period_r(filter_, channels_, kLdsBudget, 5);
+    if (no_fine || period_fine_.lane_periods != period_.lane_periods) period_fine_.usable = false;
+    if (period_fine_.usable) {
+      std::vector<float> rows;
+      build_period_rows(filter_, period_fine_, &rows);
+      HIP_TRY(hipMalloc(&d_period_fine_rows_, rows.size() * sizeof(float)));
+      HIP_TRY(hipMemcpy(d_period_fine_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
   }
   slide_ = plan_slide(filter_, channels_);
   if (slide_.usable && !period_.usable) {
@@ -268,6 +281,7 @@ Batch::~Batch() {
   (void)hipFree(d_hist_[0]);
   (void)hipFree(d_hist_[1]);
   (void)hipFree(d_period_rows_);
+  (void)hipFree(d_period_fine_rows_);
   (void)hipFree(d_slide_rows_);
   (void)hipFree(d_ring_);
   if (h_ring_) (void)hipHostFree(h_ring_);
@@ -413,8 +427,8 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
     }
     hipError_t e;
     if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)
-      e = launch_period(filter_, period_, d_period_rows_, channels_, descs, d_descs,
-                        packed ? &pack : nullptr, n_streams_, float_io, stream);
+      e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs,
+                        d_descs, packed ? &pack : nullptr, n_streams_, float_io, stream);
     else if (mode_ == SPEEXHIP_MODE_FAST && slide_.usable)
       e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, d_descs,
                        packed ? &pack : nullptr, n_streams_, float_io, stream);

@@ -89,6 +89,8 @@ class Batch {
   ExactGeometry exact_geo_;
   PeriodPlan period_;      // primary fast path (kernels_period.hip)
   float *d_period_rows_ = nullptr;
+  PeriodPlan period_fine_;  // the same filter with 5 phases per wave: single-generation launches
+  float *d_period_fine_rows_ = nullptr;
   SlidePlan slide_;        // small-ratio fast path (kernels_slide.hip); neither usable -> exact
   float *d_slide_rows_ = nullptr;
 

@@ -63,10 +63,13 @@ struct PeriodPlan {         // per filter, fixed at init
   size_t rows_floats = 0, window_bytes = 0;
 };
 PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget);
+PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r);
 void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<float> *rows);
-hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
-                         const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                         uint32_t n_streams, bool float_io, hipStream_t stream);
+// `fine`: the same filter planned with r = 5 (or null); single-generation launches take it
+hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, const PeriodPlan *fine,
+                         const float *d_rows_fine, uint32_t channels, const StreamDesc *h_descs,
+                         const StreamDesc *d_descs, const DescPack *pack, uint32_t n_streams, bool float_io,
+                         hipStream_t stream);
 
 // ---- small-ratio fast kernel (kernels_slide.hip): den <= 6, num <= 4 -------------------------
 struct SlidePlan {

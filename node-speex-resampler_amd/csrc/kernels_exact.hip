@@ -58,7 +58,7 @@ __device__ __forceinline__ void cubic_weights(float f, float w[4]) {
 // T = sample type of the call: int16_t (round + saturate on the way out, resample.c:1018-1022)
 // or float (the FIR value as is, resample.c:927-963).
 template <int KIND, int CT, bool STAGED, bool PACKED, typename T>
-__global__ __launch_bounds__(256) void resample_exact(ExactParams p, const StreamDesc *streams,
+__global__ __launch_bounds__(256) void resample_exact(ExactParams p, const StreamDesc *__restrict__ streams,
                                                       DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
   const uint32_t hist_frames = d.hist_frames;
 
   if (blockIdx.x == gridDim.x - 1) {  // one extra workgroup per stream rolls the history
-    if (blockIdx.z == 0) roll_history<T>(p.channels, d);
+    if (blockIdx.z == 0) roll_history<T>(p.channels, d, p.outs_per_block);
     return;
   }
   const uint32_t k_first = blockIdx.x * p.outs_per_block;
@@ -83,12 +83,12 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
   if (STAGED) {
     float *tab_lds = lds;
     float *xs_lds = lds + ((p.table_len + 3) & ~3u);
-    for (uint32_t i = threadIdx.x; i < p.table_len; i += blockDim.x) tab_lds[i] = p.table[i];
+    for (uint32_t i = threadIdx.x; i < p.table_len; i += p.outs_per_block) tab_lds[i] = p.table[i];
     const uint64_t t_last = t_first + static_cast<uint64_t>(k_count - 1) * p.num;
     const uint32_t span =
         static_cast<uint32_t>(static_cast<int64_t>(d.last0) + static_cast<int64_t>(t_last / p.den) - base) +
         p.taps;
-    for (uint32_t i = threadIdx.x; i < span * CT; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < span * CT; i += p.outs_per_block) {
       const uint32_t f = i / CT, ct = i - f * CT;
       const uint32_t c = c_first + ct;
       xs_lds[i] = c < C ? virtual_sample<T>(d, hist_frames, C, base + f, c) : 0.f;

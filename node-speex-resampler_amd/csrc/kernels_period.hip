@@ -32,6 +32,19 @@
 #include "kernels.h"
 
 namespace speexhip {
+// Diagnostics build only (-DSPEEXHIP_STAMPS, tools/stamps.py): every workgroup records when it
+// reached a few points, on the 100 MHz s_memrealtime clock all CUs share.  Not in the product.
+#ifdef SPEEXHIP_STAMPS
+__device__ unsigned long long g_stamps[8192 * 16];
+#define STAMP(k)                                                                                         \
+  do {                                                                                                   \
+    const uint32_t lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                \
+    if ((threadIdx.x & 63u) == 0 && lin_ < 8192)                                                         \
+      atomicMax(&g_stamps[lin_ * 16 + (k)], (unsigned long long)__builtin_amdgcn_s_memrealtime());        \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -93,7 +106,7 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   const uint32_t C = c.C;
   const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
   // (delta_g < num: no padding boundary before the group's first sample)
-  const float *xp = xs + c.xlane + delta_g * C + it_lo * 4 * C;
+  const float *xp = xs + c.xlane + delta_g * C + it_lo * (40 / R) * C;
   // padded layout: the host shifted this group's start by <= 3 frames so that the one padding
   // boundaries its window crosses fall between iterations (the first before iteration wrap_it)
   // (counted DOWN to the next boundary, like the loop itself: with 80 SGPRs there is no register to
@@ -110,13 +123,16 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   // A wait is lgkmcnt(0) (scalar loads return out of order and share the counter with LDS),
   // so a bank's loads must be issued right AFTER the other bank's wait; `touch_bank` is an
   // empty asm that reads the bank and thereby makes hipcc put the wait exactly there.
-  const float *__restrict__ trow = rows + (static_cast<size_t>(g) * p.l4 + it_lo) * (4 * R);
-  f32x2 ta[R], tb[R], xa[2], xb[2];
-  auto load_bank = [&](f32x2 (&t)[R], f32x2 (&x)[2], const float *tp, const float *sp) {
+  // A bank is always 20 taps = 10 SGPR pairs: 2 steps of R = 10 phases, or 4 steps of R = 5.
+  constexpr int STEPS = 20 / R;  // steps per bank; an iteration is two banks
+  static_assert(R == 10 || R == 5, "a bank holds 20 taps");
+  const float *__restrict__ trow = rows + (static_cast<size_t>(g) * p.l4 + it_lo) * (2 * STEPS * R);
+  f32x2 ta[10], tb[10], xa[STEPS], xb[STEPS];
+  auto load_bank = [&](f32x2 (&t)[10], f32x2 (&x)[STEPS], const float *tp, const float *sp) {
 #pragma unroll
-    for (int j = 0; j < R; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
+    for (int j = 0; j < 10; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < STEPS; u++) {
       if (CT == 2) {
         x[u] = *reinterpret_cast<const f32x2 *>(sp + u * C);
       } else {
@@ -125,18 +141,18 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
       }
     }
   };
-  auto touch_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
-    if constexpr (R == 10) {
+  auto touch_bank = [&](const f32x2 (&t)[10], const f32x2 (&x)[STEPS]) {
+    if constexpr (STEPS == 2) {
       asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
                    "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]));
     } else {
-      static_assert(R == 5, "touch_bank lists the tap pairs of R = 10 or R = 5");
-      asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "v"(x[0]), "v"(x[1]));
+      asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
+                   "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
     }
   };
-  auto fma_bank = [&](const f32x2 (&t)[R], const f32x2 (&x)[2]) {
+  auto fma_bank = [&](const f32x2 (&t)[10], const f32x2 (&x)[STEPS]) {
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < STEPS; u++)
 #pragma unroll
       for (int i = 0; i < R; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
   };
@@ -144,14 +160,14 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   for (uint32_t left = it_hi - it_lo; left != 0; left--) {
     touch_bank(ta, xa);
     __builtin_amdgcn_sched_barrier(0);
-    load_bank(tb, xb, trow + 2 * R, xp + 2 * C);
+    load_bank(tb, xb, trow + 20, xp + STEPS * C);
     __builtin_amdgcn_sched_barrier(0);
     fma_bank(ta, xa);
     __builtin_amdgcn_sched_barrier(0);
     touch_bank(tb, xb);
     __builtin_amdgcn_sched_barrier(0);
-    trow += 4 * R;
-    xp += 4 * C;
+    trow += 40;
+    xp += 2 * STEPS * C;
     if (PADDED && --to_wrap == 0) {  // wave-uniform: the window pointer steps over the bank padding
       xp += p.pad;
       to_wrap = p.wrap_step;         // the next period boundary, num/4 iterations on (or never)
@@ -286,9 +302,24 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
     f32x2 acc[R];  // .x = first channel of the pair, .y = second (unused when CT == 1)
 #pragma unroll
     for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
+#ifdef SPEEXHIP_STAMPS
+    const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime();
+#endif
     fir_group<R, CT, PADDED>(p, rows, xs, c, g, 0, (p.skip & 4u) ? 0 : p.l4, acc);
+#ifdef SPEEXHIP_STAMPS
+    {
+      asm volatile("" ::"v"(acc[0]));
+      const unsigned long long fir_t1 = __builtin_amdgcn_s_memtime();
+      const uint32_t lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      if ((threadIdx.x & 63u) == 0 && lin_ < 8192) atomicMax(&g_stamps[lin_ * 16 + 7], fir_t1 - fir_t0);
+    }
+#endif
+    STAMP(5);
     if ((p.skip & 8u) || !c.live) continue;
+    if (p.prio & 2u) __builtin_amdgcn_s_setprio(2);
     store_group<R, CT, ONE_GROUP, T>(p, d, c, g, acc);
+    if (p.prio & 2u) __builtin_amdgcn_s_setprio(0);
+    STAMP(6);
   }
 }
 
@@ -345,7 +376,7 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
 
   // copy-out: wave w takes rows w, w + nw, ...; lane l the dwords [4l, 4l+4) of the row; image
   // dword j holds the row's samples 2j - sh and 2j + 1 - sh
-  const uint32_t nw = blockDim.x >> 6;
+  const uint32_t nw = p.threads >> 6;
   const uint32_t *img = reinterpret_cast<const uint32_t *>(xs);
   for (uint32_t m = wave; m < m_cnt; m += nw) {
     const uint32_t sh = shift_of(m);
@@ -388,29 +419,53 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
 // shares of its phase groups.
 template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
-    PeriodParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
+    PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  if (p.skip & 64u) return;  // diagnostics: bare dispatch cost
-  const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
-  if (blockIdx.x == p.history_block) {
-    if (blockIdx.z == 0) roll_history<T>(p.channels, d);
-    return;
+  // A workgroup that starts beside another one's FIR loop competes with 16 older waves for every
+  // issue slot: its few hundred prologue and staging instructions -- the ones that put its window
+  // loads in flight -- took 4-5 us there (0.5 us on an idle CU).  They run at raised priority; the
+  // FIR loop and everything after it at the default.
+  if (p.prio & 1u) __builtin_amdgcn_s_setprio(3);
+  STAMP(0);
+#ifdef SPEEXHIP_STAMPS
+  {
+    const uint32_t lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && lin_ < 8192)
+      g_stamps[lin_ * 16 + 8] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11))) << 32) |
+                                __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
   }
-  if (d.n_out == 0 || blockIdx.x > p.history_block) return;
+#endif
+  // Everything up to the window geometry is computed BEFORE the first branch (on whatever values an
+  // exiting workgroup happens to have: pure arithmetic, no memory access): the kernel arguments and
+  // the descriptor then arrive through one batch of scalar loads and a single wait instead of one
+  // round trip per early exit (four dependent waits, ~1.0 us from start to the first staging load).
+  const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   const uint32_t K_end = d.k_shift + d.n_out;            // exclusive canonical output index
   const uint32_t m_total = (K_end + p.den - 1) / p.den;  // periods touched by this call
   const uint32_t m_lo = blockIdx.x * p.lane_periods;
-  if (m_lo >= m_total) return;
-  const uint32_t m_cnt = min(p.lane_periods, m_total - m_lo);
-
-  const WindowGeom wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, PADDED ? p.pad : 0u,
-                                       PADDED ? p.period_magic : 0u);
-  if (!(p.skip & 2u)) {
-    u32x4 w[3];
-    window_fetch<3, T>(wg, w);
-    window_commit<3, T>(xs, d, wg, w);
+  const uint32_t m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 1u;
+  const WindowGeom wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, p.threads,
+                                       PADDED ? p.pad : 0u, PADDED ? p.period_magic : 0u);
+  if (p.skip & 64u) return;  // diagnostics: bare dispatch cost
+  if (blockIdx.x == p.history_block) {
+    if (blockIdx.z == 0) roll_history<T>(p.channels, d, p.threads);
+    return;
   }
+  if (d.n_out == 0 || blockIdx.x > p.history_block || m_lo >= m_total) return;
+  STAMP(1);
+  if (!(p.skip & 2u)) {
+    // 5 x 16 bytes per lane in flight: a 76 KB window staged by 1024 lanes in one round of loads
+    // (the padded commit needs more registers per group: 3 there keeps the kernel at 8 waves per SIMD)
+    constexpr int UNR = PADDED ? 3 : 5;
+    u32x4 w[UNR];
+    window_fetch<UNR, T>(wg, w);
+    STAMP(2);
+    window_commit<UNR, T>(xs, d, wg, w);
+  }
+  STAMP(3);
   __syncthreads();
+  if (p.prio & 1u) __builtin_amdgcn_s_setprio(0);
+  STAMP(4);
   if (p.skip & 128u) return;  // diagnostics: prologue + staging only
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
@@ -444,19 +499,30 @@ hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const Des
 }
 
 const size_t kSlack = 16;  // floats: window starts on the input's 16-byte grid, staged by 8
-// Phases per wave.  -DSPEEXHIP_R=5 builds the alternative that was measured against it: half the
-// FMAs per sample read and tap load, but rows padded by 4 instead of 9 steps -- one stream 13.26 ->
-// 12.88 us, 32 streams 202 -> 212 us, stereo 48k->44.1k 189 -> 182 us: not worth a second table.
-#ifndef SPEEXHIP_R
-#define SPEEXHIP_R 10
-#endif
-const uint32_t kR = SPEEXHIP_R;
+// Phases per wave: R = 10 (banks of 2 steps) or R = 5 (banks of 4 steps; same 20 taps per bank, so the
+// same distance between a bank's loads and its use).  R = 5 pads its rows by 4 instead of 9 steps and
+// gives a tile twice as many wave-sized pieces -- what a launch of a single generation of workgroups
+// needs -- at half the FMAs per sample read and 20-byte instead of 40-byte store pieces per lane.
+uint32_t default_r() {
+  static const uint32_t r = [] {
+    const char *e = std::getenv("SPEEXHIP_R");
+    return e != nullptr && std::atoi(e) == 5 ? 5u : 10u;
+  }();
+  return r;
+}
 
 }  // namespace
 
 PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget) {
+  PeriodPlan t = plan_period_r(f, channels, lds_budget, default_r());
+  if (!t.usable && t.r != 10) t = plan_period_r(f, channels, lds_budget, 10);
+  return t;
+}
+
+PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r) {
   PeriodPlan t;
-  t.r = kR;
+  t.r = r;
+  const uint32_t it_steps = 40 / t.r;  // steps per loop iteration (two banks)
   t.ct = (channels % 2 == 0) ? 2 : 1;
   t.cgroups = channels / t.ct;
   t.groups = (f.den + t.r - 1) / t.r;
@@ -466,12 +532,12 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
     const uint32_t r_last = std::min<uint32_t>(g * t.r + t.r - 1, f.den - 1);
     dmax = std::max<uint32_t>(dmax, static_cast<uint32_t>((static_cast<uint64_t>(r_last) * f.num) / f.den - d0));
   }
-  t.row_len = (f.taps + dmax + 3) / 4 * 4;
-  t.l4 = t.row_len / 4;
+  t.row_len = (f.taps + dmax + it_steps - 1) / it_steps * it_steps;
+  t.l4 = t.row_len / it_steps;
   t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * t.r * f.num) / f.den) + t.row_len;
   t.lane_periods = 64 / t.cgroups;  // revised below once the window size is known
-  // + one iteration (4R floats) of zero padding: the tap pipeline prefetches one past the end
-  t.rows_floats = static_cast<size_t>(t.groups) * t.l4 * 4 * t.r + 4 * t.r;
+  // + one iteration (40 floats) of zero padding: the tap pipeline prefetches one past the end
+  t.rows_floats = static_cast<size_t>(t.groups) * t.row_len * t.r + 40;
   // Bank padding: the lanes of a wave read the window num*channels floats apart.  Pick the pad
   // (multiple of 4 floats, inserted after every period) with the fewest lanes of a half-wave on
   // the same bank (ds_read_b32) / bank pair (ds_read_b64); 1 = conflict-free.  (Measured on
@@ -502,6 +568,7 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
   static const bool no_pad = std::getenv("SPEEXHIP_NO_PAD") != nullptr;
   if (no_pad) t.pad = 0;
   if (std::getenv("SPEEXHIP_PAD")) t.pad = static_cast<uint32_t>(std::atoi(std::getenv("SPEEXHIP_PAD"))) & ~3u;  // diagnostics
+  if (t.pad != 0 && t.r != 10) return t;  // (the padded walk below is written for 4-step iterations)
   if (t.pad != 0) {
     // A padded window is only walked cheaply if every period boundary a group's window crosses
     // falls between two iterations: the first one is moved there by starting the group k <= 3
@@ -518,7 +585,7 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
     if (ok) {
       t.row_len = row_len;
       t.l4 = row_len / 4;
-      t.rows_floats = static_cast<size_t>(t.groups) * t.l4 * 4 * t.r + 4 * t.r;
+      t.rows_floats = static_cast<size_t>(t.groups) * t.row_len * t.r + 40;
       t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * t.r * f.num) / f.den) + t.row_len;
     } else {
       t.pad = 0;
@@ -531,7 +598,7 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
     //  reads -- and discards -- one period past its last, so size the image for an even count)
     if (t.ct == 1) lane_periods = (lane_periods + 1) / 2 * 2;
     const size_t pad_floats = static_cast<size_t>(t.pad) * (lane_periods + t.tail_frames / f.num + 2);
-    size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + 4) * channels + pad_floats) * 4 +
+    size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + it_steps) * channels + pad_floats) * 4 +
                    kSlack * 4;
     return bytes;
   };
@@ -595,21 +662,66 @@ void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<flo
       phase_taps(f, phase, h.data());
       for (uint32_t j = 0; j < f.taps; j++) {
         const uint32_t s = j + shift;
-        (*rows)[((static_cast<size_t>(g) * t.l4 + s / 4) * 4 + (s & 3)) * t.r + i] = static_cast<float>(h[j]);
+        (*rows)[(static_cast<size_t>(g) * t.row_len + s) * t.r + i] = static_cast<float>(h[j]);
       }
     }
   }
 }
 
-hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
-                         const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
-                         uint32_t n_streams, bool float_io, hipStream_t stream) {
+namespace {
+uint32_t periods_of_launch(const FilterSpec &f, const StreamDesc *h_descs, uint32_t n_streams) {
   uint32_t max_periods = 0;
   for (uint32_t s = 0; s < n_streams; s++) {
     if (h_descs[s].n_out == 0) continue;
     const uint64_t k_end = static_cast<uint64_t>(h_descs[s].k_shift) + h_descs[s].n_out;
     max_periods = std::max<uint32_t>(max_periods, static_cast<uint32_t>((k_end + f.den - 1) / f.den));
   }
+  return max_periods;
+}
+
+// Shares a tile's phase groups are split into when one workgroup per tile would leave CUs idle.
+uint32_t split_count(const PeriodPlan &t, uint32_t tiles, uint32_t n_streams, uint32_t resident) {
+  // (measured on cfg2, one stream: 1/2/4 shares -> 18.5/13.6/14.8 us: split until the launch has
+  //  about one workgroup per CU, not more -- every share re-stages the window.
+  //  Also tried: splitting each group's TAP range over the spare waves of a share, partial sums
+  //  meeting in LDS -- +1 us, the two extra barriers cost more than the occupancy gains.)
+  static const uint32_t force_splits = std::getenv("SPEEXHIP_SPLITS") ? std::atoi(std::getenv("SPEEXHIP_SPLITS")) : 0;
+  if (force_splits) return std::min<uint32_t>(force_splits, t.groups);
+  uint32_t splits = 1;
+  while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident / 2 &&
+         (t.groups + splits * 2 - 1) / (splits * 2) >= 2)
+    splits *= 2;
+  return splits;
+}
+
+hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
+                              const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                              uint32_t n_streams, bool float_io, hipStream_t stream);
+}  // namespace
+
+// `fine` (may be null / unusable): the same filter planned with R = 5.  A launch that is a single
+// generation of workgroups -- one that the R = 10 plan would have to split into shares whose
+// workgroups run 8 FIR waves (2 per SIMD) beside 8 staging helpers -- takes it instead: 16 FIR
+// waves per workgroup, 4 per SIMD, each with half the phases (cfg2, one stream: 12.95 -> 12.09 us;
+// in launches of several generations R = 10 wins: 32 streams 210 vs 225 us).
+hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, const PeriodPlan *fine,
+                         const float *d_rows_fine, uint32_t channels, const StreamDesc *h_descs,
+                         const StreamDesc *d_descs, const DescPack *pack, uint32_t n_streams, bool float_io,
+                         hipStream_t stream) {
+  if (fine != nullptr && fine->usable && d_rows_fine != nullptr) {
+    const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
+    const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
+    if (split_count(t, tiles, n_streams, 2 * device_compute_units()) > 1)
+      return launch_period_plan(f, *fine, d_rows_fine, channels, h_descs, d_descs, pack, n_streams, float_io, stream);
+  }
+  return launch_period_plan(f, t, d_rows, channels, h_descs, d_descs, pack, n_streams, float_io, stream);
+}
+
+namespace {
+hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
+                              const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                              uint32_t n_streams, bool float_io, hipStream_t stream) {
+  const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
   const uint32_t resident = 2 * device_compute_units();  // two workgroups fit per CU
   // One workgroup per (tile, stream); the hardware dispatcher refills a CU the moment a workgroup
@@ -618,22 +730,11 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   // streams -- 228 vs 212 us --, 25 % slower on the 8-channel configuration.)
   // When one workgroup per tile leaves CUs idle (one short stream), the phase groups of a tile are
   // split over several workgroups.
-  uint32_t splits = 1;
-  static const uint32_t force_splits = std::getenv("SPEEXHIP_SPLITS") ? std::atoi(std::getenv("SPEEXHIP_SPLITS")) : 0;
-  if (force_splits)
-    splits = std::min<uint32_t>(force_splits, t.groups);
-  else
-    // (measured on cfg2, one stream: 1/2/4 shares -> 18.5/13.6/14.8 us: split until the launch has
-    //  about one workgroup per CU, not more -- every share re-stages the window.
-    //  Also tried: splitting each group's TAP range over the spare waves of a share, partial sums
-    //  meeting in LDS -- +1 us, the two extra barriers cost more than the occupancy gains.
-    //  Phase costs of that launch (rocprofv3, parts skipped, profiles/r01_phases_cfg2_s1.txt): bare
-    //  dispatch 1.7, descriptor + geometry 1.0, window staging 1.9, FIR loop 6.6, stores 3.0 --
-    //  14.8 us if serial against 13.2 us measured: a launch that is a single generation of
-    //  workgroups overlaps very little.)
-    while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident / 2 &&
-           (t.groups + splits * 2 - 1) / (splits * 2) >= 2)
-      splits *= 2;
+  // (Phase costs of the single-stream launch, R = 10, rocprofv3 with parts skipped,
+  //  profiles/r01_phases_cfg2_s1.txt: bare dispatch 1.7, descriptor + geometry 1.0, window staging 1.9,
+  //  FIR loop 6.6, stores 3.0 -- 14.8 us if serial against 13.2 us measured: a launch that is a
+  //  single generation of workgroups overlaps very little.)
+  const uint32_t splits = split_count(t, tiles, n_streams, resident);
   static const uint32_t max_waves = std::getenv("SPEEXHIP_WAVES") ? std::atoi(std::getenv("SPEEXHIP_WAVES")) : 16;
   const uint32_t wave_groups = std::min<uint32_t>((t.groups + splits - 1) / splits, max_waves);
   PeriodParams p;
@@ -664,9 +765,12 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   //  48k->44.1k q5 mono 146 -> 153 us; it stays reachable with SPEEXHIP_ROWS=1 for the tests)
   if ((env_rows > 0 || (env_rows < 0 && static_cast<uint64_t>(tiles) * n_streams * 2 >= resident && f.den % 2 == 0)) &&
       !float_io && t.ct == 1 && t.cgroups == 1 && wave_groups * splits >= t.groups) {
-    const uint32_t stride = ((wave_groups * kR + 1) / 2 + 5) | 1u;  // samples/2 + the shift + 4 dwords of slack, odd
+    const uint32_t stride = ((wave_groups * t.r + 1) / 2 + 5) | 1u;  // samples/2 + the shift + 4 dwords of slack, odd
     if (static_cast<size_t>(stride) * t.lane_periods * 4 + 16 <= t.window_bytes) p.image_stride = stride;
   }
+  p.threads = 0;  // set below
+  static const int env_prio = std::getenv("SPEEXHIP_PRIO") ? std::atoi(std::getenv("SPEEXHIP_PRIO")) : 3;
+  p.prio = static_cast<uint32_t>(env_prio);
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
   // A workgroup that owns only a share of the groups still stages the whole window: lend it the
@@ -674,6 +778,7 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   static const int env_helpers = std::getenv("SPEEXHIP_HELPERS") ? std::atoi(std::getenv("SPEEXHIP_HELPERS")) : 1;
   const bool helpers = env_helpers != 0 && splits > 1 && p.image_stride == 0;  // (the image paths have barriers of their own)
   const uint32_t threads = (helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
+  p.threads = threads;
   // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8
   // when a tile is split: workgroups whose linear ids differ by a multiple of 8 share an XCD, so
   // the `splits` workgroups that stage the same input window hit in that XCD's L2 instead of
@@ -681,10 +786,17 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   uint32_t grid_x = (max_periods == 0 ? 0 : tiles) + 1;
   if (splits > 1 && n_streams == 1) grid_x = (grid_x + 7) / 8 * 8;
   const dim3 grid(grid_x, n_streams, splits);
-#define SPEEXHIP_PERIOD_CASE(CTV, ONE, PADV)                                                            \
-  return float_io ? launch_rc<kR, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, stream)   \
-                  : launch_rc<kR, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
+#define SPEEXHIP_PERIOD_CASE_R(RV, CTV, ONE, PADV)                                                            \
+  return float_io ? launch_rc<RV, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, stream)   \
+                  : launch_rc<RV, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
   const bool padded = t.pad != 0;
+  if (t.r == 5) {  // never padded (plan_period_r)
+    if (t.ct == 2 && t.cgroups == 1) SPEEXHIP_PERIOD_CASE_R(5, 2, true, false);
+    if (t.ct == 2) SPEEXHIP_PERIOD_CASE_R(5, 2, false, false);
+    if (t.cgroups == 1) SPEEXHIP_PERIOD_CASE_R(5, 1, true, false);
+    SPEEXHIP_PERIOD_CASE_R(5, 1, false, false);
+  }
+#define SPEEXHIP_PERIOD_CASE(CTV, ONE, PADV) SPEEXHIP_PERIOD_CASE_R(10, CTV, ONE, PADV)
   if (t.ct == 2) {
     if (t.cgroups == 1 && !padded) SPEEXHIP_PERIOD_CASE(2, true, false);
     if (t.cgroups == 1) SPEEXHIP_PERIOD_CASE(2, true, true);
@@ -696,6 +808,21 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
   if (!padded) SPEEXHIP_PERIOD_CASE(1, false, false);
   SPEEXHIP_PERIOD_CASE(1, false, true);
 #undef SPEEXHIP_PERIOD_CASE
+#undef SPEEXHIP_PERIOD_CASE_R
 }
+}  // namespace
+
+#ifdef SPEEXHIP_STAMPS
+extern "C" __attribute__((visibility("default"))) int speexhip_debug_stamps(unsigned long long *dst, size_t n, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (dst && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long)) != hipSuccess) return 2;
+  if (clear) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess) return 3;
+    if (hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 16) != hipSuccess) return 4;
+  }
+  return 0;
+}
+#endif
 
 }  // namespace speexhip

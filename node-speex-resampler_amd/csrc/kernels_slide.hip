@@ -54,11 +54,11 @@ __device__ __forceinline__ void fma_bcast_x(f32x2 &acc, const f32x2 &tap_pair, c
 // P: periods per lane; NUM: input frames per period; U = P*NUM tap steps per iteration.
 template <int P, int NUM, int NP, bool PAIR_CH, bool PACKED, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void resample_slide(
-    SlideParams p, const float *__restrict__ rows, const StreamDesc *streams, DescPack pack) {
+    SlideParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
-    roll_history<T>(p.channels, d);
+    roll_history<T>(p.channels, d, p.threads);
     return;
   }
   if (d.n_out == 0) return;
@@ -73,12 +73,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   // ---- stage: frames [f0, f0 + m_cnt*num + row_len + one row) of V as float, in rows of P*NUM
   //      frames `row_stride` floats apart: the shared loader's padded image with the row as its
   //      padding period (16-byte loads, all in flight at once; device_helpers.h) ----
-  const WindowGeom wg = window_geom<T>(d, C, NUM, NUM + p.row_len + P * NUM, m_lo, m_cnt,
+  const WindowGeom wg = window_geom<T>(d, C, NUM, NUM + p.row_len + P * NUM, m_lo, m_cnt, p.threads,
                                        p.row_stride - P * NUM * C, p.row_magic, P * NUM * C);
   if (!(p.skip & 2u)) {
-    u32x4 w[3];
-    window_fetch<3, T>(wg, w);
-    window_commit<3, T>(xs, d, wg, w);
+    u32x4 w[4];
+    window_fetch<4, T>(wg, w);
+    window_commit<4, T>(xs, d, wg, w);
   }
   __syncthreads();
 
@@ -334,6 +334,7 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   const size_t lds = (rows_needed * t.row_stride + 16) * 4;
   dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
   const uint32_t threads = waves * 64;
+  p.threads = threads;
 #define SPEEXHIP_SLIDE_CASE(PP, NUMV, NPV, CHV)                           \
   if (t.p == PP && t.num == NUMV && t.np == NPV && t.pair_ch == CHV)      \
     return float_io ? launch_up<PP, NUMV, NPV, CHV, float>(p, d_descs, pack, grid, threads, lds, stream) \

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "libspeexhip.so")
+# (SPEEXHIP_LIB_PATH: same-box A/B of two builds of the library, tools/gpu_ab.sh; never set in tests)
+LIB_PATH = os.environ.get("SPEEXHIP_LIB_PATH") or os.path.join(PKG_DIR, "libspeexhip.so")
 
 MODE_FAST, MODE_EXACT = 0, 1
 KERNEL_NAMES = ("direct_single", "direct_double", "interpolate_single", "interpolate_double")
