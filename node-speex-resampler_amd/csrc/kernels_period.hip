@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "device_helpers.h"
@@ -98,21 +99,20 @@ __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshi
   return c;
 }
 
-// acc[i] += sum over iterations [it_lo, it_hi) of group g's taps times the lane's samples.
+// acc[i] += group g's taps times the lane's samples, over the iterations the host tabulated for g.
 template <int R, int CT, bool PADDED>
 __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
-                                          const LaneCtx &c, uint32_t g, uint32_t it_lo, uint32_t it_hi,
-                                          f32x2 (&acc)[R]) {
+                                          const LaneCtx &c, uint32_t g, bool skip_all, f32x2 (&acc)[R]) {
   const uint32_t C = c.C;
   const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
   // (delta_g < num: no padding boundary before the group's first sample)
-  const float *xp = xs + c.xlane + delta_g * C + it_lo * (40 / R) * C;
+  const float *xp = xs + c.xlane + delta_g * C;
   // padded layout: the host shifted this group's start by <= 3 frames so that the one padding
   // boundaries its window crosses fall between iterations (the first before iteration wrap_it)
   // (counted DOWN to the next boundary, like the loop itself: with 80 SGPRs there is no register to
   //  spare for loop bounds, and a bound reloaded from the kernel arguments drags an lgkmcnt(0) wait
   //  -- i.e. the whole tap prefetch -- into every iteration)
-  uint32_t to_wrap = PADDED ? p.delta[p.groups + g] - it_lo : 0u;
+  uint32_t to_wrap = PADDED ? p.delta[p.groups + g] : 0u;
   // Taps are wave-uniform: they travel HBM/L2 -> scalar cache -> SGPRs (s_load: the row pointer
   // is a __restrict__ kernel argument, so the loads are provably invariant) and feed
   // v_pk_fma_f32 directly.
@@ -126,7 +126,7 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   // A bank is always 20 taps = 10 SGPR pairs: 2 steps of R = 10 phases, or 4 steps of R = 5.
   constexpr int STEPS = 20 / R;  // steps per bank; an iteration is two banks
   static_assert(R == 10 || R == 5, "a bank holds 20 taps");
-  const float *__restrict__ trow = rows + (static_cast<size_t>(g) * p.l4 + it_lo) * (2 * STEPS * R);
+  const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (2 * STEPS * R);
   f32x2 ta[10], tb[10], xa[STEPS], xb[STEPS];
   auto load_bank = [&](f32x2 (&t)[10], f32x2 (&x)[STEPS], const float *tp, const float *sp) {
 #pragma unroll
@@ -150,34 +150,62 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
                    "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
     }
   };
-  auto fma_bank = [&](const f32x2 (&t)[10], const f32x2 (&x)[STEPS]) {
+  // phases [LO, HI) of the group only: the head and tail iterations of a group, where the host
+  // knows half of the rows to be all zero (below)
+  auto fma_bank = [&](const f32x2 (&t)[10], const f32x2 (&x)[STEPS], auto lo_c, auto hi_c) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
 #pragma unroll
     for (int u = 0; u < STEPS; u++)
 #pragma unroll
-      for (int i = 0; i < R; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
+      for (int i = LO; i < HI; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
   };
   load_bank(ta, xa, trow, xp);
-  for (uint32_t left = it_hi - it_lo; left != 0; left--) {
-    touch_bank(ta, xa);
-    __builtin_amdgcn_sched_barrier(0);
-    load_bank(tb, xb, trow + 20, xp + STEPS * C);
-    __builtin_amdgcn_sched_barrier(0);
-    fma_bank(ta, xa);
-    __builtin_amdgcn_sched_barrier(0);
-    touch_bank(tb, xb);
-    __builtin_amdgcn_sched_barrier(0);
-    trow += 40;
-    xp += 2 * STEPS * C;
-    if (PADDED && --to_wrap == 0) {  // wave-uniform: the window pointer steps over the bank padding
-      xp += p.pad;
-      to_wrap = p.wrap_step;         // the next period boundary, num/4 iterations on (or never)
+  auto run = [&](uint32_t count, auto lo_c, auto hi_c) {
+    for (uint32_t left = count; left != 0; left--) {
+      touch_bank(ta, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      load_bank(tb, xb, trow + 20, xp + STEPS * C);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_bank(ta, xa, lo_c, hi_c);
+      __builtin_amdgcn_sched_barrier(0);
+      touch_bank(tb, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      trow += 40;
+      xp += 2 * STEPS * C;
+      if (PADDED && --to_wrap == 0) {  // wave-uniform: the window pointer steps over the bank padding
+        xp += p.pad;
+        to_wrap = p.wrap_step;         // the next period boundary, num/4 iterations on (or never)
+      }
+      // next iteration's bank A: the rows carry one iteration of zero padding past the last
+      // group and the window one step group of slack, so the final prefetch stays in bounds
+      load_bank(ta, xa, trow, xp);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_bank(tb, xb, lo_c, hi_c);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // next iteration's bank A: the rows carry one iteration of zero padding past the last
-    // group and the window one step group of slack, so the final prefetch stays in bounds
-    load_bank(ta, xa, trow, xp);
-    __builtin_amdgcn_sched_barrier(0);
-    fma_bank(tb, xb);
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  // The R rows of a group start up to R-1 steps apart (each phase's window begins ~num/den input
+  // frames after the previous one's), so the loop covers taps + that spread steps and every row is
+  // zero outside its own `taps` of them.  Whole iterations in which one HALF of the rows is zero are
+  // run on the other half only: `head` leading iterations where rows R/2.. have not begun, `tail`
+  // trailing ones where rows ..R/2-1 have ended (44.1k->48k q7: 1400 -> 1320 or 1340 FMAs per group).
+  // The counts come from the host per group (build_period_rows); skipped products are exact zeros.
+  if constexpr (R == 10) {
+    const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+    const uint32_t head = trips & 15u, tail = (trips >> 4) & 15u;
+    // (the accumulators are made opaque between the loops: left alone the register allocator ties
+    //  all of them into one 32-register tuple in some instantiations and spills it around each loop)
+    auto pin = [&]() {
+      asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                   "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]));
+    };
+    run(head, std::integral_constant<int, 0>(), std::integral_constant<int, R / 2>());
+    pin();
+    run((trips >> 8) - head - tail, std::integral_constant<int, 0>(), std::integral_constant<int, R>());
+    pin();
+    run(tail, std::integral_constant<int, R / 2>(), std::integral_constant<int, R>());
+  } else {
+    run(skip_all ? 0u : p.delta[2 * p.groups + g] >> 8, std::integral_constant<int, 0>(), std::integral_constant<int, R>());
   }
   touch_bank(ta, xa);  // retire the last prefetch
 }
@@ -241,8 +269,13 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
     G<float> *o = out_ptr<float>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
     if (ONE_GROUP && CT == 2 && i_lo == 0 && i_hi == R) {
 #pragma unroll
-      for (int i = 0; i + 1 < R; i += 2)
-        *(G<f32x4_a4> *)(o + 2 * i) = f32x4_a4{acc[i].x, acc[i].y, acc[i + 1].x, acc[i + 1].y};
+      for (int i = 0; i + 1 < R; i += 2) {
+        // (through opaque copies: a 16-byte store straight from two accumulators makes the register
+        //  allocator tie all R of them into one tuple, which it then spills around the FIR loops)
+        float a0 = acc[i].x, a1 = acc[i].y, a2 = acc[i + 1].x, a3 = acc[i + 1].y;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        *(G<f32x4_a4> *)(o + 2 * i) = f32x4_a4{a0, a1, a2, a3};
+      }
       if constexpr (R % 2 != 0) {
         o[2 * (R - 1)] = acc[R - 1].x;
         o[2 * (R - 1) + 1] = acc[R - 1].y;
@@ -305,7 +338,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 #ifdef SPEEXHIP_STAMPS
     const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    fir_group<R, CT, PADDED>(p, rows, xs, c, g, 0, (p.skip & 4u) ? 0 : p.l4, acc);
+    fir_group<R, CT, PADDED>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
 #ifdef SPEEXHIP_STAMPS
     {
       asm volatile("" ::"v"(acc[0]));
@@ -347,7 +380,7 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
   f32x2 acc[R];
 #pragma unroll
   for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
-  if (valid && !(p.skip & 4u)) fir_group<R, 1, PADDED>(p, rows, xs, c, g, 0, p.l4, acc);
+  if (valid) fir_group<R, 1, PADDED>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
   __syncthreads();  // every wave is done with the window
   if (p.skip & 8u) return;
 
@@ -418,7 +451,7 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
 // Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
 // shares of its phase groups.
 template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
+__global__ __launch_bounds__(1024, 8) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   // A workgroup that starts beside another one's FIR loop competes with 16 older waves for every
@@ -456,7 +489,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80))) void res
   if (!(p.skip & 2u)) {
     // 5 x 16 bytes per lane in flight: a 76 KB window staged by 1024 lanes in one round of loads
     // (the padded commit needs more registers per group: 3 there keeps the kernel at 8 waves per SIMD)
-    constexpr int UNR = PADDED ? 3 : 5;
+    // (float samples: 4 -- five float groups in flight spill at the 64 VGPRs of 8 waves per SIMD)
+    constexpr int UNR = PADDED ? 3 : (sizeof(T) == 4 ? (ONE_GROUP ? 4 : 3) : 5);
     u32x4 w[UNR];
     window_fetch<UNR, T>(wg, w);
     STAMP(2);
@@ -641,7 +675,10 @@ void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<flo
   // taps, then per group two uint32 tables (bit-copied into the float array):
   //   delta'[g] = (g*R*num) div den - k_g   first input frame of the group inside a period
   //   wrap[g]   = iteration before which the window pointer skips the bank padding (~0u: never)
-  rows->assign(t.rows_floats + 2 * t.groups, 0.f);
+  //   trips[g]  = head | tail << 4 | iterations << 8 (fir_group): iterations of the group's loop, of which the
+  //               first `head` touch only rows 0..R/2-1 and the last `tail` only rows R/2..R-1
+  rows->assign(t.rows_floats + 3 * t.groups, 0.f);
+  const uint32_t it_steps = 40 / t.r;
   for (uint32_t g = 0; g < t.groups; g++) {
     const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
     const uint32_t k = group_shift(f, t, g);
@@ -651,20 +688,39 @@ void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<flo
     std::memcpy(&(*rows)[t.rows_floats + g], &delta, sizeof(delta));
     std::memcpy(&(*rows)[t.rows_floats + t.groups + g], &wrap, sizeof(wrap));
   }
+  static const bool no_trim = std::getenv("SPEEXHIP_NO_TRIM") != nullptr;  // diagnostics: A/B of the trimming
   std::vector<double> h(f.taps);
   for (uint32_t g = 0; g < t.groups; g++) {
     const uint64_t d0 = (static_cast<uint64_t>(g) * t.r * f.num) / f.den - group_shift(f, t, g);
+    // iterations in which each half of the rows has a non-zero tap: [first, last]
+    uint32_t first[2] = {0xffffffffu, 0xffffffffu}, last[2] = {0, 0};
     for (uint32_t i = 0; i < t.r; i++) {
       const uint32_t r = g * t.r + i;
       if (r >= f.den) continue;  // padding phases of the last group stay zero
       const uint32_t phase = static_cast<uint32_t>((static_cast<uint64_t>(r) * f.num) % f.den);
       const uint32_t shift = static_cast<uint32_t>((static_cast<uint64_t>(r) * f.num) / f.den - d0);
+      const uint32_t half = (t.r == 10 && i >= t.r / 2) ? 1 : 0;
+      first[half] = std::min(first[half], shift / it_steps);
+      last[half] = std::max(last[half], (shift + f.taps - 1) / it_steps);
       phase_taps(f, phase, h.data());
       for (uint32_t j = 0; j < f.taps; j++) {
         const uint32_t s = j + shift;
         (*rows)[(static_cast<size_t>(g) * t.row_len + s) * t.r + i] = static_cast<float>(h[j]);
       }
     }
+    uint32_t total = std::max(last[0], last[1]) + 1, head = 0, tail = 0;
+    if (t.r == 10 && !no_trim) {
+      if (first[1] == 0xffffffffu) {  // the group has no row in its second half at all
+        total = last[0] + 1;
+      } else {
+        head = std::min<uint32_t>(first[1], 15);
+        tail = std::min<uint32_t>(total - std::min(total, last[0] + 1), 15);
+        if (head + tail > total) head = tail = 0;
+      }
+    }
+    if (no_trim) total = t.l4;
+    const uint32_t trips = head | tail << 4 | total << 8;
+    std::memcpy(&(*rows)[t.rows_floats + 2 * t.groups + g], &trips, sizeof(trips));
   }
 }
 
