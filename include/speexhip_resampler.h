@@ -124,6 +124,33 @@ SPEEXHIP_API int speexhip_resampler_get_output_latency(SpeexHipResamplerState *s
 SPEEXHIP_API int speexhip_resampler_skip_zeros(SpeexHipResamplerState *st);
 SPEEXHIP_API int speexhip_resampler_reset_mem(SpeexHipResamplerState *st);
 
+/* Replace speex_resampler_process_int / _process_float (speex_resampler.h:159-200,
+ * resample.c:968-1036, 927-963): ONE channel of the state, host buffers whose consecutive samples
+ * are `input stride` / `output stride` apart (speex_resampler_set/get_input/output_stride,
+ * speex_resampler.h:279-303, resample.c:1170-1188; both 1 after init, resample.c:842-843).  As in
+ * the reference every channel keeps its own position (last_sample / samp_frac_num /
+ * magic_samples, resample.c:135-137), so channels may be advanced unevenly; an interleaved call on
+ * such a state then handles channel after channel with the caller's lengths and reports the
+ * lengths of the last one (resample.c:1061-1082).  These run the bit-exact kernel on one channel
+ * in either mode. */
+SPEEXHIP_API int speexhip_resampler_process_int(SpeexHipResamplerState *st, uint32_t channel_index,
+                                                const int16_t *in, uint32_t *in_len, int16_t *out,
+                                                uint32_t *out_len);
+SPEEXHIP_API int speexhip_resampler_process_float(SpeexHipResamplerState *st, uint32_t channel_index,
+                                                  const float *in, uint32_t *in_len, float *out,
+                                                  uint32_t *out_len);
+SPEEXHIP_API void speexhip_resampler_set_input_stride(SpeexHipResamplerState *st, uint32_t stride);
+SPEEXHIP_API void speexhip_resampler_get_input_stride(SpeexHipResamplerState *st, uint32_t *stride);
+SPEEXHIP_API void speexhip_resampler_set_output_stride(SpeexHipResamplerState *st, uint32_t stride);
+SPEEXHIP_API void speexhip_resampler_get_output_stride(SpeexHipResamplerState *st, uint32_t *stride);
+
+/* When a filter change cannot build its filter -- the new filter length overflows
+ * (resample.c:620-621, 641-655) or memory runs out (here: device memory) -- the reference keeps
+ * its old filter length and history, keeps the NEW rates / ratio / quality, installs
+ * resampler_basic_zero (resample.c:561-591, 785-791) and returns RESAMPLER_ERR_ALLOC_FAILED: from
+ * then on every processing call writes zeros with the right lengths, moves the counters, and
+ * returns ALLOC_FAILED too, until a later set_rate / set_quality succeeds.  Same here. */
+
 /* Replaces speex_resampler_strerror (speex_resampler.h:338, resample.c:1222-1239); same
  * strings for codes 0..4, the reference's "Unknown error..." text for 5 and out-of-range
  * codes, and a HIP message for SPEEXHIP_ERR_DEVICE. */
@@ -276,6 +303,17 @@ SPEEXHIP_API int speexhip_plan_filter_change(uint32_t old_filt_len, uint32_t new
 
 /* Library build info: "speexhip <version> gfx950". */
 SPEEXHIP_API const char *speexhip_version(void);
+
+/* One channel's position (extension; the reference keeps these in its private state:
+ * last_sample[c], samp_frac_num[c], magic_samples[c], resample.c:135-137). */
+SPEEXHIP_API int speexhip_resampler_get_channel_position(SpeexHipResamplerState *st, uint32_t channel,
+                                                         int32_t *last_sample, uint32_t *samp_frac_num,
+                                                         uint32_t *magic_samples);
+
+/* Test hook: the n-th next device allocation made while installing a filter fails, as if the
+ * device were out of memory (exercises the resampler_basic_zero fallback, and the release of what
+ * an aborted install had already allocated, without exhausting HBM); 0 = off. */
+SPEEXHIP_API void speexhip_debug_fail_device_allocs(int n);
 
 #ifdef __cplusplus
 }

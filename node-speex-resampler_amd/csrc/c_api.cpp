@@ -142,6 +142,45 @@ int speexhip_resampler_process_chunks_float(SpeexHipResamplerState *st, uint32_t
                                         out_len, true);
 }
 
+int speexhip_resampler_process_int(SpeexHipResamplerState *st, uint32_t channel_index, const int16_t *in,
+                                   uint32_t *in_len, int16_t *out, uint32_t *out_len) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
+    return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->process_channel_host(channel_index, in, in_len, out, out_len, false);
+}
+
+int speexhip_resampler_process_float(SpeexHipResamplerState *st, uint32_t channel_index, const float *in,
+                                     uint32_t *in_len, float *out, uint32_t *out_len) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
+    return SPEEXHIP_ERR_INVALID_ARG;
+  return st->batch->process_channel_host(channel_index, in, in_len, out, out_len, true);
+}
+
+void speexhip_resampler_set_input_stride(SpeexHipResamplerState *st, uint32_t stride) {
+  st->batch->set_strides(stride, 0, true, false);
+}
+void speexhip_resampler_get_input_stride(SpeexHipResamplerState *st, uint32_t *stride) {
+  *stride = st->batch->in_stride();
+}
+void speexhip_resampler_set_output_stride(SpeexHipResamplerState *st, uint32_t stride) {
+  st->batch->set_strides(0, stride, false, true);
+}
+void speexhip_resampler_get_output_stride(SpeexHipResamplerState *st, uint32_t *stride) {
+  *stride = st->batch->out_stride();
+}
+
+int speexhip_resampler_get_channel_position(SpeexHipResamplerState *st, uint32_t channel, int32_t *last_sample,
+                                            uint32_t *samp_frac_num, uint32_t *magic_samples) {
+  if (st == nullptr || channel >= st->batch->channels()) return SPEEXHIP_ERR_INVALID_ARG;
+  const speexhip::StreamPos p = st->batch->channel_pos(0, channel);
+  if (last_sample) *last_sample = p.last;
+  if (samp_frac_num) *samp_frac_num = p.frac;
+  if (magic_samples) *magic_samples = p.magic;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+void speexhip_debug_fail_device_allocs(int n) { speexhip::debug_fail_device_allocs(n); }
+
 void speexhip_resampler_get_rate(SpeexHipResamplerState *st, uint32_t *in_rate, uint32_t *out_rate) {
   *in_rate = st->batch->filter().in_rate;
   *out_rate = st->batch->filter().out_rate;

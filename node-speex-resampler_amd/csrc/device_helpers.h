@@ -42,7 +42,10 @@ struct PerLoad {
 // i.e. reference resample.c:898-899 (and :914-919 for pending frames) applied once over the
 // whole call.
 template <typename T>
-__device__ __forceinline__ void roll_history(uint32_t channels, const StreamDesc &d, uint32_t nthr) {
+__device__ __forceinline__ void roll_history(uint32_t channels, const StreamDesc &d, uint32_t nthr,
+                                             uint32_t in_stride = 0, uint32_t hist_stride = 0) {
+  if (in_stride == 0) in_stride = channels;      // interleaved frames
+  if (hist_stride == 0) hist_stride = channels;
   const uint32_t hist_frames = d.hist_frames;
   const uint32_t total = d.hist_keep * channels;
   for (uint32_t i = threadIdx.x; i < total; i += nthr) {
@@ -50,14 +53,14 @@ __device__ __forceinline__ void roll_history(uint32_t channels, const StreamDesc
     const int64_t v = static_cast<int64_t>(d.consumed) + h;
     float s;
     if (v < static_cast<int64_t>(hist_frames)) {
-      s = hist_ptr(d)[v * channels + c];
+      s = hist_ptr(d)[v * hist_stride + c];
     } else {
       const int64_t f = v - hist_frames;
       s = (d.in != nullptr && f < static_cast<int64_t>(d.in_frames))
-              ? static_cast<float>(in_ptr<T>(d)[f * channels + c])
+              ? static_cast<float>(in_ptr<T>(d)[f * in_stride + c])
               : 0.f;
     }
-    ((g_f32 *)d.hist_next)[i] = s;
+    ((g_f32 *)d.hist_next)[static_cast<size_t>(h) * hist_stride + c] = s;
   }
 }
 

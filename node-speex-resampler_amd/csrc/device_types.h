@@ -41,6 +41,13 @@ struct ExactParams {
   uint32_t channels;
   uint32_t outs_per_block;  // output frames per workgroup (== blockDim.x)
   uint32_t span_cap;        // frames of LDS sample window per workgroup
+  // Samples between two frames of one channel in the input / output / history buffers: all equal
+  // to `channels` for interleaved calls.  The per-channel entry points (reference
+  // resample.c:927-1036 with the strides of :1170-1188) run ONE channel (channels == 1 here)
+  // through buffers with strides of their own.
+  uint32_t in_stride, out_stride, hist_stride;
+  uint32_t zero;            // != 0: resampler_basic_zero (resample.c:561-591): outputs are zeros, the
+                            // counters and the history move as usual
 };
 
 struct SlideParams {

@@ -2,6 +2,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -45,11 +46,45 @@ class DeviceScope {
   DeviceScope device_scope(device_); \
   HIP_TRY(device_scope.error())
 
+std::atomic<int> g_fail_allocs{0};
+
+// Device allocation of the filter installs: ALLOC_FAILED when the device is out of memory (or the
+// test hook says so) -- the caller then falls back to resampler_basic_zero like the reference
+// (resample.c:785-791) --, DEVICE for anything else.
+int dev_alloc(void **ptr, size_t bytes) {
+  *ptr = nullptr;
+  // test hook: a countdown -- the allocation that brings it to zero fails
+  if (g_fail_allocs.load() > 0 && g_fail_allocs.fetch_sub(1) == 1) return SPEEXHIP_ERR_ALLOC_FAILED;
+  const hipError_t e = hipMalloc(ptr, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    return SPEEXHIP_ERR_ALLOC_FAILED;
+  }
+  if (hip_failed(e, "hipMalloc")) return SPEEXHIP_ERR_DEVICE;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
 const size_t kLdsBudget = 150 * 1024;  // of the CU's 160 KiB
 const size_t kDirectCopyBytes = 256 * 1024;  // host buffers at least this big skip the pinned bounce buffer
 }  // namespace
 
 const char *last_device_error() { return g_last_error.c_str(); }
+void debug_fail_device_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
+
+bool Batch::uniform(uint32_t s) const {
+  const StreamPos &a = P(s, 0);
+  for (uint32_t c = 1; c < channels_; c++) {
+    const StreamPos &b = P(s, c);
+    if (a.last != b.last || a.frac != b.frac || a.magic != b.magic) return false;
+  }
+  return true;
+}
+
+uint32_t Batch::max_magic(uint32_t s) const {
+  uint32_t m = 0;
+  for (uint32_t c = 0; c < channels_; c++) m = std::max(m, P(s, c).magic);
+  return m;
+}
 
 Batch *Batch::create(uint32_t n_streams, uint32_t channels, uint32_t in_rate, uint32_t out_rate,
                      int quality, int *err) {
@@ -99,9 +134,10 @@ int Batch::setup() {
   const char *m = std::getenv("SPEEXHIP_MODE");
   if (m != nullptr && std::strcmp(m, "exact") == 0) mode_ = SPEEXHIP_MODE_EXACT;
 
-  pos_.assign(n_streams_, StreamPos());
+  pos_.assign(static_cast<size_t>(n_streams_) * channels_, StreamPos());
   started_.assign(n_streams_, 0);
-  int rc = install_filter(std::vector<float>(), filter_.taps - 1);  // resample.c:721-725: silence
+  const FilterSpec designed = filter_;
+  int rc = install_filter(designed, std::vector<float>(), designed.taps - 1);  // resample.c:721-725: silence
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   if (n_streams_ > static_cast<uint32_t>(kMaxPackedStreams)) {
     const size_t ring_bytes = sizeof(StreamDesc) * n_streams_ * kRing;
@@ -113,60 +149,86 @@ int Batch::setup() {
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-// (Re)build everything on the device that depends on filter_: the sinc table, the fast
-// kernels' tap rows and the history buffers (hist = all streams' lines, hist_frames_cap frames
-// each, interleaved; empty = silence).
-int Batch::install_filter(const std::vector<float> &hist, uint32_t hist_frames_cap) {
-  (void)hipFree(d_table_);
-  (void)hipFree(d_hist_[0]);
-  (void)hipFree(d_hist_[1]);
-  (void)hipFree(d_period_rows_);
-  (void)hipFree(d_period_fine_rows_);
-  (void)hipFree(d_slide_rows_);
-  d_table_ = d_hist_[0] = d_hist_[1] = d_period_rows_ = d_period_fine_rows_ = d_slide_rows_ = nullptr;
-  line_ = std::max(line_, filter_.taps - 1 + kBlockIn);  // grow-only, resample.c:709-720
-
-  HIP_TRY(hipMalloc(&d_table_, sizeof(float) * filter_.table_len));
-  HIP_TRY(hipMemcpy(d_table_, filter_.table.data(), sizeof(float) * filter_.table_len,
-                    hipMemcpyHostToDevice));
-  hist_elems_ = static_cast<size_t>(hist_frames_cap) * channels_;
-  const size_t hist_bytes = std::max<size_t>(hist_elems_ * n_streams_ * sizeof(float), 16);
+// Build everything on the device that depends on the filter `f` -- the sinc table, the fast
+// kernels' tap rows, the history buffers (hist = all streams' lines, hist_frames_cap frames each,
+// interleaved; empty = silence) -- and only then replace what the batch holds: a failed
+// allocation leaves the batch exactly as it was (the caller decides what a failure means,
+// resample.c:785-791).
+int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, uint32_t hist_frames_cap) {
+  struct Fresh {
+    float *table = nullptr, *hist[2] = {nullptr, nullptr}, *period = nullptr, *fine = nullptr, *slide = nullptr;
+    ~Fresh() {
+      (void)hipFree(table);
+      (void)hipFree(hist[0]);
+      (void)hipFree(hist[1]);
+      (void)hipFree(period);
+      (void)hipFree(fine);
+      (void)hipFree(slide);
+    }
+  } n;
+  auto upload = [&](float **dst, const float *src, size_t count) -> int {
+    const int rc = dev_alloc(reinterpret_cast<void **>(dst), std::max<size_t>(count * sizeof(float), 16));
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    if (count != 0) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
+    return SPEEXHIP_ERR_SUCCESS;
+  };
+  int rc = upload(&n.table, f.table.data(), f.table_len);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  const size_t hist_elems = static_cast<size_t>(hist_frames_cap) * channels_;
+  const size_t hist_bytes = std::max<size_t>(hist_elems * n_streams_ * sizeof(float), 16);
   for (int i = 0; i < 2; i++) {
-    HIP_TRY(hipMalloc(&d_hist_[i], hist_bytes));
-    HIP_TRY(hipMemset(d_hist_[i], 0, hist_bytes));
+    rc = dev_alloc(reinterpret_cast<void **>(&n.hist[i]), hist_bytes);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    HIP_TRY(hipMemset(n.hist[i], 0, hist_bytes));
   }
-  hist_cur_ = 0;
   if (!hist.empty())
-    HIP_TRY(hipMemcpy(d_hist_[0], hist.data(), hist_elems_ * n_streams_ * sizeof(float), hipMemcpyHostToDevice));
-  exact_geo_ = exact_geometry(filter_, channels_, kLdsBudget);
-  period_ = plan_period(filter_, channels_, kLdsBudget);
-  if (period_.usable) {
+    HIP_TRY(hipMemcpy(n.hist[0], hist.data(), hist_elems * n_streams_ * sizeof(float), hipMemcpyHostToDevice));
+  const ExactGeometry geo = exact_geometry(f, channels_, kLdsBudget);
+  const ExactGeometry geo_ch = exact_geometry(f, 1, kLdsBudget);
+  PeriodPlan period = plan_period(f, channels_, kLdsBudget);
+  if (period.usable) {
     std::vector<float> rows;
-    build_period_rows(filter_, period_, &rows);
-    HIP_TRY(hipMalloc(&d_period_rows_, rows.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(d_period_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    build_period_rows(f, period, &rows);
+    rc = upload(&n.period, rows.data(), rows.size());
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
-  period_fine_ = PeriodPlan();
-  if (period_.usable && period_.r == 10) {
+  PeriodPlan fine;
+  if (period.usable && period.r == 10) {
     static const bool no_fine = std::getenv("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
-    period_fine_ = plan_period_r(filter_, channels_, kLdsBudget, 5);
-    if (no_fine || period_fine_.lane_periods != period_.lane_periods) period_fine_.usable = false;
-    if (period_fine_.usable) {
+    fine = plan_period_r(f, channels_, kLdsBudget, 5);
+    if (no_fine || fine.lane_periods != period.lane_periods) fine.usable = false;
+    if (fine.usable) {
       std::vector<float> rows;
-      build_period_rows(filter_, period_fine_, &rows);
-      HIP_TRY(hipMalloc(&d_period_fine_rows_, rows.size() * sizeof(float)));
-      HIP_TRY(hipMemcpy(d_period_fine_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+      build_period_rows(f, fine, &rows);
+      rc = upload(&n.fine, rows.data(), rows.size());
+      if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     }
   }
-  slide_ = plan_slide(filter_, channels_);
-  if (slide_.usable && !period_.usable) {
+  SlidePlan slide = plan_slide(f, channels_);
+  if (slide.usable && !period.usable) {
     std::vector<float> rows;
-    build_slide_rows(filter_, slide_, &rows);
-    HIP_TRY(hipMalloc(&d_slide_rows_, rows.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(d_slide_rows_, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    build_slide_rows(f, slide, &rows);
+    rc = upload(&n.slide, rows.data(), rows.size());
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   } else {
-    slide_.usable = false;
+    slide.usable = false;
   }
+  // commit: nothing below can fail
+  std::swap(d_table_, n.table);
+  std::swap(d_hist_[0], n.hist[0]);
+  std::swap(d_hist_[1], n.hist[1]);
+  std::swap(d_period_rows_, n.period);
+  std::swap(d_period_fine_rows_, n.fine);
+  std::swap(d_slide_rows_, n.slide);  // (~Fresh releases what the batch held before)
+  filter_ = f;
+  line_ = std::max(line_, f.taps - 1 + kBlockIn);  // grow-only, resample.c:709-720
+  hist_elems_ = hist_elems;
+  hist_cur_ = 0;
+  exact_geo_ = geo;
+  exact_geo_ch_ = geo_ch;
+  period_ = period;
+  period_fine_ = fine;
+  slide_ = slide;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -180,7 +242,8 @@ int Batch::fetch_history(std::vector<float> *host) {
 }
 
 // Switch every stream to the filter `next` (already designed): the tail of update_filter(),
-// resample.c:703-782, per stream, on the host -- this is rare control-plane work.
+// resample.c:703-782, per channel, on the host -- this is rare control-plane work.  Positions and
+// device state change only if everything succeeded.
 int Batch::adopt_filter(const FilterSpec &next) {
   ON_DEVICE();
   std::vector<float> old;
@@ -188,29 +251,70 @@ int Batch::adopt_filter(const FilterSpec &next) {
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   const uint32_t old_taps = filter_.taps, new_taps = next.taps;
   const size_t old_stride = hist_elems_;
-  std::vector<Realign> moves(n_streams_);
+  std::vector<StreamPos> moved = pos_;
+  std::vector<Realign> moves(pos_.size());
   uint32_t cap_frames = new_taps - 1;
-  for (uint32_t s = 0; s < n_streams_; s++) {
-    if (started_[s]) moves[s] = realign_history(old_taps, new_taps, pos_[s].magic);
-    cap_frames = std::max(cap_frames, new_taps - 1 + (started_[s] ? moves[s].new_magic : pos_[s].magic));
-  }
+  for (uint32_t s = 0; s < n_streams_; s++)
+    for (uint32_t c = 0; c < channels_; c++) {
+      const size_t i = static_cast<size_t>(s) * channels_ + c;
+      if (started_[s]) {
+        moves[i] = realign_history(old_taps, new_taps, pos_[i].magic);
+        moved[i].magic = moves[i].new_magic;
+        moved[i].last += moves[i].last_delta;
+      }
+      cap_frames = std::max(cap_frames, new_taps - 1 + moved[i].magic);
+    }
   std::vector<float> fresh(static_cast<size_t>(cap_frames) * channels_ * n_streams_, 0.f);
   for (uint32_t s = 0; s < n_streams_; s++) {
     if (!started_[s]) continue;  // resample.c:721-726: nothing processed yet -> silence
-    const int64_t have = static_cast<int64_t>(old_taps - 1) + pos_[s].magic;
-    const uint32_t keep = new_taps - 1 + moves[s].new_magic;
     const float *src = old.data() + s * old_stride;
     float *dst = fresh.data() + static_cast<size_t>(s) * cap_frames * channels_;
-    for (uint32_t j = 0; j < keep; j++) {
-      const int64_t from = static_cast<int64_t>(j) + moves[s].shift;
-      if (from < 0 || from >= have) continue;
-      std::memcpy(dst + static_cast<size_t>(j) * channels_, src + from * channels_, sizeof(float) * channels_);
+    for (uint32_t c = 0; c < channels_; c++) {
+      const size_t i = static_cast<size_t>(s) * channels_ + c;
+      const int64_t have = static_cast<int64_t>(old_taps - 1) + pos_[i].magic;
+      const uint32_t keep = new_taps - 1 + moved[i].magic;
+      for (uint32_t j = 0; j < keep; j++) {
+        const int64_t from = static_cast<int64_t>(j) + moves[i].shift;
+        if (from < 0 || from >= have) continue;
+        dst[static_cast<size_t>(j) * channels_ + c] = src[from * channels_ + c];
+      }
     }
-    pos_[s].magic = moves[s].new_magic;
-    pos_[s].last += moves[s].last_delta;
   }
-  filter_ = next;
-  return install_filter(fresh, cap_frames);
+  rc = install_filter(next, fresh, cap_frames);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  pos_ = moved;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+// resample.c:785-791: the new filter could not be built.  The reference keeps its old filter
+// length (so its history stays where it is), has already taken the new rates / ratio / quality
+// and the advances derived from them, and installs resampler_basic_zero: outputs are zeros with
+// the right lengths until a later filter change succeeds.
+void Batch::enter_zero_mode(const FilterSpec &n) {
+  filter_.in_rate = n.in_rate;
+  filter_.out_rate = n.out_rate;
+  filter_.num = n.num;
+  filter_.den = n.den;
+  filter_.quality = n.quality;
+  filter_.int_advance = n.int_advance;
+  filter_.frac_advance = n.frac_advance;
+  zero_mode_ = true;
+}
+
+// Common tail of set_rate_frac / set_quality: `next` was designed with result design_rc; fracs =
+// every channel's phase numerator on the new denominator (set_rate_frac) or null.
+int Batch::change_filter(const FilterSpec &next, int design_rc, const std::vector<uint32_t> *fracs) {
+  int rc = design_rc;
+  if (rc == SPEEXHIP_ERR_SUCCESS) rc = adopt_filter(next);
+  if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;  // nothing was touched
+  if (fracs != nullptr)
+    for (size_t i = 0; i < pos_.size(); i++) pos_[i].frac = (*fracs)[i];
+  if (rc == SPEEXHIP_ERR_ALLOC_FAILED) {
+    enter_zero_mode(next);
+    return rc;
+  }
+  zero_mode_ = false;
+  return SPEEXHIP_ERR_SUCCESS;
 }
 
 int Batch::set_rate_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate) {
@@ -220,19 +324,17 @@ int Batch::set_rate_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rat
       filter_.den == ratio_den)
     return SPEEXHIP_ERR_SUCCESS;
   FilterSpec next;
-  int rc = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, filter_.quality, &next);
-  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  // phase numerators move to the new denominator (resample.c:1130-1139).  On overflow the
-  // reference returns with its state half-updated; here nothing has been touched yet.
-  std::vector<uint32_t> frac(n_streams_);
-  for (uint32_t s = 0; s < n_streams_; s++) {
-    frac[s] = pos_[s].frac;
-    if (!scale_phase(&frac[s], next.den, filter_.den)) return SPEEXHIP_ERR_OVERFLOW;
+  const int design_rc = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, filter_.quality, &next);
+  if (design_rc != SPEEXHIP_ERR_SUCCESS && design_rc != SPEEXHIP_ERR_ALLOC_FAILED) return design_rc;
+  // phase numerators move to the new denominator (resample.c:1130-1139; next.num / next.den are set
+  // even when the design failed later on).  On overflow the reference returns with its state
+  // half-updated; here nothing has been touched yet.
+  std::vector<uint32_t> frac(pos_.size());
+  for (size_t i = 0; i < pos_.size(); i++) {
+    frac[i] = pos_[i].frac;
+    if (!scale_phase(&frac[i], next.den, filter_.den)) return SPEEXHIP_ERR_OVERFLOW;
   }
-  rc = adopt_filter(next);
-  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  for (uint32_t s = 0; s < n_streams_; s++) pos_[s].frac = frac[s];
-  return SPEEXHIP_ERR_SUCCESS;
+  return change_filter(next, design_rc, &frac);
 }
 
 int Batch::set_quality(int quality) {
@@ -240,13 +342,14 @@ int Batch::set_quality(int quality) {
   if (quality == filter_.quality) return SPEEXHIP_ERR_SUCCESS;  // resample.c:1157-1158
   FilterSpec next;
   // the stored ratio is already reduced, so designing from it reproduces num/den
-  const int rc = design_filter_frac(filter_.num, filter_.den, filter_.in_rate, filter_.out_rate, quality, &next);
-  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  return adopt_filter(next);
+  const int design_rc =
+      design_filter_frac(filter_.num, filter_.den, filter_.in_rate, filter_.out_rate, quality, &next);
+  if (design_rc != SPEEXHIP_ERR_SUCCESS && design_rc != SPEEXHIP_ERR_ALLOC_FAILED) return design_rc;
+  return change_filter(next, design_rc, nullptr);
 }
 
 int Batch::skip_zeros() {  // resample.c:1200-1206
-  for (uint32_t s = 0; s < n_streams_; s++) pos_[s].last = static_cast<int32_t>(filter_.taps / 2);
+  for (StreamPos &p : pos_) p.last = static_cast<int32_t>(filter_.taps / 2);
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -266,7 +369,7 @@ int Batch::reset_mem() {  // resample.c:1208-1220
       const uint64_t first = static_cast<uint64_t>(c) * line_;
       for (uint32_t j = 0; j + 1 < filter_.taps && first + j < run; j++) line[static_cast<size_t>(j) * channels_ + c] = 0.f;
     }
-    pos_[s] = StreamPos();
+    for (uint32_t c = 0; c < channels_; c++) P(s, c) = StreamPos();
   }
   if (!h.empty())
     HIP_TRY(hipMemcpy(d_hist_[hist_cur_], h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -298,7 +401,8 @@ CallPlan Batch::peek(uint32_t s, uint32_t in_len, uint32_t out_capacity, bool fl
   EntryRules rules;
   rules.block_in = block_in();
   rules.float_entry = float_io;
-  return plan_call(filter_.num, filter_.den, in_len, out_capacity, pos_[s], rules);
+  // (an interleaved call reports the counters of its LAST channel, resample.c:1070-1078)
+  return plan_call(filter_.num, filter_.den, in_len, out_capacity, P(s, channels_ - 1), rules);
 }
 
 int Batch::set_mode(int mode) {
@@ -322,9 +426,9 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
   o->mode = mode_;
   o->fast_path = period_.usable ? 2 : (slide_.usable ? 3 : 0);
   if (s < n_streams_) {
-    o->last_sample = pos_[s].last;
-    o->samp_frac_num = pos_[s].frac;
-    o->magic_samples = pos_[s].magic;
+    o->last_sample = P(s, 0).last;
+    o->samp_frac_num = P(s, 0).frac;
+    o->magic_samples = P(s, 0).magic;
   }
   o->block_in = block_in();
   o->device = device_;
@@ -334,7 +438,7 @@ int Batch::history(uint32_t s, float *dst) {
   if (s >= n_streams_) return SPEEXHIP_ERR_INVALID_ARG;
   ON_DEVICE();
   HIP_TRY(hipDeviceSynchronize());
-  const size_t n = static_cast<size_t>(filter_.taps - 1 + pos_[s].magic) * channels_;
+  const size_t n = static_cast<size_t>(filter_.taps - 1 + max_magic(s)) * channels_;
   if (n)
     HIP_TRY(hipMemcpy(dst, d_hist_[hist_cur_] + s * hist_elems_, n * sizeof(float), hipMemcpyDeviceToHost));
   return SPEEXHIP_ERR_SUCCESS;
@@ -348,9 +452,16 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
   EntryRules rules;
   rules.block_in = block_in();
   rules.float_entry = float_io;
+  for (uint32_t s = 0; s < n_streams_; s++)
+    if (!uniform(s)) {
+      // channels that the per-channel entry points moved apart: one channel at a time, as the
+      // reference's interleaved call does (resample.c:1061-1082)
+      if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
+      return process_split(d_in, in_len, d_out, out_len, float_io, stream, nullptr);
+    }
   std::vector<CallPlan> plans(n_streams_);
   for (uint32_t s = 0; s < n_streams_; s++) {
-    plans[s] = plan_call(filter_.num, filter_.den, in_len[s], out_len[s], pos_[s], rules);
+    plans[s] = plan_call(filter_.num, filter_.den, in_len[s], out_len[s], P(s, 0), rules);
     // resample.c:886: any block run marks the state as started
     if (in_len[s] != 0 && out_len[s] != 0) started_[s] = 1;
   }
@@ -360,7 +471,78 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
     in_len[s] = plans[s].consumed;
     out_len[s] = plans[s].produced;
   }
+  // resample.c:1081 (and :962, :1035): with resampler_basic_zero installed every call reports the failure
+  return zero_mode_ ? SPEEXHIP_ERR_ALLOC_FAILED : SPEEXHIP_ERR_SUCCESS;
+}
+
+// One channel of a single-stream batch from plan.begin to plan.end on device buffers whose frames
+// are in_stride / out_stride samples apart (the exact kernel on one channel; bit-exact in both
+// modes).  The history ping-pong is per stream, so the channel's new line is copied back beside
+// the other channels' lines.
+int Batch::run_channel(uint32_t c, const void *d_in, uint32_t in_stride, uint32_t in_frames, void *d_out,
+                       uint32_t out_stride, const CallPlan &plan, bool float_io, hipStream_t stream) {
+  const uint32_t walked = plan.magic_used + plan.consumed;
+  if (plan.produced == 0 && walked == 0) return SPEEXHIP_ERR_SUCCESS;
+  if (have_last_stream_ && stream != last_stream_) {
+    if (order_ev_ == nullptr) HIP_TRY(hipEventCreateWithFlags(&order_ev_, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(order_ev_, last_stream_));
+    HIP_TRY(hipStreamWaitEvent(stream, order_ev_, 0));
+  }
+  last_stream_ = stream;
+  have_last_stream_ = true;
+  DescPack pack;
+  std::memset(&pack, 0, sizeof(pack));
+  StreamDesc &d = pack.d[0];
+  d.in = d_in;
+  d.hist = d_hist_[hist_cur_] + c;
+  d.out = d_out;
+  d.hist_next = d_hist_[hist_cur_ ^ 1] + c;
+  d.in_frames = in_frames;
+  d.n_out = plan.produced;
+  d.consumed = walked;
+  d.hist_frames = filter_.taps - 1 + plan.begin.magic;
+  d.hist_keep = filter_.taps - 1 + plan.end.magic;
+  d.last0 = plan.begin.last;
+  d.frac0 = plan.begin.frac;
+  const ExactStrides strides = {in_stride, out_stride, channels_};
+  ExactGeometry geo = exact_geo_ch_;
+  if (zero_mode_) {  // the window geometry belongs to the filter that is no longer in force
+    geo.staged = false;
+    geo.lds_bytes = 0;
+    geo.outs_per_block = 256;
+  }
+  const hipError_t e = launch_exact(filter_, geo, d_table_, 1, nullptr, &pack, 1, plan.produced, float_io, stream,
+                                    &strides, zero_mode_);
+  if (hip_failed(e, "kernel launch")) return SPEEXHIP_ERR_DEVICE;
+  if (d.hist_keep != 0)
+    HIP_TRY(hipMemcpy2DAsync(d_hist_[hist_cur_] + c, channels_ * sizeof(float), d_hist_[hist_cur_ ^ 1] + c,
+                             channels_ * sizeof(float), sizeof(float), d.hist_keep, hipMemcpyDeviceToDevice,
+                             stream));
   return SPEEXHIP_ERR_SUCCESS;
+}
+
+// The interleaved call on a stream whose channels stand at different positions: channel by
+// channel with the caller's lengths restored before each, the lengths of the LAST channel
+// reported (resample.c:1061-1082).  d_in / d_out: interleaved device buffers.
+int Batch::process_split(const void *d_in, uint32_t *in_len, void *d_out, uint32_t *out_len, bool float_io,
+                         hipStream_t stream, std::vector<CallPlan> *plans_out) {
+  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
+  EntryRules rules;
+  rules.block_in = block_in();
+  rules.float_entry = float_io;
+  const uint32_t want_in = *in_len, want_out = *out_len;
+  if (want_in != 0 && want_out != 0) started_[0] = 1;
+  for (uint32_t c = 0; c < channels_; c++) {
+    const CallPlan plan = plan_call(filter_.num, filter_.den, want_in, want_out, P(0, c), rules);
+    const int rc = run_channel(c, d_in ? static_cast<const char *>(d_in) + c * es : nullptr, channels_, want_in,
+                               static_cast<char *>(d_out) + c * es, channels_, plan, float_io, stream);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    P(0, c) = plan.end;
+    *in_len = plan.consumed;
+    *out_len = plan.produced;
+    if (plans_out) plans_out->push_back(plan);
+  }
+  return zero_mode_ ? SPEEXHIP_ERR_ALLOC_FAILED : SPEEXHIP_ERR_SUCCESS;
 }
 
 // One launch that carries every stream from plans[s].begin to plans[s].end.  in_frames[s] =
@@ -426,7 +608,14 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       d_descs = dst;
     }
     hipError_t e;
-    if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)
+    if (zero_mode_) {
+      ExactGeometry geo = exact_geo_;  // (its window geometry belongs to the filter no longer in force)
+      geo.staged = false;
+      geo.lds_bytes = 0;
+      geo.outs_per_block = 256;
+      e = launch_exact(filter_, geo, d_table_, channels_, d_descs, packed ? &pack : nullptr, n_streams_, max_out,
+                       float_io, stream, nullptr, true);
+    } else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)
       e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs,
                         d_descs, packed ? &pack : nullptr, n_streams_, float_io, stream);
     else if (mode_ == SPEEXHIP_MODE_FAST && slide_.usable)
@@ -442,7 +631,8 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
     }
     hist_cur_ ^= 1;
   }
-  for (uint32_t s = 0; s < n_streams_; s++) pos_[s] = plans[s].end;
+  for (uint32_t s = 0; s < n_streams_; s++)
+    for (uint32_t c = 0; c < channels_; c++) P(s, c) = plans[s].end;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -478,9 +668,11 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   ON_DEVICE();
   const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
   const uint32_t frames = *in_len;
+  const bool split = !uniform(0);
   // only as many output frames as this call can produce need a device buffer
-  const uint32_t will_make =
-      produced_closed_form(filter_.num, filter_.den, frames, *out_len, pos_[0]);
+  uint32_t will_make = 0;
+  for (uint32_t c = 0; c < (split ? channels_ : 1u); c++)
+    will_make = std::max(will_make, produced_closed_form(filter_.num, filter_.den, frames, *out_len, P(0, c)));
   const size_t in_bytes = static_cast<size_t>(frames) * channels_ * es;
   const size_t out_bytes = static_cast<size_t>(will_make) * channels_ * es;
   int rc = ensure_stage(in_bytes, out_bytes);
@@ -489,7 +681,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   // copies itself and does it 2.2-2.5x faster than memcpy -> pinned -> DMA in one thread (2^20
   // stereo frames: 0.46 -> 0.21 ms per call, 8 channels 1.57 -> 0.63 ms).  Small ones keep the
   // pinned bounce buffers (a few % faster below ~256 KB).
-  const bool direct_in = in_bytes >= kDirectCopyBytes, direct_out = out_bytes >= kDirectCopyBytes;
+  const bool direct_in = in_bytes >= kDirectCopyBytes, direct_out = out_bytes >= kDirectCopyBytes && !split;
   if (in != nullptr && in_bytes != 0) {
     if (direct_in) {
       HIP_TRY(hipMemcpyAsync(d_stage_in_, in, in_bytes, hipMemcpyHostToDevice, own_stream_));
@@ -498,15 +690,72 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
       HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, in_bytes, hipMemcpyHostToDevice, own_stream_));
     }
   }
+  if (split) {
+    // channels at different positions write different numbers of frames: fetch the whole block
+    // and hand the caller only the samples each channel really wrote
+    std::vector<CallPlan> plans;
+    rc = process_split(in != nullptr ? d_stage_in_ : nullptr, in_len, d_stage_out_, out_len, float_io, own_stream_,
+                       &plans);
+    if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
+    uint32_t most = 0;
+    for (const CallPlan &pl : plans) most = std::max(most, pl.produced);
+    const size_t bytes = static_cast<size_t>(most) * channels_ * es;
+    if (bytes != 0) HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, bytes, hipMemcpyDeviceToHost, own_stream_));
+    HIP_TRY(hipStreamSynchronize(own_stream_));
+    for (uint32_t c = 0; c < channels_; c++)
+      for (uint32_t j = 0; j < plans[c].produced; j++)
+        std::memcpy(static_cast<char *>(out) + (static_cast<size_t>(j) * channels_ + c) * es,
+                    h_pin_out_ + (static_cast<size_t>(j) * channels_ + c) * es, es);
+    return rc;
+  }
   rc = process_device(in != nullptr ? d_stage_in_ : nullptr, 0, in_len, d_stage_out_, 0, out_len, float_io,
                       own_stream_);
-  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
   const size_t made = static_cast<size_t>(*out_len) * channels_ * es;
   if (made != 0)
     HIP_TRY(hipMemcpyAsync(direct_out ? out : h_pin_out_, d_stage_out_, made, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
   if (made != 0 && !direct_out) std::memcpy(out, h_pin_out_, made);
-  return SPEEXHIP_ERR_SUCCESS;
+  return rc;
+}
+
+// speex_resampler_process_int / _process_float (resample.c:927-1036): ONE channel, host buffers
+// whose samples are in_stride_ / out_stride_ apart (resample.c:1170-1188).  The samples travel as a
+// dense line; the state's other channels are not touched.
+int Batch::process_channel_host(uint32_t c, const void *in, uint32_t *in_len, void *out, uint32_t *out_len,
+                                bool float_io) {
+  if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
+  if (c >= channels_) return SPEEXHIP_ERR_INVALID_ARG;
+  ON_DEVICE();
+  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
+  EntryRules rules;
+  rules.block_in = block_in();
+  rules.float_entry = float_io;
+  const uint32_t frames = *in_len;
+  const CallPlan plan = plan_call(filter_.num, filter_.den, frames, *out_len, P(0, c), rules);
+  if (frames != 0 && *out_len != 0) started_[0] = 1;
+  int rc = ensure_stage(static_cast<size_t>(frames) * es, static_cast<size_t>(plan.produced) * es);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  if (in != nullptr && frames != 0) {
+    for (uint32_t j = 0; j < frames; j++)
+      std::memcpy(h_pin_in_ + static_cast<size_t>(j) * es,
+                  static_cast<const char *>(in) + static_cast<size_t>(j) * in_stride_ * es, es);
+    HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, static_cast<size_t>(frames) * es, hipMemcpyHostToDevice,
+                           own_stream_));
+  }
+  rc = run_channel(c, in != nullptr ? d_stage_in_ : nullptr, 1, frames, d_stage_out_, 1, plan, float_io, own_stream_);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  if (plan.produced != 0)
+    HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, static_cast<size_t>(plan.produced) * es, hipMemcpyDeviceToHost,
+                           own_stream_));
+  HIP_TRY(hipStreamSynchronize(own_stream_));
+  for (uint32_t j = 0; j < plan.produced; j++)
+    std::memcpy(static_cast<char *>(out) + static_cast<size_t>(j) * out_stride_ * es,
+                h_pin_out_ + static_cast<size_t>(j) * es, es);
+  P(0, c) = plan.end;
+  *in_len = plan.consumed;
+  *out_len = plan.produced;
+  return zero_mode_ ? SPEEXHIP_ERR_ALLOC_FAILED : SPEEXHIP_ERR_SUCCESS;
 }
 
 // A sequence of calls on one stream as one transfer and (normally) one launch.  Every output
@@ -523,6 +772,16 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
   if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
   ON_DEVICE();
   const size_t fb = (float_io ? sizeof(float) : sizeof(int16_t)) * channels_;  // bytes per frame
+  if (!uniform(0) || zero_mode_) {  // rare states: the separate calls, one after the other
+    int last = SPEEXHIP_ERR_SUCCESS;
+    char *o = static_cast<char *>(out);
+    for (uint32_t i = 0; i < n_chunks; i++) {
+      last = process_host(in != nullptr ? in[i] : nullptr, &in_len[i], o, &out_len[i], float_io);
+      if (last != SPEEXHIP_ERR_SUCCESS && last != SPEEXHIP_ERR_ALLOC_FAILED) return last;
+      o += static_cast<size_t>(out_len[i]) * fb;
+    }
+    return last;
+  }
   EntryRules rules;
   rules.block_in = block_in();
   rules.float_entry = float_io;
@@ -533,7 +792,7 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
   };
   std::vector<CallPlan> plans(n_chunks);
   std::vector<Group> groups;
-  StreamPos pos = pos_[0];
+  StreamPos pos = P(0, 0);
   uint64_t frames = 0, made = 0;
   bool open = false;
   for (uint32_t i = 0; i < n_chunks; i++) {

@@ -16,6 +16,8 @@
 namespace speexhip {
 
 const char *last_device_error();  // text of the most recent HIP failure on this thread
+// Test hook: the n-th next device allocation of a filter install fails (resample.c:785-791 path); 0 = off.
+void debug_fail_device_allocs(int n);
 
 class Batch {
  public:
@@ -38,6 +40,21 @@ class Batch {
   // written back to back into `out` (room for the sum of the capacities).
   int process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_t *in_len, void *out,
                           uint32_t *out_len, bool float_io);
+  // One channel of a single-stream batch through host buffers with the state's input / output
+  // strides: speex_resampler_process_int / _process_float (resample.c:927-1036).  Channels
+  // advance independently, as in the reference (per-channel last_sample / samp_frac_num /
+  // magic_samples, resample.c:135-137).
+  int process_channel_host(uint32_t channel, const void *in, uint32_t *in_len, void *out, uint32_t *out_len,
+                           bool float_io);
+  void set_strides(uint32_t in_stride, uint32_t out_stride, bool set_in, bool set_out) {
+    if (set_in) in_stride_ = in_stride;
+    if (set_out) out_stride_ = out_stride;
+  }
+  uint32_t in_stride() const { return in_stride_; }
+  uint32_t out_stride() const { return out_stride_; }
+  // position of one channel (resample.c last_sample / samp_frac_num / magic_samples)
+  StreamPos channel_pos(uint32_t s, uint32_t c) const { return pos_[static_cast<size_t>(s) * channels_ + c]; }
+  bool zero_mode() const { return zero_mode_; }
 
   // Mid-stream control (reference resample.c:1084-1220).  These wait for the
   // device, re-align every stream's history on the host (resample.c:727-782) and rebuild the
@@ -59,12 +76,23 @@ class Batch {
   int history(uint32_t stream, float *dst);
   const FilterSpec &filter() const { return filter_; }
   uint32_t n_streams() const { return n_streams_; }
+  uint32_t channels() const { return channels_; }
 
  private:
   Batch() = default;
   int setup();
-  int install_filter(const std::vector<float> &hist, uint32_t hist_frames_cap);
+  int install_filter(const FilterSpec &f, const std::vector<float> &hist, uint32_t hist_frames_cap);
   int adopt_filter(const FilterSpec &next);
+  int change_filter(const FilterSpec &next, int design_rc, const std::vector<uint32_t> *fracs);
+  void enter_zero_mode(const FilterSpec &partly_designed);
+  StreamPos &P(uint32_t s, uint32_t c) { return pos_[static_cast<size_t>(s) * channels_ + c]; }
+  const StreamPos &P(uint32_t s, uint32_t c) const { return pos_[static_cast<size_t>(s) * channels_ + c]; }
+  bool uniform(uint32_t s) const;  // all channels of stream s at the same position
+  uint32_t max_magic(uint32_t s) const;
+  int run_channel(uint32_t c, const void *d_in, uint32_t in_stride, uint32_t in_frames, void *d_out,
+                  uint32_t out_stride, const CallPlan &plan, bool float_io, hipStream_t stream);
+  int process_split(const void *d_in, uint32_t *in_len, void *d_out, uint32_t *out_len, bool float_io,
+                    hipStream_t stream, std::vector<CallPlan> *plans_out);
   int fetch_history(std::vector<float> *host);
   uint32_t block_in() const { return line_ - (filter_.taps - 1); }
   int ensure_stage(size_t in_bytes, size_t out_bytes);
@@ -75,7 +103,12 @@ class Batch {
   uint32_t n_streams_ = 0, channels_ = 0;
   int device_ = 0;
   int mode_ = SPEEXHIP_MODE_FAST;
-  std::vector<StreamPos> pos_;
+  std::vector<StreamPos> pos_;    // [stream][channel] (the reference keeps them per channel, resample.c:135-137;
+                                  // interleaved calls move all channels of a stream together)
+  bool zero_mode_ = false;        // resampler_ptr == resampler_basic_zero (resample.c:785-791): the last
+                                  // filter change failed; outputs are zeros until one succeeds
+  uint32_t in_stride_ = 1, out_stride_ = 1;  // resample.c:842-843, 1170-1188 (per-channel entry points)
+  ExactGeometry exact_geo_ch_;    // the exact kernel's geometry for one-channel launches
   std::vector<uint8_t> started_;  // per stream: a block has run (resample.c:886), so a filter
                                   // change must re-align the history instead of clearing it
   uint32_t line_ = 0;             // frames per channel line, grow-only (resample.c

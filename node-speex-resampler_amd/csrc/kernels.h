@@ -50,9 +50,15 @@ struct ExactGeometry {
   bool staged = true;          // false: filter/window too large for LDS, read through L2
 };
 ExactGeometry exact_geometry(const FilterSpec &f, uint32_t channels, size_t lds_budget);
+// strides (samples between two frames of a channel) of a launch that is not a plain interleaved one;
+// zero = resampler_basic_zero (resample.c:561-591)
+struct ExactStrides {
+  uint32_t in, out, hist;
+};
 hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float *d_table,
                         uint32_t channels, const StreamDesc *d_descs, const DescPack *pack,
-                        uint32_t n_streams, uint32_t max_n_out, bool float_io, hipStream_t stream);
+                        uint32_t n_streams, uint32_t max_n_out, bool float_io, hipStream_t stream,
+                        const ExactStrides *strides = nullptr, bool zero = false);
 
 // ---- primary fast kernel: period-lane mapping, taps in SGPRs (kernels_period.hip) ----------
 struct PeriodPlan {         // per filter, fixed at init

@@ -32,12 +32,12 @@ namespace {
 
 // V = history ++ input at V-frame v, channel c (history is float, the input has the call's type T)
 template <typename T>
-__device__ __forceinline__ float virtual_sample(const StreamDesc &d, uint32_t hist_frames,
-                                                uint32_t channels, int64_t v, uint32_t c) {
-  if (v < static_cast<int64_t>(hist_frames)) return hist_ptr(d)[v * channels + c];
+__device__ __forceinline__ float virtual_sample(const StreamDesc &d, uint32_t hist_frames, uint32_t hist_stride,
+                                                uint32_t in_stride, int64_t v, uint32_t c) {
+  if (v < static_cast<int64_t>(hist_frames)) return hist_ptr(d)[v * hist_stride + c];
   v -= hist_frames;
   if (d.in == nullptr || v >= static_cast<int64_t>(d.in_frames)) return 0.f;
-  return static_cast<float>(in_ptr<T>(d)[v * channels + c]);
+  return static_cast<float>(in_ptr<T>(d)[v * in_stride + c]);
 }
 
 // reference arch.h:208-209 -- the add and the floor are double
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
   const uint32_t hist_frames = d.hist_frames;
 
   if (blockIdx.x == gridDim.x - 1) {  // one extra workgroup per stream rolls the history
-    if (blockIdx.z == 0) roll_history<T>(p.channels, d, p.outs_per_block);
+    if (blockIdx.z == 0) roll_history<T>(p.channels, d, p.outs_per_block, p.in_stride, p.hist_stride);
     return;
   }
   const uint32_t k_first = blockIdx.x * p.outs_per_block;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
     for (uint32_t i = threadIdx.x; i < span * CT; i += p.outs_per_block) {
       const uint32_t f = i / CT, ct = i - f * CT;
       const uint32_t c = c_first + ct;
-      xs_lds[i] = c < C ? virtual_sample<T>(d, hist_frames, C, base + f, c) : 0.f;
+      xs_lds[i] = c < C ? virtual_sample<T>(d, hist_frames, p.hist_stride, p.in_stride, base + f, c) : 0.f;
     }
     __syncthreads();
     tab = tab_lds;
@@ -109,11 +109,14 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
   auto sample = [&](int j, int ct) -> float {
     if (STAGED) return xs[(rel + j) * CT + ct];
     const uint32_t c = c_first + ct;
-    return c < C ? virtual_sample<T>(d, hist_frames, C, pos + j, c) : 0.f;
+    return c < C ? virtual_sample<T>(d, hist_frames, p.hist_stride, p.in_stride, pos + j, c) : 0.f;
   };
 
   float y[CT];
-  if (KIND == kDirectSingle) {
+  if (p.zero) {  // resample.c:561-591: the filter could not be built -- lengths stay right, samples are zero
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) y[ct] = 0.f;
+  } else if (KIND == kDirectSingle) {
     const float *h = tab + static_cast<size_t>(phase) * n;
     float s[CT];
 #pragma unroll
@@ -194,12 +197,12 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
   }
 
   if constexpr (sizeof(T) == 4) {  // float I/O: no rounding
-    G<float> *o = out_ptr<float>(d) + static_cast<size_t>(k) * C + c_first;
+    G<float> *o = out_ptr<float>(d) + static_cast<size_t>(k) * p.out_stride + c_first;
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
       if (c_first + ct < C) o[ct] = y[ct];
   } else {
-    G<int16_t> *o = out_ptr<int16_t>(d) + static_cast<size_t>(k) * C + c_first;
+    G<int16_t> *o = out_ptr<int16_t>(d) + static_cast<size_t>(k) * p.out_stride + c_first;
     if (CT == 2 && c_first + 1 < C && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
       // both channels of an even-channel frame: one aligned 32-bit store
       const uint32_t packed = static_cast<uint16_t>(word2int(y[0])) |
@@ -281,7 +284,8 @@ ExactGeometry exact_geometry(const FilterSpec &f, uint32_t channels, size_t lds_
 
 hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float *d_table,
                         uint32_t channels, const StreamDesc *d_descs, const DescPack *pack,
-                        uint32_t n_streams, uint32_t max_n_out, bool float_io, hipStream_t stream) {
+                        uint32_t n_streams, uint32_t max_n_out, bool float_io, hipStream_t stream,
+                        const ExactStrides *strides, bool zero) {
   ExactParams p;
   p.table = d_table;
   p.table_len = f.table_len;
@@ -292,6 +296,10 @@ hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float
   p.channels = channels;
   p.outs_per_block = g.outs_per_block;
   p.span_cap = g.span_cap;
+  p.in_stride = strides ? strides->in : channels;
+  p.out_stride = strides ? strides->out : channels;
+  p.hist_stride = strides ? strides->hist : channels;
+  p.zero = zero ? 1u : 0u;
   const uint32_t blocks = (max_n_out + g.outs_per_block - 1) / g.outs_per_block;
   dim3 grid(blocks + 1, n_streams, g.channel_groups);
   return float_io ? launch_typed<float>(f, p, d_descs, pack, g, grid, stream)

@@ -39,6 +39,11 @@ EXPORTS = [
     # chunk coalescing
     "speexhip_resampler_process_chunks_int", "speexhip_resampler_process_chunks_float",
     "speexhip_resampler_peek",
+    # per-channel entry points + strides (rest of row N2), the zero fallback's test hook (row a6)
+    "speexhip_resampler_process_int", "speexhip_resampler_process_float",
+    "speexhip_resampler_set_input_stride", "speexhip_resampler_get_input_stride",
+    "speexhip_resampler_set_output_stride", "speexhip_resampler_get_output_stride",
+    "speexhip_resampler_get_channel_position", "speexhip_debug_fail_device_allocs",
 ]
 
 
@@ -141,6 +146,20 @@ def lib():
             f.argtypes = [p, u32, C.POINTER(C.c_void_p), pu32, p, pu32]
         L.speexhip_resampler_peek.restype = i32
         L.speexhip_resampler_peek.argtypes = [p, u32, u32, i32, pu32, pu32]
+        L.speexhip_resampler_process_int.restype = i32
+        L.speexhip_resampler_process_int.argtypes = [p, u32, pi16, pu32, pi16, pu32]
+        L.speexhip_resampler_process_float.restype = i32
+        L.speexhip_resampler_process_float.argtypes = [p, u32, pf32, pu32, pf32, pu32]
+        for f in (L.speexhip_resampler_set_input_stride, L.speexhip_resampler_set_output_stride):
+            f.restype = None
+            f.argtypes = [p, u32]
+        for f in (L.speexhip_resampler_get_input_stride, L.speexhip_resampler_get_output_stride):
+            f.restype = None
+            f.argtypes = [p, pu32]
+        L.speexhip_resampler_get_channel_position.restype = i32
+        L.speexhip_resampler_get_channel_position.argtypes = [p, u32, pi32, pu32, pu32]
+        L.speexhip_debug_fail_device_allocs.restype = None
+        L.speexhip_debug_fail_device_allocs.argtypes = [i32]
         _lib = L
     return _lib
 
@@ -300,6 +319,51 @@ class Resampler:
     def history(self):
         """(taps-1, channels) float32: the reference's `mem` after the last call"""
         return self._lines()[: self.taps - 1].copy()
+
+    # ---- raw calls: same names and results as oracle._RawMixin (return code + whole buffer) ----
+    SENTINEL_I16, SENTINEL_F32 = 0x5A5A, 1234.5
+
+    def raw_call(self, kind, x, cap, null_frames=0):
+        dt, cdt, fill = ((np.int16, C.c_int16, self.SENTINEL_I16) if kind == "int" else
+                         (np.float32, C.c_float, self.SENTINEL_F32))
+        if x is None:
+            ptr, n = None, int(null_frames)
+        else:
+            x = np.ascontiguousarray(x, dtype=dt).reshape(-1, self.channels)
+            ptr, n = x.ctypes.data_as(C.POINTER(cdt)), x.shape[0]
+        out = np.full((max(int(cap), 1), self.channels), fill, dt)
+        il, ol = C.c_uint32(n), C.c_uint32(int(cap))
+        fn = (lib().speexhip_resampler_process_interleaved_int if kind == "int"
+              else lib().speexhip_resampler_process_interleaved_float)
+        rc = fn(self._h, ptr, C.byref(il), out.ctypes.data_as(C.POINTER(cdt)), C.byref(ol))
+        return rc, il.value, ol.value, out
+
+    def channel_call(self, kind, c, x, cap, in_stride=1, out_stride=1, null_frames=0):
+        dt, cdt, fill = ((np.int16, C.c_int16, self.SENTINEL_I16) if kind == "int" else
+                         (np.float32, C.c_float, self.SENTINEL_F32))
+        lib().speexhip_resampler_set_input_stride(self._h, in_stride)
+        lib().speexhip_resampler_set_output_stride(self._h, out_stride)
+        if x is None:
+            ptr, n = None, int(null_frames)
+        else:
+            x = np.asarray(x, dtype=dt).reshape(-1)
+            n = x.shape[0]
+            buf = np.full(max((n - 1) * in_stride + 1, 1), fill, dt)
+            buf[: (n - 1) * in_stride + 1: in_stride] = x
+            ptr = buf.ctypes.data_as(C.POINTER(cdt))
+        out = np.full(max((int(cap) - 1) * out_stride + 1, 1), fill, dt)
+        il, ol = C.c_uint32(n), C.c_uint32(int(cap))
+        fn = lib().speexhip_resampler_process_int if kind == "int" else lib().speexhip_resampler_process_float
+        rc = fn(self._h, c, ptr, C.byref(il), out.ctypes.data_as(C.POINTER(cdt)), C.byref(ol))
+        return rc, il.value, ol.value, out
+
+    def positions(self):
+        res = []
+        for c in range(self.channels):
+            a, b, m = C.c_int32(), C.c_uint32(), C.c_uint32()
+            lib().speexhip_resampler_get_channel_position(self._h, c, C.byref(a), C.byref(b), C.byref(m))
+            res.append((a.value, b.value, m.value))
+        return res
 
     def process(self, frames, out_capacity, null_frames=0):
         """frames=None: the reference's in == NULL case (null_frames frames of silence)."""

@@ -97,7 +97,56 @@ class _FloatMixin:
         return out[: ol.value].copy(), il.value
 
 
-class Oracle(_Base, _FloatMixin):
+SENTINEL_I16 = 0x5A5A   # what the raw calls below pre-fill their output buffers with:
+SENTINEL_F32 = 1234.5   # every sample a call does NOT write must still hold it afterwards
+
+
+class _RawMixin:
+    """Calls that return the return code and the WHOLE output buffer (pre-filled with a sentinel),
+    for states whose channels stand at different positions and for the per-channel entry points
+    (speex_resampler_process_int / _process_float with strides, resample.c:927-1036, 1170-1188).
+    Same method names on Oracle, Reference and the HIP mirror (speexhip.Resampler)."""
+
+    def raw_call(self, kind, x, cap, null_frames=0):
+        """kind 'int' | 'float'; x: (frames, ch) array or None.  -> (rc, used, produced, out[cap, ch])"""
+        dt, cdt, fill = ((np.int16, C.c_int16, SENTINEL_I16) if kind == "int" else
+                         (np.float32, C.c_float, SENTINEL_F32))
+        if x is None:
+            ptr, n = None, int(null_frames)
+        else:
+            x = np.ascontiguousarray(x, dtype=dt).reshape(-1, self.channels)
+            ptr, n = x.ctypes.data_as(C.POINTER(cdt)), x.shape[0]
+        out = np.full((max(int(cap), 1), self.channels), fill, dt)
+        il, ol = C.c_uint32(n), C.c_uint32(int(cap))
+        rc = self._raw_interleaved(kind, ptr, C.byref(il), out.ctypes.data_as(C.POINTER(cdt)), C.byref(ol))
+        return rc, il.value, ol.value, out
+
+    def channel_call(self, kind, c, x, cap, in_stride=1, out_stride=1, null_frames=0):
+        """One channel: x = that channel's samples (1-D) or None.  The samples are laid out
+        `in_stride` apart in a sentinel-filled buffer, the output buffer holds cap samples
+        `out_stride` apart.  -> (rc, used, produced, whole output buffer)"""
+        dt, cdt, fill = ((np.int16, C.c_int16, SENTINEL_I16) if kind == "int" else
+                         (np.float32, C.c_float, SENTINEL_F32))
+        self._set_strides(in_stride, out_stride)
+        if x is None:
+            ptr, n = None, int(null_frames)
+        else:
+            x = np.asarray(x, dtype=dt).reshape(-1)
+            n = x.shape[0]
+            buf = np.full(max((n - 1) * in_stride + 1, 1), fill, dt)
+            buf[: (n - 1) * in_stride + 1: in_stride] = x
+            ptr = buf.ctypes.data_as(C.POINTER(cdt))
+        out = np.full(max((int(cap) - 1) * out_stride + 1, 1), fill, dt)
+        il, ol = C.c_uint32(n), C.c_uint32(int(cap))
+        rc = self._raw_channel(kind, c, ptr, C.byref(il), out.ctypes.data_as(C.POINTER(cdt)), C.byref(ol))
+        return rc, il.value, ol.value, out
+
+    def positions(self):
+        """[(last_sample, samp_frac_num, magic_samples)] per channel"""
+        return [self._chan_pos(c) for c in range(self.channels)]
+
+
+class Oracle(_Base, _FloatMixin, _RawMixin):
     """Our CPU restatement."""
 
     _lib = None
@@ -138,6 +187,16 @@ class Oracle(_Base, _FloatMixin):
                 f.argtypes = [C.c_void_p]
             L.orc_pending.restype = C.c_uint32
             L.orc_pending.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+            L.orc_process_int.restype = C.c_int
+            L.orc_process_int.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int16), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]
+            L.orc_process_float.restype = C.c_int
+            L.orc_process_float.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32),
+                                            C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+            L.orc_set_input_stride.argtypes = [C.c_void_p, C.c_uint32]
+            L.orc_set_output_stride.argtypes = [C.c_void_p, C.c_uint32]
+            L.orc_channel_position.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
             cls._lib = L
         return cls._lib
 
@@ -217,6 +276,22 @@ class Oracle(_Base, _FloatMixin):
     def _process_float(self, i, il, o, ol):
         return self.lib().orc_process_interleaved_float(self._h, i, il, o, ol)
 
+    def _raw_interleaved(self, kind, i, il, o, ol):
+        return (self._process if kind == "int" else self._process_float)(i, il, o, ol)
+
+    def _raw_channel(self, kind, c, i, il, o, ol):
+        fn = self.lib().orc_process_int if kind == "int" else self.lib().orc_process_float
+        return fn(self._h, c, i, il, o, ol)
+
+    def _set_strides(self, a, b):
+        self.lib().orc_set_input_stride(self._h, a)
+        self.lib().orc_set_output_stride(self._h, b)
+
+    def _chan_pos(self, c):
+        a, b, m = C.c_int32(), C.c_uint32(), C.c_uint32()
+        self.lib().orc_channel_position(self._h, c, C.byref(a), C.byref(b), C.byref(m))
+        return a.value, b.value, m.value
+
     def table(self):
         p = self.lib().orc_table(self._h)
         return np.ctypeslib.as_array(p, shape=(self.table_len,)).copy()
@@ -253,7 +328,7 @@ class _RefState(C.Structure):
     ]
 
 
-class Reference(_Base, _FloatMixin):
+class Reference(_Base, _FloatMixin, _RawMixin):
     """The reference's own C implementation (oracle/_ref/libspeexref.so)."""
 
     _lib = None
@@ -288,6 +363,15 @@ class Reference(_Base, _FloatMixin):
             for f in (L.speex_resampler_get_input_latency, L.speex_resampler_get_output_latency,
                       L.speex_resampler_skip_zeros, L.speex_resampler_reset_mem):
                 f.argtypes = [P]
+            L.speex_resampler_process_int.restype = C.c_int
+            L.speex_resampler_process_int.argtypes = [P, C.c_uint32, C.POINTER(C.c_int16), C.POINTER(C.c_uint32),
+                                                      C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]
+            L.speex_resampler_process_float.restype = C.c_int
+            L.speex_resampler_process_float.argtypes = [P, C.c_uint32, C.POINTER(C.c_float),
+                                                        C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                                                        C.POINTER(C.c_uint32)]
+            L.speex_resampler_set_input_stride.argtypes = [P, C.c_uint32]
+            L.speex_resampler_set_output_stride.argtypes = [P, C.c_uint32]
             cls._lib = L
         return cls._lib
 
@@ -371,6 +455,22 @@ class Reference(_Base, _FloatMixin):
 
     def _process_float(self, i, il, o, ol):
         return self.lib().speex_resampler_process_interleaved_float(self._h, i, il, o, ol)
+
+    def _raw_interleaved(self, kind, i, il, o, ol):
+        return (self._process if kind == "int" else self._process_float)(i, il, o, ol)
+
+    def _raw_channel(self, kind, c, i, il, o, ol):
+        fn = (self.lib().speex_resampler_process_int if kind == "int"
+              else self.lib().speex_resampler_process_float)
+        return fn(self._h, c, i, il, o, ol)
+
+    def _set_strides(self, a, b):
+        self.lib().speex_resampler_set_input_stride(self._h, a)
+        self.lib().speex_resampler_set_output_stride(self._h, b)
+
+    def _chan_pos(self, c):
+        st = self._h.contents
+        return int(st.last_sample[c]), int(st.samp_frac_num[c]), int(st.magic_samples[c])
 
     def table(self):
         return np.ctypeslib.as_array(self._h.contents.sinc_table, shape=(self.table_len,)).copy()

@@ -113,6 +113,9 @@ typedef struct orc_state {
                         (right after the history) left over from a filter-length change */
   int started;       /* a block has been processed: filter changes must re-align the history */
   int live;          /* construction finished (resample.c "initialised") */
+  int zero;          /* the last filter change failed: resampler_basic_zero is installed
+                        (resample.c:561-591, 785-791) */
+  uint32_t in_stride, out_stride; /* per-channel entry points, resample.c:842-843, 1170-1188 */
 } orc_state;
 
 /* Window value at x in [0,1] by 4-point cubic interpolation of the table
@@ -261,9 +264,18 @@ static int design(orc_state *o) {
           tap_value(o->cutoff, (i / (float)o->os - o->taps / 2), o->taps, q->win);
     o->kind = o->quality > 8 ? K_INTERP_DOUBLE : K_INTERP_SINGLE;
   }
-  return fit_lines(o, old_taps);
+  o->zero = 0; /* a real kernel is installed at :682-698, before the history is fitted */
+  {
+    const int rc = fit_lines(o, old_taps);
+    if (rc != ORC_OK) {
+      o->zero = 1;
+      o->taps = old_taps;
+    }
+    return rc;
+  }
 fail:
-  o->taps = old_taps; /* :785-791 */
+  o->zero = 1;        /* :785 resampler_basic_zero */
+  o->taps = old_taps; /* :786-790: the history still belongs to the old filter length */
   return ORC_ERR_ALLOC;
 }
 
@@ -324,6 +336,7 @@ orc_state *orc_new_frac(uint32_t channels, uint32_t ratio_num, uint32_t ratio_de
     e = ORC_ERR_ALLOC;
   } else {
     o->channels = channels;
+    o->in_stride = o->out_stride = 1; /* :842-843 */
     o->quality = -1;
     o->cutoff = 1.f;
     o->pos = (int32_t *)calloc(channels, sizeof(int32_t));
@@ -439,7 +452,7 @@ static uint32_t run_block(orc_state *o, uint32_t c, uint32_t nin, uint32_t cap, 
   uint32_t made = 0;
   o->started = 1;
   while (!(pos >= (int32_t)nin || made >= cap)) {
-    const float v = fir_sample(o, x + pos, phase);
+    const float v = o->zero ? 0.f : fir_sample(o, x + pos, phase); /* resample.c:561-591 */
     if (as_pcm)
       ((int16_t *)out)[(size_t)made * stride] = to_pcm(v);
     else
@@ -476,7 +489,7 @@ static uint32_t drain_pending(orc_state *o, uint32_t c, uint32_t cap, void *out,
 /* One channel of one call through the int16 entry point: blocks of at most (line - history)
  * input frames -- 160 unless the filter has been shortened since -- and at most 1024 outputs,
  * pending frames first (resample.c:968-1036).  Strided int16 in/out. */
-static void run_channel(orc_state *o, uint32_t c, const int16_t *in, uint32_t stride,
+static void run_channel(orc_state *o, uint32_t c, const int16_t *in, uint32_t in_stride, uint32_t stride,
                         uint32_t *in_len, int16_t *out, uint32_t *out_len) {
   float *x = o->lines + (size_t)c * o->line;
   const uint32_t hist = o->taps - 1;
@@ -492,13 +505,13 @@ static void run_channel(orc_state *o, uint32_t c, const int16_t *in, uint32_t st
     }
     if (!o->pending[c]) {
       const uint32_t nin = in_left > block_in ? block_in : in_left;
-      for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? (float)in[(size_t)j * stride] : 0.f;
+      for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? (float)in[(size_t)j * in_stride] : 0.f;
       made = run_block(o, c, nin, room, out + (size_t)from_pending * stride, stride, 1, &used);
     }
     in_left -= used;
     out_left -= made;
     out += (size_t)(from_pending + made) * stride;
-    if (in) in += (size_t)used * stride;
+    if (in) in += (size_t)used * in_stride;
   }
   *in_len -= in_left;
   *out_len -= out_left;
@@ -511,16 +524,23 @@ int orc_process_interleaved_int(orc_state *o, const int16_t *in, uint32_t *in_le
   for (uint32_t c = 0; c < o->channels; c++) {
     *in_len = want_in;
     *out_len = want_out;
-    run_channel(o, c, in ? in + c : NULL, o->channels, in_len, out + c, out_len);
+    run_channel(o, c, in ? in + c : NULL, o->channels, o->channels, in_len, out + c, out_len);
   }
-  return ORC_OK;
+  return o->zero ? ORC_ERR_ALLOC : ORC_OK; /* :1081 */
+}
+
+/* resample.c:968-1036 as a public call: one channel, the state's strides (:1170-1188) */
+int orc_process_int(orc_state *o, uint32_t c, const int16_t *in, uint32_t *in_len, int16_t *out,
+                    uint32_t *out_len) {
+  run_channel(o, c, in, o->in_stride, o->out_stride, in_len, out, out_len);
+  return o->zero ? ORC_ERR_ALLOC : ORC_OK; /* :1035 */
 }
 
 /* One channel of one call through the FLOAT entry point (resample.c:927-963): input frames are
  * copied as they are, the FIR values are written unrounded, and -- unlike the int16 entry
  * point -- a block's output is limited only by the room left (resample.c:943), not by 1024;
  * pending frames are drained once, up front, even when the call brings no input. */
-static void run_channel_float(orc_state *o, uint32_t c, const float *in, uint32_t stride,
+static void run_channel_float(orc_state *o, uint32_t c, const float *in, uint32_t in_stride, uint32_t stride,
                               uint32_t *in_len, float *out, uint32_t *out_len) {
   float *x = o->lines + (size_t)c * o->line;
   const uint32_t hist = o->taps - 1;
@@ -535,12 +555,12 @@ static void run_channel_float(orc_state *o, uint32_t c, const float *in, uint32_
     while (in_left && out_left) {
       const uint32_t nin = in_left > block_in ? block_in : in_left;
       uint32_t used = 0;
-      for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? in[(size_t)j * stride] : 0.f;
+      for (uint32_t j = 0; j < nin; j++) x[hist + j] = in ? in[(size_t)j * in_stride] : 0.f;
       const uint32_t made = run_block(o, c, nin, out_left, out, stride, 0, &used);
       in_left -= used;
       out_left -= made;
       out += (size_t)made * stride;
-      if (in) in += (size_t)used * stride;
+      if (in) in += (size_t)used * in_stride;
     }
   }
   *in_len -= in_left;
@@ -554,9 +574,28 @@ int orc_process_interleaved_float(orc_state *o, const float *in, uint32_t *in_le
   for (uint32_t c = 0; c < o->channels; c++) {
     *in_len = want_in;
     *out_len = want_out;
-    run_channel_float(o, c, in ? in + c : NULL, o->channels, in_len, out + c, out_len);
+    run_channel_float(o, c, in ? in + c : NULL, o->channels, o->channels, in_len, out + c, out_len);
   }
-  return ORC_OK;
+  return o->zero ? ORC_ERR_ALLOC : ORC_OK; /* :1058 */
+}
+
+/* resample.c:927-963 as a public call */
+int orc_process_float(orc_state *o, uint32_t c, const float *in, uint32_t *in_len, float *out,
+                      uint32_t *out_len) {
+  run_channel_float(o, c, in, o->in_stride, o->out_stride, in_len, out, out_len);
+  return o->zero ? ORC_ERR_ALLOC : ORC_OK; /* :962 */
+}
+
+/* resample.c:1170-1188 */
+void orc_set_input_stride(orc_state *o, uint32_t stride) { o->in_stride = stride; }
+void orc_set_output_stride(orc_state *o, uint32_t stride) { o->out_stride = stride; }
+uint32_t orc_get_input_stride(const orc_state *o) { return o->in_stride; }
+uint32_t orc_get_output_stride(const orc_state *o) { return o->out_stride; }
+/* one channel's position: last_sample, samp_frac_num, magic_samples */
+void orc_channel_position(const orc_state *o, uint32_t c, int32_t *pos, uint32_t *phase, uint32_t *pending) {
+  *pos = o->pos[c];
+  *phase = o->phase[c];
+  *pending = o->pending[c];
 }
 
 /* resample.c:1089-1093, 1147-1151, 1165-1168 */

@@ -835,3 +835,106 @@ def test_random_control_soak_against_the_oracle():
             assert np.array_equal(r.history()[:, c], ref.history(c)), (seed, args)
             assert np.array_equal(r.pending(c), ref.pending(c)), (seed, args)
         r.close()
+
+
+def _channel_scripts():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "golden_channels.json")) as f:
+        return json.load(f)["scripts"]
+
+
+def test_per_channel_entry_points_and_failed_filter_fallback_exact_mode():
+    """SURVEY 8 rows N2 (speex_resampler_process_int / _process_float with strides, channels
+    advanced unevenly, interleaved calls on the uneven state) and a6 (resampler_basic_zero after a
+    filter change that cannot build its filter): 624 ops recorded from the reference, bit for bit
+    in EXACT mode -- return codes, counters, digests of the whole sentinel-filled output buffers
+    (samples a call must not touch included), every channel's position."""
+    from make_golden_channels import apply_channel_op
+    ops = 0
+    for c in _channel_scripts():
+        r = speexhip.Resampler(c["channels"], c["in_rate"], c["out_rate"], c["quality"], mode=speexhip.MODE_EXACT)
+        for k, (op, want) in enumerate(zip(c["ops"], c["results"])):
+            got = apply_channel_op(r, op, c["channels"])
+            assert got == want, (c["name"], k, op, got, want)
+            ops += 1
+        r.close()
+    assert ops == 624
+
+
+def test_per_channel_scripts_fast_mode_against_the_oracle():
+    """The same scripts in FAST mode: the per-channel calls and every call on an uneven state run the
+    bit-exact one-channel kernel; interleaved calls on an even state run the fast kernels (+-1 LSB,
+    float 4e-6).  Counters, return codes and positions always equal the oracle's."""
+    from make_golden_channels import channel_input
+    for c in _channel_scripts()[:12]:
+        ch = c["channels"]
+        r = speexhip.Resampler(ch, c["in_rate"], c["out_rate"], c["quality"], mode=speexhip.MODE_FAST)
+        ref = orc.Oracle(ch, c["in_rate"], c["out_rate"], c["quality"])
+        for k, op in enumerate(c["ops"]):
+            kind = op[0]
+            if kind in ("int_ch", "float_ch"):
+                _, cc, frames, cap, seed, istr, ostr = op
+                x = channel_input(kind[:-3], frames, seed) if seed >= 0 else None
+                a = r.channel_call(kind[:-3], cc, x, cap, istr, ostr, null_frames=frames)
+                b = ref.channel_call(kind[:-3], cc, x, cap, istr, ostr, null_frames=frames)
+                assert a[:3] == b[:3] and np.array_equal(a[3], b[3]), (c["name"], k, op)
+            elif kind in ("int", "float"):
+                _, frames, cap, seed = op
+                x = channel_input(kind, frames * ch, seed).reshape(frames, ch)
+                a, b = r.raw_call(kind, x, cap), ref.raw_call(kind, x, cap)
+                assert a[:3] == b[:3], (c["name"], k, op, a[:3], b[:3])
+                if kind == "int":
+                    assert np.abs(a[3].astype(np.int32) - b[3].astype(np.int32)).max() <= TOL_LSB, (c["name"], k)
+                else:
+                    # (4e-6 of full scale; a float call after int16 calls sees int16-scaled history)
+                    scale = max(1.0, float(np.abs(b[3][: b[2]]).max()) if b[2] else 1.0)
+                    assert np.abs(a[3].astype(np.float64) - b[3].astype(np.float64)).max() <= 4e-6 * scale, (c["name"], k)
+            else:
+                fn = {"rate": "set_rate", "ratefrac": "set_rate_frac", "quality": "set_quality", "skip": "skip_zeros",
+                      "reset": "reset_mem"}[kind]
+                assert getattr(r, fn)(*op[1:]) == getattr(ref, fn)(*op[1:]), (c["name"], k, op)
+            assert r.positions() == ref.positions() and r.taps == ref.taps and r.ratio() == ref.ratio(), (c["name"], k)
+        r.close()
+
+
+def test_device_allocation_failure_installs_the_zero_fallback_and_keeps_the_stream():
+    """Row a6 where it cannot come from the arguments: the device runs out of memory while a new
+    filter is installed (test hook: the n-th next device allocation fails -- the table, a history
+    buffer, a tap-row table ...).  As in the reference (resample.c:785-791): the call returns
+    ALLOC_FAILED, rates / ratio / quality are the NEW ones, the filter length and the history the
+    OLD ones; processing calls write zeros, move the counters by the new ratio and return
+    ALLOC_FAILED; a later change that succeeds ends the fallback."""
+    ch, q = 2, 5
+    x = orc.lcg_pcm(4000 * ch, 31).reshape(-1, ch)
+    hook = speexhip.lib().speexhip_debug_fail_device_allocs
+    for nth in (1, 2, 3, 4):  # the table, two history buffers, the tap rows
+        r = speexhip.Resampler(ch, 44100, 48000, q, mode=speexhip.MODE_EXACT)
+        rc, used, made, out = r.raw_call("int", x[:1000], 2000)
+        assert rc == 0 and out[:made].any()
+        hist_before, pos_before = r.history(), r.positions()
+        hook(nth)
+        rc = r.set_rate(32000, 48000)
+        hook(0)
+        assert rc == 1, (nth, rc)                                   # RESAMPLER_ERR_ALLOC_FAILED
+        assert r.rate() == (32000, 48000) and r.ratio() == (2, 3) and r.taps == 80, nth
+        assert np.array_equal(r.history(), hist_before)
+        # phase numerators were carried to the new denominator (resample.c:1130-1139), positions kept
+        assert [p[0] for p in r.positions()] == [p[0] for p in pos_before]
+        assert all(p[1] < 3 for p in r.positions())
+        last, frac, magic = r.positions()[0]
+        want_used, want_made, _, _, _ = speexhip.plan_call_ex(2, 3, 1000, 2000, False, r.info()["block_in"], last,
+                                                              frac, magic)
+        rc, used, made, out = r.raw_call("int", x[1000:2000], 2000)
+        assert rc == 1 and (used, made) == (want_used, want_made) and made > 1400, (nth, rc, used, made)
+        assert not out[:made].any() and (out[made:] == r.SENTINEL_I16).all()
+        # the same request in REDUCED form is a no-op (resample.c:1116-1117 compares with the stored,
+        # reduced ratio): the fallback stays
+        assert r.set_rate_frac(2, 3, 32000, 48000) == 0 and r.info()["filt_len"] == 80
+        rc, used, made, out = r.raw_call("float", np.ones((100, ch), np.float32), 200)
+        assert rc == 1 and made > 0 and not out[:made].any()
+        rc, used, made, out = r.channel_call("int", 1, x[:300, 0], 500, 2, 3)
+        assert rc == 1 and made > 0 and not out[: (made - 1) * 3 + 1: 3].any()
+        assert r.set_quality(8) == 0 and r.taps == 160                  # a change that succeeds ends it
+        rc, used, made, out = r.raw_call("int", x[2000:3000], 2000)
+        assert rc == 0 and out[:made].any()
+        r.close()

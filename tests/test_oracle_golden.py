@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from golden_util import drive, make_input, sha1
+from golden_util import ROOT, drive, make_input, sha1
 
 
 def test_lcg_generator_matches_scalar_definition():
@@ -158,3 +158,30 @@ def test_oracle_equals_reference_build_on_random_control_scripts():
             for c in range(ch):
                 assert a.history(c).tobytes() == b.history(c).tobytes()
                 assert a.pending(c).tobytes() == b.pending(c).tobytes()
+
+
+def test_restatement_reproduces_the_per_channel_and_failed_filter_scripts():
+    """the per-channel entry points with strides (resample.c:927-1036,
+    1170-1188), interleaved calls on states whose channels stand apart (:1061-1082) and the
+    resampler_basic_zero fallback after a filter change that cannot build its filter (:561-591,
+    785-791) -- 624 ops recorded from the reference (tests/golden/make_golden_channels.py): return
+    codes, counters, digests of the whole sentinel-filled output buffers, every channel's position."""
+    import json
+    from make_golden_channels import apply_channel_op
+    with open(os.path.join(ROOT, "tests", "golden", "golden_channels.json")) as f:
+        doc = json.load(f)
+    assert doc["sentinels"] == [orc.SENTINEL_I16, orc.SENTINEL_F32]
+    ops = zero_ops = 0
+    for c in doc["scripts"]:
+        eng = orc.Oracle(c["channels"], c["in_rate"], c["out_rate"], c["quality"])
+        for k, (op, want) in enumerate(zip(c["ops"], c["results"])):
+            got = apply_channel_op(eng, op, c["channels"])
+            assert got == want, (c["name"], k, op, got, want)
+            ops += 1
+            zero_ops += op[0] in ("int", "float", "int_ch", "float_ch") and want[0] == 1
+    assert ops == 624 and zero_ops >= 50
+    if orc.have_reference():  # dev container / prebuilt _ref: the recorded rows ARE the reference's
+        c = doc["scripts"][3]
+        eng = orc.Reference(c["channels"], c["in_rate"], c["out_rate"], c["quality"])
+        for op, want in zip(c["ops"], c["results"]):
+            assert apply_channel_op(eng, op, c["channels"]) == want
