@@ -681,6 +681,17 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   // copies itself and does it 2.2-2.5x faster than memcpy -> pinned -> DMA in one thread (2^20
   // stereo frames: 0.46 -> 0.21 ms per call, 8 channels 1.57 -> 0.63 ms).  Small ones keep the
   // pinned bounce buffers (a few % faster below ~256 KB).
+  // What was tried in round 2 to get below this (2^20 stereo frames, 207 us per call; tools/ubench_copy.hip):
+  // PCIe is full duplex -- both copies at once from pinned memory take 103 us instead of 175 -- but
+  //   * H2D / kernel / D2H of 2-8 pieces on three streams chained by events: +30 us per piece (a
+  //     cross-stream wait costs ~14 us on this stack and nothing overlapped);
+  //   * pieces alternating on two independent in-order streams: 189 us at 2 pieces, more beyond (a
+  //     copy-engine <-> kernel hand-over costs ~10 us, and kernels of two streams never ran side by side);
+  //   * the caller's buffers pinned for the call (hipHostRegister, ~5 us) and read / written by the
+  //     kernels straight through PCIe, one launch: 166 us -- and, one run in three, a stretch of stale
+  //     zeros near the end of the output when buffers at recycled addresses were pinned again.  Not
+  //     shippable; removed.
+  // So the call stays three in-order steps on one stream.
   const bool direct_in = in_bytes >= kDirectCopyBytes, direct_out = out_bytes >= kDirectCopyBytes && !split;
   if (in != nullptr && in_bytes != 0) {
     if (direct_in) {

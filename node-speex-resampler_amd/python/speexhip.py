@@ -434,9 +434,11 @@ class Resampler:
             off += caps[i]
         return outs, list(lens)
 
-    def process_device(self, d_in_ptr, in_frames, d_out_ptr, out_capacity, stream_ptr=0):
+    def process_device(self, d_in_ptr, in_frames, d_out_ptr, out_capacity, stream_ptr=0, float_io=False):
         il, ol = C.c_uint32(in_frames), C.c_uint32(out_capacity)
-        rc = lib().speexhip_resampler_process_interleaved_int_device(
+        fn = (lib().speexhip_resampler_process_interleaved_float_device if float_io
+              else lib().speexhip_resampler_process_interleaved_int_device)
+        rc = fn(
             self._h, C.c_void_p(d_in_ptr), C.byref(il), C.c_void_p(d_out_ptr), C.byref(ol),
             C.c_void_p(stream_ptr))
         if rc:

@@ -938,3 +938,40 @@ def test_device_allocation_failure_installs_the_zero_fallback_and_keeps_the_stre
         rc, used, made, out = r.raw_call("int", x[2000:3000], 2000)
         assert rc == 0 and out[:made].any()
         r.close()
+
+
+@pytest.mark.parametrize("mode", [speexhip.MODE_EXACT, speexhip.MODE_FAST])
+def test_host_buffer_call_equals_the_device_pointer_call(mode):
+    """The host-buffer entry points (staged copies around the launch; aligned and misaligned caller
+    buffers) against the same launch on device-resident buffers: the bytes, the counters, the
+    position and the history must be identical -- in both modes, over several consecutive calls
+    (the second and third start from a full history and a non-zero phase), for int16 and float and
+    for a decimating 8-channel stream."""
+    import torch
+    for (ch, i, o, q, frames, fio) in [(2, 44100, 48000, 7, 1 << 20, False), (2, 44100, 48000, 7, 300000, True),
+                                      (8, 48000, 44100, 5, 200000, False), (1, 24000, 48000, 10, 400000, False)]:
+        a = speexhip.Resampler(ch, i, o, q, mode=mode)
+        b = speexhip.Resampler(ch, i, o, q, mode=mode)
+        cap, _ = orc.wrapper_capacity(frames * ch * 2, i, o, ch)
+        for call in range(3):
+            x = orc.lcg_pcm(frames * ch, 70 + call).reshape(frames, ch)
+            if call == 2:  # a misaligned view: the staged path
+                buf = np.zeros(x.size + 1, np.int16)
+                buf[1:] = x.reshape(-1)
+                x = buf[1:].reshape(frames, ch)
+                assert x.ctypes.data % 16 != 0
+            if fio:
+                x = (x.astype(np.float32) / np.float32(32768.0))
+                got, used = a.process_float(x, cap)
+            else:
+                got, used = a.process(x, cap)
+            d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+            d_out = torch.zeros((cap, ch), dtype=torch.float32 if fio else torch.int16, device="cuda")
+            u2, m2 = b.process_device(d_in.data_ptr(), frames, d_out.data_ptr(), cap,
+                                      torch.cuda.current_stream().cuda_stream, float_io=fio)
+            torch.cuda.synchronize()
+            assert (used, got.shape[0]) == (u2, m2), (ch, i, o, call)
+            assert np.array_equal(got, d_out[:m2].cpu().numpy()), (ch, i, o, fio, call, "bytes differ")
+            assert a.position() == b.position() and np.array_equal(a.history(), b.history())
+        a.close()
+        b.close()
