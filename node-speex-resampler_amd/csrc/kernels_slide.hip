@@ -1,4 +1,4 @@
-// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6, num <= 4, and n:1 for n = 5, 6, 8, 12):
+// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6 with num <= 5, and n:1 for n <= 10 and 12):
 // integer up-sampling 24k->48k, 16k->48k, 8k->48k, same-rate, 2:1 / 3:1 / 4:1 decimation, 3:2,
 // 2:3 ... (BASELINE configs[2]; the reference picks resampler_basic_direct_* for
 // most of these, deps/speex/resample.c:331-435).  +-1 LSB.
@@ -248,6 +248,14 @@ const SlideShape kShapes[] = {
     {5, 1, true, 4}, {5, 1, false, 4}, {6, 1, true, 4}, {6, 1, false, 4},
     // 8:1 and 12:1 (192k -> 24k / 16k, 96k -> 12k / 8k): two periods per lane, 24- / 36-frame window
     {8, 1, true, 2}, {8, 1, false, 2}, {12, 1, true, 2}, {12, 1, false, 2},
+    // den = 5 (8k -> 40k, 16k -> 40k, 24k -> 40k, 32k -> 40k): five accumulator pairs per period for channel
+    // pairs; odd channel counts pad den to 6 phases (np = 3, the den = 6 shapes)
+    {1, 5, true, 4}, {2, 5, true, 4}, {3, 5, true, 2}, {4, 5, true, 2},
+    {2, 3, false, 4}, {3, 3, false, 2}, {4, 3, false, 2},
+    // 7:1, 9:1, 10:1 (56k -> 8k, 72k -> 8k, 44.1k -> 4.41k, 80k -> 8k)
+    {7, 1, true, 2}, {7, 1, false, 2}, {9, 1, true, 2}, {9, 1, false, 2}, {10, 1, true, 2}, {10, 1, false, 2},
+    // 5:2, 5:3, 5:4 (40k -> 16k / 24k / 32k)
+    {5, 2, true, 2}, {5, 3, true, 2}, {5, 4, true, 2}, {5, 2, false, 2},
 };
 }  // namespace
 
@@ -364,6 +372,23 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   SPEEXHIP_SLIDE_CASE(2, 8, 1, false)
   SPEEXHIP_SLIDE_CASE(2, 12, 1, true)
   SPEEXHIP_SLIDE_CASE(2, 12, 1, false)
+  SPEEXHIP_SLIDE_CASE(4, 1, 5, true)
+  SPEEXHIP_SLIDE_CASE(4, 2, 5, true)
+  SPEEXHIP_SLIDE_CASE(2, 3, 5, true)
+  SPEEXHIP_SLIDE_CASE(2, 4, 5, true)
+  SPEEXHIP_SLIDE_CASE(4, 2, 3, false)
+  SPEEXHIP_SLIDE_CASE(2, 3, 3, false)
+  SPEEXHIP_SLIDE_CASE(2, 4, 3, false)
+  SPEEXHIP_SLIDE_CASE(2, 7, 1, true)
+  SPEEXHIP_SLIDE_CASE(2, 7, 1, false)
+  SPEEXHIP_SLIDE_CASE(2, 9, 1, true)
+  SPEEXHIP_SLIDE_CASE(2, 9, 1, false)
+  SPEEXHIP_SLIDE_CASE(2, 10, 1, true)
+  SPEEXHIP_SLIDE_CASE(2, 10, 1, false)
+  SPEEXHIP_SLIDE_CASE(2, 5, 2, true)
+  SPEEXHIP_SLIDE_CASE(2, 5, 3, true)
+  SPEEXHIP_SLIDE_CASE(2, 5, 4, true)
+  SPEEXHIP_SLIDE_CASE(2, 5, 2, false)
 #undef SPEEXHIP_SLIDE_CASE
   return hipErrorInvalidValue;
 }

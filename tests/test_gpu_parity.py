@@ -274,7 +274,13 @@ def test_small_ratio_sliding_window_kernel_variants():
              # num > 1: 2:1, 3:1, 4:1 decimation, 3:2, 2:3
              (2, 96000, 48000, 7), (1, 48000, 24000, 10), (2, 48000, 16000, 5), (1, 48000, 16000, 8),
              (2, 48000, 12000, 4), (1, 32000, 8000, 6), (2, 48000, 32000, 7), (1, 48000, 32000, 3),
-             (2, 32000, 48000, 9), (1, 32000, 48000, 5)]
+             (2, 32000, 48000, 9), (1, 32000, 48000, 5),
+             # den = 5: 1:5, 2:5, 3:5, 4:5, stereo (five accumulator pairs) and mono / 3 ch (den padded to 6)
+             (2, 8000, 40000, 7), (1, 8000, 40000, 5), (2, 16000, 40000, 10), (1, 16000, 40000, 3),
+             (2, 24000, 40000, 6), (3, 24000, 40000, 4), (2, 32000, 40000, 8), (1, 32000, 40000, 9),
+             # 5:2, 5:3, 5:4
+             (2, 40000, 16000, 5), (1, 40000, 16000, 7), (2, 40000, 24000, 4), (1, 40000, 24000, 6),
+             (2, 40000, 32000, 10), (1, 40000, 32000, 2)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -371,10 +377,10 @@ def test_eight_channel_padded_window_and_odd_channel_counts():
 
 
 def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
-    """Ratios no fast kernel covers (den = 5, 7:1, filters too long for LDS) must still be right:
+    """Ratios no fast kernel covers (11:1, 5:6, filters too long for LDS) must still be right:
     FAST mode falls back to the bit-exact kernel (fast_path == 0), staged in LDS or streaming
     straight from L2 when the filter does not fit."""
-    for (ch, i, o, q, frames) in [(1, 56000, 8000, 5, 30000), (2, 8000, 40000, 4, 4000),
+    for (ch, i, o, q, frames) in [(1, 88000, 8000, 5, 30000), (2, 40000, 48000, 4, 4000),
                                   (1, 192000, 1000, 10, 120000), (2, 96000, 1500, 3, 90000)]:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -396,7 +402,10 @@ def test_n_to_one_decimation_takes_the_slide_kernel():
                           (2, 40000, 8000, 4), (3, 48000, 8000, 6),
                           # 8:1 and 12:1: the long decimation filters of 96k / 192k sources (1024 - 3072 taps)
                           (2, 192000, 24000, 7), (1, 96000, 12000, 10), (2, 96000, 8000, 5), (1, 192000, 16000, 10),
-                          (4, 192000, 16000, 3)]:
+                          (4, 192000, 16000, 3),
+                          # 7:1, 9:1, 10:1
+                          (2, 56000, 8000, 6), (1, 56000, 8000, 9), (2, 72000, 8000, 4), (1, 72000, 8000, 7),
+                          (2, 44100, 4410, 8), (1, 80000, 8000, 10)]:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
         assert r.info()["fast_path"] == 3, (ch, i, o, q)
