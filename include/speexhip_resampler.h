@@ -124,10 +124,10 @@ SPEEXHIP_API int speexhip_resampler_get_output_latency(SpeexHipResamplerState *s
 SPEEXHIP_API int speexhip_resampler_skip_zeros(SpeexHipResamplerState *st);
 SPEEXHIP_API int speexhip_resampler_reset_mem(SpeexHipResamplerState *st);
 
-/* Replace speex_resampler_process_int / _process_float (speex_resampler.h:159-200,
+/* Replace speex_resampler_process_int / _process_float (speex_resampler.h:169-191,
  * resample.c:968-1036, 927-963): ONE channel of the state, host buffers whose consecutive samples
  * are `input stride` / `output stride` apart (speex_resampler_set/get_input/output_stride,
- * speex_resampler.h:279-303, resample.c:1170-1188; both 1 after init, resample.c:842-843).  As in
+ * speex_resampler.h:285-307, resample.c:1170-1188; both 1 after init, resample.c:842-843).  As in
  * the reference every channel keeps its own position (last_sample / samp_frac_num /
  * magic_samples, resample.c:135-137), so channels may be advanced unevenly; an interleaved call on
  * such a state then handles channel after channel with the caller's lengths and reports the

@@ -274,3 +274,99 @@ def test_bench_stream_sharding_matches_dist_util():
     assert all(len(bench.shard_streams(256, 8, r)) == 32 for r in range(8))
     a = bench.parse_args(["--gpus", "8", "--total-streams", "256"])
     assert (a.gpus, a.total_streams, a.steps, a.reps) == (8, 256, 200, 5)
+
+
+class _ChannelModel:
+    """Per-channel bookkeeping of one state, driven only through the library's host-only entry
+    points -- what engine.cpp keeps per (stream, channel), incl. the failed-filter fallback
+    (reference resample.c:785-791: new rates and advances, old filter length, zeros out)."""
+
+    def __init__(self, ch, in_rate, out_rate, quality):
+        self.ch, self.quality = ch, quality
+        self.pos = [[0, 0, 0] for _ in range(ch)]  # last_sample, samp_frac_num, magic_samples
+        self.started = self.zero = False
+        self.line = 0
+        info = speexhip.design_filter_frac(in_rate, out_rate, in_rate, out_rate, quality)
+        self.rates = (in_rate, out_rate)
+        self.num, self.den, self.taps = info["num_rate"], info["den_rate"], info["filt_len"]
+        self.line = self.taps - 1 + 160
+
+    def _plan(self, c, frames, cap, float_entry):
+        used, made, *self.pos[c] = speexhip.plan_call_ex(self.num, self.den, frames, cap, float_entry,
+                                                         self.line - (self.taps - 1), *self.pos[c])
+        self.started = self.started or (frames > 0 and cap > 0)
+        return used, made
+
+    def _change(self, n, d, i, o, quality):
+        from math import gcd
+        info_rc = 0
+        try:
+            info = speexhip.design_filter_frac(n, d, i, o, quality)
+        except ValueError as e:  # strerror text of the code
+            assert str(e) == "Memory allocation failed.", e
+            info_rc, info = 1, None
+        g = gcd(n, d)
+        new_num, new_den = n // g, d // g
+        fracs = []
+        for p in self.pos:
+            rc, _, _, _, f = speexhip.plan_filter_change(self.taps, self.taps, 0, p[1], self.den, new_den)
+            if rc:
+                return rc
+            fracs.append(f)
+        if info is not None and self.started:
+            for p in self.pos:
+                rc, _shift, magic, delta, _ = speexhip.plan_filter_change(self.taps, info["filt_len"], p[2])
+                p[2], p[0] = magic, p[0] + delta
+        for p, f in zip(self.pos, fracs):
+            p[1] = f
+        self.rates, self.num, self.den, self.quality = (i, o), new_num, new_den, quality
+        if info is None:
+            self.zero = True
+            return 1
+        self.zero = False
+        self.taps = info["filt_len"]
+        self.line = max(self.line, self.taps - 1 + 160)
+        return 0
+
+    def op(self, op):
+        kind = op[0]
+        if kind in ("int_ch", "float_ch"):
+            used, made = self._plan(op[1], op[2], op[3], kind == "float_ch")
+            res = [1 if self.zero else 0, used, made]
+        elif kind in ("int", "float"):
+            for c in range(self.ch):  # resample.c:1061-1082: the last channel's counters are reported
+                used, made = self._plan(c, op[1], op[2], kind == "float")
+            res = [1 if self.zero else 0, used, made]
+        elif kind in ("rate", "ratefrac"):
+            n, d, i, o = (op[1], op[2], op[1], op[2]) if kind == "rate" else op[1:5]
+            same = (self.rates, self.num, self.den) == ((i, o), n, d)
+            res = [0 if same else self._change(n, d, i, o, self.quality)]
+        elif kind == "quality":
+            res = [0 if op[1] == self.quality else self._change(self.num, self.den, *self.rates, op[1])]
+        elif kind == "skip":
+            for p in self.pos:
+                p[0] = self.taps // 2
+            res = [0]
+        else:
+            self.pos = [[0, 0, 0] for _ in range(self.ch)]
+            res = [0]
+        return res + [[list(p) for p in self.pos], self.taps, *self.rates, self.num, self.den]
+
+
+def test_per_channel_planner_and_failed_filter_counters_match_the_reference_scripts():
+    """SURVEY 8 rows a6 / N2 on the CPU: per-channel positions through the product's planner (incl.
+    channels advanced unevenly, interleaved calls on the uneven state) and the counters of the
+    resampler_basic_zero fallback -- new ratio, old filter length -- over the 624 recorded ops of
+    tests/golden/golden_channels.json (digests need the GPU)."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "golden_channels.json")) as f:
+        scripts = json.load(f)["scripts"]
+    checked = 0
+    for c in scripts:
+        m = _ChannelModel(c["channels"], c["in_rate"], c["out_rate"], c["quality"])
+        for k, (op, want) in enumerate(zip(c["ops"], c["results"])):
+            got = m.op(op)
+            want = [w for w in want if not isinstance(w, str)]
+            assert got == want, (c["name"], k, op, got, want)
+            checked += 1
+    assert checked == 624
