@@ -368,7 +368,10 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 // one row apart, deposit into distinct banks.
 // (The stereo counterpart -- 40-byte pieces per lane -- was built too: stores alone 74 -> 48 us, but
 //  the launch as a whole within noise at every size, 210.8-213.5 vs 212.4-213.5 us at 32 streams and
-//  slower below; removed.)
+//  slower below; removed.  Round 2 built it for frames of several channel pairs as well -- 4-byte
+//  pieces per lane there, image [period][frame][pair], 16-byte row stores: 4 ch 44.1k->48k 431 -> 421 us,
+//  but 8 ch 48k->44.1k 621 -> 644 us and 6 ch 670 -> 735 us at 32 streams: the two barriers and the
+//  serial copy-out cost more than the per-lane stores they replace; removed.)
 template <int R, bool PADDED>
 __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const float *__restrict__ rows,
                                                    const StreamDesc &d, float *xs, uint32_t xshift, uint32_t m_lo,
