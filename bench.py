@@ -225,12 +225,19 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, "
                  "or without WORLD_SIZE (bench.py then starts the ranks itself)" % (args.gpus, world, args.gpus))
     n_dev = torch.cuda.device_count()
-    if local >= n_dev:
+    # BENCH_SHARE_GPU=1 (tests only): all ranks on GPU 0 with the gloo backend, so that the N-rank code
+    # path -- launcher, rendezvous, barriers, MAX / SUM reductions, rank-0 line -- can be exercised
+    # end to end on a 1-GPU box.  The line then says so and its numbers mean nothing.
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if local >= n_dev and not (share and n_dev >= 1):
         sys.exit("bench.py: rank %d needs GPU %d but this node shows %d GPU(s)" % (rank, local, n_dev))
-    world, rank, local = dist_util.init("nccl")
+    world, rank, local = dist_util.init("gloo" if share else "nccl")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ctl = torch.device("cpu") if share else dev  # where the control collectives run
 
     cfg = CONFIGS[args.config]
     if args.custom:
@@ -300,7 +307,7 @@ def main():
     it = args.warmup + 1
     for r in range(reps):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dist_util.barrier(dev)
+        dist_util.barrier(ctl)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record(stream)
@@ -313,13 +320,13 @@ def main():
         ev1.record(stream)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        dist_util.barrier(dev)
-        wall.append(dist_util.reduce_scalar(elapsed, "max", dev))
+        dist_util.barrier(ctl)
+        wall.append(dist_util.reduce_scalar(elapsed, "max", ctl))
         gpu.append(ev0.elapsed_time(ev1))
 
-    total_in_samples = dist_util.reduce_int(args.steps * S * F * ch, dev)
-    total_out_samples = dist_util.reduce_int(produced * ch, dev)
-    checksum = dist_util.reduce_int(first_sum, dev)
+    total_in_samples = dist_util.reduce_int(args.steps * S * F * ch, ctl)
+    total_out_samples = dist_util.reduce_int(produced * ch, ctl)
+    checksum = dist_util.reduce_int(first_sum, ctl)
 
     rc = 0
     if rank == 0:
@@ -382,6 +389,8 @@ def main():
                      "frac": round(tfl / VALU_PEAK_TFLOPS, 4), "flops_per_launch": int(flops)},
             "checksum": checksum,
         }
+        if share:
+            line["config"]["parallelism"] += "; TEST RUN: all ranks share GPU 0 (BENCH_SHARE_GPU=1, gloo) -- not a measurement"
         if first_chunks:
             line["parity"], ok = parity_block(cfg, F, first_chunks, fio)
             if not ok:

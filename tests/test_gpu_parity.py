@@ -984,3 +984,43 @@ def test_host_buffer_call_equals_the_device_pointer_call(mode):
             assert a.position() == b.position() and np.array_equal(a.history(), b.history())
         a.close()
         b.close()
+
+
+def test_bench_n_rank_path_end_to_end_on_one_gpu():
+    """bench.py --gpus 2 started plainly (it spawns the two ranks itself) with BENCH_SHARE_GPU=1: both
+    ranks on GPU 0, control collectives over gloo.  The numbers mean nothing; what is checked is the
+    N-rank code path of the contract: one JSON line from rank 0, n_gpus = 2, the whole-job value is
+    the SUM over ranks (twice the input samples per step of one rank), MAX-over-ranks timing, the
+    checksum summed over ranks, parity of rank 0's streams, weak and strong (--total-streams) forms."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BENCH_SHARE_GPU"] = "1"
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--reps", "2",
+            "--frames", "65536", "--preheat-ms", "20"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--reps", "2",
+                          "--frames", "65536", "--preheat-ms", "20", "--no-cpu-baseline"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    for extra, scaling, per_gpu, total in (([], "weak", 1, 2), (["--total-streams", "6"], "strong", 3, 6)):
+        r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 5
+        assert d["config"]["streams_per_gpu"] == per_gpu and d["config"]["streams_total"] == total
+        assert "not a measurement" in d["config"]["parallelism"]
+        # value = whole-job input samples / (median MAX-over-ranks time)
+        assert abs(d["value"] - total * 65536 * 2 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+        assert d["parity"]["counters_equal"] and d["parity"]["max_abs_diff_lsb"] <= 1
+        assert "cpu_baseline" not in d  # N = 1 only
+    assert d1["n_gpus"] == 1 and d1["config"]["streams_total"] == 1
+    # the driver's launch form: torch.distributed.run starts the ranks, bench.py finds WORLD_SIZE set
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29577"] + base[1:], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
