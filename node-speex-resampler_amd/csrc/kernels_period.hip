@@ -336,15 +336,19 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 #pragma unroll
     for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
 #ifdef SPEEXHIP_STAMPS
-    const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime(), fir_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     fir_group<R, CT, PADDED>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
 #ifdef SPEEXHIP_STAMPS
     {
       asm volatile("" ::"v"(acc[0]));
-      const unsigned long long fir_t1 = __builtin_amdgcn_s_memtime();
+      const unsigned long long fir_t1 = __builtin_amdgcn_s_memtime(), fir_r1 = __builtin_amdgcn_s_memrealtime();
       const uint32_t lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
       if ((threadIdx.x & 63u) == 0 && lin_ < 8192) atomicMax(&g_stamps[lin_ * 16 + 7], fir_t1 - fir_t0);
+      if (threadIdx.x == 0 && lin_ < 8192) {  // wave 0: shader cycles and 100 MHz ticks of the same interval
+        g_stamps[lin_ * 16 + 9] = fir_t1 - fir_t0;
+        g_stamps[lin_ * 16 + 10] = fir_r1 - fir_r0;
+      }
     }
 #endif
     STAMP(5);

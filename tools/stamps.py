@@ -61,10 +61,12 @@ for launch in range(a.launches):
         print("  %-18s min %7.2f  p10 %7.2f  median %7.2f  p90 %7.2f  max %7.2f" % (
             nm, col.min(), np.percentile(col, 10), np.median(col), np.percentile(col, 90), col.max()))
     d7 = w[:, 7].astype(np.float64)
-    dt = (rel[:, 5] - rel[:, 4])
-    print("  longest FIR loop of a workgroup's waves, shader cycles (s_memtime): median %.0f p90 %.0f max %.0f; "
-          "barrier->FIR done %.2f us => clock >= %.2f GHz" % (np.median(d7), np.percentile(d7, 90), d7.max(),
-                                                              np.median(dt), np.median(d7) / np.median(dt) / 1e3))
+    print("  longest FIR loop among a workgroup's waves, shader cycles (s_memtime): median %.0f p90 %.0f max %.0f" % (
+        np.median(d7), np.percentile(d7, 90), d7.max()))
+    ok = w[:, 10] > 0
+    clk = w[ok, 9] / (w[ok, 10] * 10.0)  # cycles per ns = GHz (s_memtime over s_memrealtime, wave 0's FIR loop)
+    print("  in-kernel clock over wave 0's FIR loop (s_memtime / s_memrealtime): median %.2f GHz  p10 %.2f  p90 %.2f" % (
+        np.median(clk), np.percentile(clk, 10), np.percentile(clk, 90)))
     for k in range(1, 7):
         d = rel[:, k] - rel[:, k - 1]
         print("  phase %-38s median %6.2f  p90 %6.2f  max %6.2f us" % (names[k - 1] + " -> " + names[k], np.median(d), np.percentile(d, 90), d.max()))
