@@ -790,7 +790,13 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // One workgroup per (tile, stream); the hardware dispatcher refills a CU the moment a workgroup
   // retires.  (A persistent walk of the tile list with the next tile's window prefetched into
   // registers lived here until round 1's last measurements at sustained clocks: 7 % slower at 32
-  // streams -- 228 vs 212 us --, 25 % slower on the 8-channel configuration.)
+  // streams -- 228 vs 212 us --, 25 % slower on the 8-channel configuration.  Round 2 built it once
+  // more -- 512 resident workgroups walking tiles tile_step apart, the next tile's input lines
+  // touched into L2 during the FIR loop, no slot turnover, the history roll folded into workgroup 0 --
+  // and measured 224 vs 205 us at 32 streams, 703 vs 604 us on 8 channels: a tile's FIR time varies by
+  // +-20 % (profiles/r02_stamps_cfg2_s32.txt), so a static share of 7 tiles per workgroup ends with
+  // the slowest of 512, where the dispatcher hands the next tile to whichever CU is free; and what a
+  // fresh workgroup costs between two FIR loops is hidden behind the other workgroup's FIR anyway.)
   // When one workgroup per tile leaves CUs idle (one short stream), the phase groups of a tile are
   // split over several workgroups.
   // (Phase costs of the single-stream launch, R = 10, rocprofv3 with parts skipped,
