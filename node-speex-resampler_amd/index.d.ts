@@ -38,7 +38,11 @@ declare class SpeexResampler {
 
     /** consecutive chunks in one GPU launch; result[i] equals processChunk(chunks[i]) */
     processChunks(chunks: Buffer[]): Buffer[];
-    /** processChunk off the event loop; calls on one instance stay in order */
+    /**
+     * processChunk off the event loop; calls on one instance stay in order.  While one is pending the
+     * synchronous methods of the same instance (processChunk, processChunks, processChunkFloat, setRate,
+     * setQuality, skipZeros, resetMem, flush, destroy) throw: await the promise first.
+     */
     processChunkAsync(chunk: Buffer): Promise<Buffer>;
     /** interleaved float32 PCM in and out (speex_resampler_process_interleaved_float) */
     processChunkFloat(chunk: Buffer): Buffer;
