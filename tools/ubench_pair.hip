@@ -25,7 +25,7 @@ __device__ __forceinline__ void fma_ph(f32x2 &acc, const f32x2 &tap_pair, const 
 
 // PH = false: 10 accumulator pairs (channel pair), per bank 2 steps: 10 tap pairs + 2 ds_read_b64
 // PH = true : 5 accumulator pairs (phase pairs),  per bank 2 steps: 10 tap pairs + 1 ds_read2_b32
-template <bool PH, int GROUPS_PER_WAVE>
+template <bool PH, int GROUPS_PER_WAVE, int ROW_MASK = 15, bool PIN = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(80)))
 void fir(const float *__restrict__ rows, float *__restrict__ out, int l4, int num, int lds_floats) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -36,7 +36,7 @@ void fir(const float *__restrict__ rows, float *__restrict__ out, int l4, int nu
   float s = 0;
   for (int gi = 0; gi < GROUPS_PER_WAVE; gi++) {
     const int g = wave * GROUPS_PER_WAVE + gi;
-    const float *__restrict__ trow = rows + (size_t)(g & 15) * l4 * 4 * R;
+    const float *__restrict__ trow = rows + (size_t)(g & ROW_MASK) * l4 * 4 * R;  // ROW_MASK: 15 = a row per wave, 0 = all waves on one row (scalar cache hits)
     // CH: lane = period, frame stride 2 floats.  PH: lane = (period = lane/2, channel = lane&1)
     const float *xp = PH ? xs + (lane >> 1) * num * 2 + (lane & 1) + (g & 15) * 18 : xs + lane * num * 2 + (g & 15) * 18;
     constexpr int NA = PH ? R / 2 : R;
@@ -74,20 +74,20 @@ void fir(const float *__restrict__ rows, float *__restrict__ out, int l4, int nu
     };
     load_bank(ta, xa, trow, xp);
     for (int left = l4; left != 0; left--) {
-      touch_bank(ta, xa);
-      __builtin_amdgcn_sched_barrier(0);
+      if (PIN) touch_bank(ta, xa);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
       load_bank(tb, xb, trow + 2 * R, xp + 4);
-      __builtin_amdgcn_sched_barrier(0);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
       fma_bank(ta, xa);
-      __builtin_amdgcn_sched_barrier(0);
-      touch_bank(tb, xb);
-      __builtin_amdgcn_sched_barrier(0);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      if (PIN) touch_bank(tb, xb);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
       trow += 4 * R;
       xp += 8;
       load_bank(ta, xa, trow, xp);
-      __builtin_amdgcn_sched_barrier(0);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
       fma_bank(tb, xb);
-      __builtin_amdgcn_sched_barrier(0);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
     touch_bank(ta, xa);
 #pragma unroll
@@ -96,11 +96,11 @@ void fir(const float *__restrict__ rows, float *__restrict__ out, int l4, int nu
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <bool PH, int GPW>
+template <bool PH, int GPW, int ROW_MASK = 15, bool PIN = true>
 int run(const char *name, const float *rows, float *out, int blocks, int threads, int lds_bytes) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  auto k = fir<PH, GPW>;
+  auto k = fir<PH, GPW, ROW_MASK, PIN>;
   CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   float best = 1e30f;
   for (int rep = 0; rep < 8; rep++) {
@@ -131,6 +131,9 @@ int main() {
   for (int i = 0; i < 40; i++) run<false, 1>("warmup", rows, out, 3584, 1024, 76376);
   printf("---- many generations (the 32-stream regime)\n");
   run<false, 1>("CH 16 waves x 1 group, 76 KB (2 WG/CU)  [shipping]", rows, out, 3584, 1024, 76376);
+  run<false, 1, 0>("CH 16 waves, all waves on ONE tap row (scalar-cache hits)", rows, out, 3584, 1024, 76376);
+  run<false, 1, 3>("CH 16 waves, 4 distinct tap rows", rows, out, 3584, 1024, 76376);
+  run<false, 1, 15, false>("CH 16 waves, order left to the compiler (no sched_barrier)", rows, out, 3584, 1024, 76376);
   run<true, 1>("PH 16 waves x 1 group, 38 KB (2 WG/CU)", rows, out, 7168, 1024, 38400);
   run<true, 2>("PH  8 waves x 2 groups, 38 KB (4 WG/CU)", rows, out, 7168, 512, 38400);
   run<true, 4>("PH  4 waves x 4 groups, 38 KB (4 WG/CU by LDS)", rows, out, 7168, 256, 38400);
