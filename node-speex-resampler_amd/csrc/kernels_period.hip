@@ -49,6 +49,8 @@ __device__ unsigned long long g_stamps[8192 * 16];
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// taps per bank of the FIR loop's two-bank pipeline, by phases per wave (host + device)
+__host__ __device__ constexpr int bank_taps(int r) { return r == 10 ? 20 : 30; }
 // dword-aligned wide global stores (global memory needs only dword alignment for x2/x4)
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -123,14 +125,18 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   // A wait is lgkmcnt(0) (scalar loads return out of order and share the counter with LDS),
   // so a bank's loads must be issued right AFTER the other bank's wait; `touch_bank` is an
   // empty asm that reads the bank and thereby makes hipcc put the wait exactly there.
-  // A bank is always 20 taps = 10 SGPR pairs: 2 steps of R = 10 phases, or 4 steps of R = 5.
-  constexpr int STEPS = 20 / R;  // steps per bank; an iteration is two banks
-  static_assert(R == 10 || R == 5, "a bank holds 20 taps");
-  const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (2 * STEPS * R);
-  f32x2 ta[10], tb[10], xa[STEPS], xb[STEPS];
-  auto load_bank = [&](f32x2 (&t)[10], f32x2 (&x)[STEPS], const float *tp, const float *sp) {
+  // A bank is 20 taps = 10 SGPR pairs for R = 10 (2 steps).  The R = 5 kernel only runs launches of
+  // one generation -- one workgroup per CU, 4 waves per SIMD, so the 80-SGPR cap that buys the second
+  // resident workgroup is not needed there -- and takes banks of 30 taps (6 steps): 30 FMAs between
+  // two waits instead of 20 give the scalar loads half as much time again to land.
+  constexpr int BANK = bank_taps(R), NP = BANK / 2;  // taps / SGPR pairs per bank
+  constexpr int STEPS = BANK / R;                     // steps per bank; an iteration is two banks
+  static_assert(R == 10 || R == 5, "phases per wave");
+  const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (2 * BANK);
+  f32x2 ta[NP], tb[NP], xa[STEPS], xb[STEPS];
+  auto load_bank = [&](f32x2 (&t)[NP], f32x2 (&x)[STEPS], const float *tp, const float *sp) {
 #pragma unroll
-    for (int j = 0; j < 10; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
+    for (int j = 0; j < NP; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
 #pragma unroll
     for (int u = 0; u < STEPS; u++) {
       if (CT == 2) {
@@ -141,18 +147,20 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
       }
     }
   };
-  auto touch_bank = [&](const f32x2 (&t)[10], const f32x2 (&x)[STEPS]) {
-    if constexpr (STEPS == 2) {
+  auto touch_bank = [&](const f32x2 (&t)[NP], const f32x2 (&x)[STEPS]) {
+    if constexpr (NP == 10) {
       asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
                    "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]));
     } else {
+      static_assert(NP == 15 && STEPS == 6, "touch_bank lists 10 pairs + 2 samples or 15 pairs + 6 samples");
       asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
-                   "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+                   "s"(t[8]), "s"(t[9]), "s"(t[10]), "s"(t[11]), "s"(t[12]), "s"(t[13]), "s"(t[14]), "v"(x[0]),
+                   "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]));
     }
   };
   // phases [LO, HI) of the group only: the head and tail iterations of a group, where the host
   // knows half of the rows to be all zero (below)
-  auto fma_bank = [&](const f32x2 (&t)[10], const f32x2 (&x)[STEPS], auto lo_c, auto hi_c) {
+  auto fma_bank = [&](const f32x2 (&t)[NP], const f32x2 (&x)[STEPS], auto lo_c, auto hi_c) {
     constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
 #pragma unroll
     for (int u = 0; u < STEPS; u++)
@@ -164,13 +172,13 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
     for (uint32_t left = count; left != 0; left--) {
       touch_bank(ta, xa);
       __builtin_amdgcn_sched_barrier(0);
-      load_bank(tb, xb, trow + 20, xp + STEPS * C);
+      load_bank(tb, xb, trow + BANK, xp + STEPS * C);
       __builtin_amdgcn_sched_barrier(0);
       fma_bank(ta, xa, lo_c, hi_c);
       __builtin_amdgcn_sched_barrier(0);
       touch_bank(tb, xb);
       __builtin_amdgcn_sched_barrier(0);
-      trow += 40;
+      trow += 2 * BANK;
       xp += 2 * STEPS * C;
       if (PADDED && --to_wrap == 0) {  // wave-uniform: the window pointer steps over the bank padding
         xp += p.pad;
@@ -454,11 +462,12 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
 // most one workgroup per CU was tried: removing the cap from this kernel gave 13.36 -> 13.0 us on
 // one stream, but as a separate __global__ around a shared device body it measured 13.59 vs 13.53 us,
 // i.e. nothing, and the refactoring cost the capped kernel 0.17 us -- not kept.)
+// The R = 5 instances only ever run one workgroup per CU (launch_period): no 64-VGPR limit for them.
 //
 // Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
 // shares of its phase groups.
 template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
-__global__ __launch_bounds__(1024, 8) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
+__global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   // A workgroup that starts beside another one's FIR loop competes with 16 older waves for every
@@ -540,8 +549,9 @@ hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const Des
 }
 
 const size_t kSlack = 16;  // floats: window starts on the input's 16-byte grid, staged by 8
-// Phases per wave: R = 10 (banks of 2 steps) or R = 5 (banks of 4 steps; same 20 taps per bank, so the
-// same distance between a bank's loads and its use).  R = 5 pads its rows by 4 instead of 9 steps and
+// Phases per wave: R = 10 (banks of 20 taps = 2 steps) or R = 5 (banks of 30 taps = 6 steps, see
+// fir_group; with 20-tap banks as well the one-stream launch measured 12.08 vs 11.95 us on the same
+// box).  R = 5 pads its rows by 4 instead of 9 steps and
 // gives a tile twice as many wave-sized pieces -- what a launch of a single generation of workgroups
 // needs -- at half the FMAs per sample read and 20-byte instead of 40-byte store pieces per lane.
 uint32_t default_r() {
@@ -563,7 +573,7 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
 PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r) {
   PeriodPlan t;
   t.r = r;
-  const uint32_t it_steps = 40 / t.r;  // steps per loop iteration (two banks)
+  const uint32_t it_steps = 2 * bank_taps(t.r) / t.r;  // steps per loop iteration (two banks)
   t.ct = (channels % 2 == 0) ? 2 : 1;
   t.cgroups = channels / t.ct;
   t.groups = (f.den + t.r - 1) / t.r;
@@ -578,7 +588,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * t.r * f.num) / f.den) + t.row_len;
   t.lane_periods = 64 / t.cgroups;  // revised below once the window size is known
   // + one iteration (40 floats) of zero padding: the tap pipeline prefetches one past the end
-  t.rows_floats = static_cast<size_t>(t.groups) * t.row_len * t.r + 40;
+  t.rows_floats = static_cast<size_t>(t.groups) * t.row_len * t.r + 2 * bank_taps(t.r);
   // Bank padding: the lanes of a wave read the window num*channels floats apart.  Pick the pad
   // (multiple of 4 floats, inserted after every period) with the fewest lanes of a half-wave on
   // the same bank (ds_read_b32) / bank pair (ds_read_b64); 1 = conflict-free.  (Measured on
@@ -685,7 +695,7 @@ void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<flo
   //   trips[g]  = head | tail << 4 | iterations << 8 (fir_group): iterations of the group's loop, of which the
   //               first `head` touch only rows 0..R/2-1 and the last `tail` only rows R/2..R-1
   rows->assign(t.rows_floats + 3 * t.groups, 0.f);
-  const uint32_t it_steps = 40 / t.r;
+  const uint32_t it_steps = 2 * bank_taps(t.r) / t.r;
   for (uint32_t g = 0; g < t.groups; g++) {
     const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
     const uint32_t k = group_shift(f, t, g);
