@@ -847,6 +847,13 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
     const uint32_t stride = ((wave_groups * t.r + 1) / 2 + 5) | 1u;  // samples/2 + the shift + 4 dwords of slack, odd
     if (static_cast<size_t>(stride) * t.lane_periods * 4 + 16 <= t.window_bytes) p.image_stride = stride;
   }
+  // (The tail: a launch of several generations ends ragged -- profiles/r02_stamps_cfg2_s32.txt: the last
+  //  tenth of the workgroups finish over 22 of 204 us; 64 streams take 404 us against 209 for 32, so ~14 us
+  //  of a launch are start + tail.  Tried: the tiles of the last 1-12 streams -- the last ones dispatched --
+  //  as 2 or 4 shares of their phase groups each, like the tiles of a one-stream launch.  16 streams
+  //  114.3 -> 111.1 us with one stream shared out, 32 streams within the +-1.5 % of repeated runs for 1-3
+  //  streams and slower beyond (8: 219 vs 213 us; 4 shares always slower), 64 streams 404 -> 407: a share
+  //  stages the whole window again and leaves its CU with half the FIR waves; removed.)
   p.threads = 0;  // set below
   static const int env_prio = std::getenv("SPEEXHIP_PRIO") ? std::atoi(std::getenv("SPEEXHIP_PRIO")) : 3;
   p.prio = static_cast<uint32_t>(env_prio);
