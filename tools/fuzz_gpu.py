@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Differential fuzz of libspeexhip against the oracle on one MI355X (test infrastructure: this is a
+checker run, the oracle is never part of the product path).
+
+Random (channels, in_rate, out_rate, quality) -- common audio rates, rates that reduce to small
+ratios (the slide kernel's shapes), near-unity and coprime oddballs (long periods, the exact kernel) --
+driven through a random call sequence: chunk sizes from 0 to a few hundred thousand frames, output
+capacities that are sometimes too small (unconsumed input, reference resample.c:1061-1082), int16 and
+float calls mixed on one state, occasional set_rate / set_quality / skip_zeros / reset_mem in between.
+EXACT mode must be bit-identical (samples, counters, positions); FAST mode within +-1 LSB (int16) /
+the float bound of tests/test_gpu_parity.py, counters and positions identical.  A trial ends at a
+set_rate that returns RESAMPLER_ERR_OVERFLOW in both (the one documented deviation: DESIGN 3.5).
+
+usage: python tools/fuzz_gpu.py [--seconds 240] [--seed 1] [--max-frames 300000]
+Prints one line per failing trial (with the seed that reproduces it) and a summary; exit code 1 on
+any failure.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "node-speex-resampler_amd", "python"))
+import oracle as orc  # noqa: E402
+import speexhip  # noqa: E402
+
+COMMON = [8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000, 176400, 192000]
+
+
+def pick_rates(rng):
+    kind = rng.randint(0, 10)
+    if kind < 5:
+        return int(rng.choice(COMMON)), int(rng.choice(COMMON))
+    if kind < 7:  # small ratios a:b times a base
+        a, b = int(rng.randint(1, 13)), int(rng.randint(1, 13))
+        base = int(rng.choice([1000, 4000, 8000, 11025]))
+        return a * base, b * base
+    if kind < 9:  # near unity / oddballs with long periods
+        r = int(rng.choice(COMMON))
+        return r, r + int(rng.randint(-300, 301)) or 1
+    return int(rng.randint(2000, 200000)), int(rng.randint(2000, 200000))
+
+
+def signal(rng, frames, ch, as_float):
+    kind = rng.randint(0, 4)
+    if kind == 0:
+        x = rng.randint(-32768, 32768, size=(frames, ch)).astype(np.int16)  # full-scale noise (saturates)
+    elif kind == 1:
+        t = np.arange(frames)[:, None] * (0.01 + 0.3 * rng.rand(1, ch))
+        x = (np.sin(t) * rng.randint(100, 32767)).astype(np.int16)
+    elif kind == 2:
+        x = np.zeros((frames, ch), np.int16)
+        if frames:
+            x[rng.randint(0, frames, size=max(1, frames // 50))] = rng.choice([-32768, 32767])
+    else:
+        x = (rng.randn(frames, ch) * 3000).clip(-32768, 32767).astype(np.int16)
+    if as_float:
+        return (x.astype(np.float32) * np.float32(1.0 + rng.rand())).astype(np.float32)
+    return x
+
+
+def one_trial(seed, max_frames):
+    rng = np.random.RandomState(seed)
+    ch = int(rng.choice([1, 1, 2, 2, 2, 3, 4, 5, 6, 7, 8]))
+    i, o = pick_rates(rng)
+    q = int(rng.randint(0, 11))
+    mode = speexhip.MODE_EXACT if rng.rand() < 0.35 else speexhip.MODE_FAST
+    what = "seed=%d ch=%d %d->%d q=%d %s" % (seed, ch, i, o, q, "exact" if mode == speexhip.MODE_EXACT else "fast")
+    try:
+        ref = orc.Oracle(ch, i, o, q)
+    except Exception:
+        ref = None
+    try:
+        got_r = speexhip.Resampler(ch, i, o, q, mode=mode)
+    except Exception as e:
+        if ref is None:
+            return None, what + " (both refuse)"
+        return "library refused a configuration the oracle accepts: %r" % (e,), what
+    if ref is None:
+        got_r.close()
+        return "library accepted a configuration the oracle refuses", what
+    n_calls = int(rng.randint(1, 7))
+    frames_done = 0
+    for call in range(n_calls):
+        ctl = rng.rand()
+        if call and ctl < 0.08:
+            q2 = int(rng.randint(0, 11))
+            if ref.set_quality(q2) != got_r.set_quality(q2):
+                return "set_quality(%d): return codes differ" % q2, what
+        elif call and ctl < 0.16:
+            i2, o2 = pick_rates(rng)
+            rc_ref, rc_got = ref.set_rate(i2, o2), got_r.set_rate(i2, o2)
+            if rc_ref != rc_got:
+                return "set_rate(%d,%d): oracle rc %d, library rc %d" % (i2, o2, rc_ref, rc_got), what
+            if rc_ref == 5:
+                # RESAMPLER_ERR_OVERFLOW: the reference returns with its state half-updated (new rates, old
+                # filter: resample.c:1130-1136 return before update_filter), the library with its state
+                # untouched (documented deviation) -- nothing comparable after this point
+                break
+        elif call and ctl < 0.20:
+            ref.skip_zeros()
+            got_r.skip_zeros()
+        elif call and ctl < 0.23:
+            ref.reset_mem()
+            got_r.reset_mem()
+        as_float = rng.rand() < 0.3
+        size_kind = rng.randint(0, 6)
+        frames = [0, 1, int(rng.randint(2, 200)), int(rng.randint(200, 5000)), int(rng.randint(5000, 60000)),
+                  int(rng.randint(60000, max_frames + 1))][size_kind]
+        frames = min(frames, max(0, max_frames * 2 - frames_done))
+        frames_done += frames
+        x = signal(rng, frames, ch, as_float)
+        in_r, out_r = ref.rate()
+        full = int(frames * out_r / max(in_r, 1)) + 64
+        cap = full if rng.rand() < 0.7 else int(rng.randint(0, full + 1))
+        if as_float:
+            want, wu = ref.process_float(x, cap)
+            got, gu = got_r.process_float(x, cap)
+        else:
+            want, wu = ref.process(x, cap)
+            got, gu = got_r.process(x, cap)
+        tag = "call %d (%s, %d frames, cap %d)" % (call, "float" if as_float else "int16", frames, cap)
+        if gu != wu or got.shape != want.shape:
+            return "%s: consumed/produced %d/%d, oracle %d/%d" % (tag, gu, got.shape[0], wu, want.shape[0]), what
+        if tuple(got_r.position()) != tuple(ref.position()):
+            return "%s: position %s, oracle %s" % (tag, got_r.position(), ref.position()), what
+        if got.size == 0:
+            continue
+        if mode == speexhip.MODE_EXACT:
+            if not np.array_equal(got, want):
+                bad = np.argwhere(got != want)
+                return "%s: EXACT differs in %d samples, first at %s" % (tag, len(bad), bad[0]), what
+        elif as_float:
+            scale = max(1.0, float(np.abs(want).max()))
+            err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+            if err > 4e-6 * scale * 8:  # 8x the bound measured on unit-scale signals: inputs here reach 65534
+                return "%s: float error %.3g at scale %.3g" % (tag, err, scale), what
+        else:
+            d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+            if d.max() > 1:
+                return "%s: %d LSB at %s" % (tag, d.max(), np.unravel_index(np.argmax(d), d.shape)), what
+            # share of samples that differ at all (each by exactly 1): ~E|difference of the two fp32 rounding
+            # errors| in LSB, growing like sqrt(taps): measured up to 3.1e-3 for filters of <= 256 taps,
+            # 5-8e-3 for decimation filters of 560-1416 taps, 1.3e-2 at 2824 taps (full-scale noise)
+            if got.size >= 20000 and (d != 0).mean() > 5e-3 * max(1.0, 1.2 * (ref.taps / 256.0) ** 0.5):
+                return "%s: %.2e of samples differ (%d taps)" % (tag, (d != 0).mean(), ref.taps), what
+    got_r.close()
+    return None, what
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-frames", type=int, default=300000)
+    ap.add_argument("--only", type=int, default=None, help="run exactly this trial seed")
+    args = ap.parse_args()
+    orc.build()
+    t0 = time.time()
+    trials = fails = 0
+    seed = args.seed * 1000003
+    while time.time() - t0 < args.seconds:
+        s = args.only if args.only is not None else seed + trials
+        err, what = one_trial(s, args.max_frames)
+        trials += 1
+        if err:
+            fails += 1
+            print("FAIL %s: %s" % (what, err), flush=True)
+        if args.only is not None:
+            print(what, "ok" if not err else "")
+            break
+    print("fuzz: %d trials, %d failures, %.0f s" % (trials, fails, time.time() - t0))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
