@@ -168,6 +168,11 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
       for (int i = LO; i < HI; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
   };
   load_bank(ta, xa, trow, xp);
+  // (Per trip hipcc spends two vector instructions beside the 40 FMAs: the window address and the trip
+  //  count, which it keeps in a VGPR -- v_add_co, branch on vcc -- because no SGPR is left under the cap.
+  //  Forcing the count into an SGPR, or running two iterations per trip (one address step, scalar count:
+  //  1 in 81), pushes SGPR spills past the 64 VGPRs into scratch in every instantiation: 32 streams
+  //  208 -> 219 us, 8 channels 607 -> 667, float 273 -> 337.)
   auto run = [&](uint32_t count, auto lo_c, auto hi_c) {
     for (uint32_t left = count; left != 0; left--) {
       touch_bank(ta, xa);
