@@ -315,6 +315,14 @@ SPEEXHIP_API int speexhip_resampler_get_channel_position(SpeexHipResamplerState 
  * an aborted install had already allocated, without exhausting HBM); 0 = off. */
 SPEEXHIP_API void speexhip_debug_fail_device_allocs(int n);
 
+/* No counterpart in the reference (its state is plain heap memory, speex_resampler_destroy
+ * resample.c:858-868 frees it).  Destroying a state here returns its device buffers, pinned staging
+ * buffers, stream and events to a process-wide pool, so that the next state -- callers make one per
+ * file or per connection, src/test.ts:27 -- does not pay hipHostMalloc / hipHostFree again
+ * (csrc/pool.h; idle memory bounded by SPEEXHIP_POOL_MB, default 1024 MiB device + 256 MiB pinned,
+ * 0 = no pool).  This hands everything idle back to the driver; returns the bytes released. */
+SPEEXHIP_API uint64_t speexhip_release_cached_memory(void);
+
 #ifdef __cplusplus
 }
 #endif

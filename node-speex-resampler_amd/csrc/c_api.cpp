@@ -4,6 +4,7 @@
 
 #include "../../include/speexhip_resampler.h"
 #include "engine.h"
+#include "pool.h"
 
 using speexhip::Batch;
 
@@ -180,6 +181,11 @@ int speexhip_resampler_get_channel_position(SpeexHipResamplerState *st, uint32_t
 }
 
 void speexhip_debug_fail_device_allocs(int n) { speexhip::debug_fail_device_allocs(n); }
+uint64_t speexhip_release_cached_memory(void) {
+  const uint64_t tables = speexhip::release_cached_tables();  // first: they return their buffers to the pool
+  (void)tables;
+  return speexhip::pool::release_idle();
+}
 
 void speexhip_resampler_get_rate(SpeexHipResamplerState *st, uint32_t *in_rate, uint32_t *out_rate) {
   *in_rate = st->batch->filter().in_rate;

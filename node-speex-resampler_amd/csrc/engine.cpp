@@ -1,10 +1,14 @@
 // engine.cpp -- see engine.h.
 #include "engine.h"
 
+#include "pool.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <list>
+#include <mutex>
 
 namespace speexhip {
 namespace {
@@ -51,11 +55,11 @@ std::atomic<int> g_fail_allocs{0};
 // Device allocation of the filter installs: ALLOC_FAILED when the device is out of memory (or the
 // test hook says so) -- the caller then falls back to resampler_basic_zero like the reference
 // (resample.c:785-791) --, DEVICE for anything else.
-int dev_alloc(void **ptr, size_t bytes) {
+int dev_alloc(int device, void **ptr, size_t bytes) {
   *ptr = nullptr;
   // test hook: a countdown -- the allocation that brings it to zero fails
   if (g_fail_allocs.load() > 0 && g_fail_allocs.fetch_sub(1) == 1) return SPEEXHIP_ERR_ALLOC_FAILED;
-  const hipError_t e = hipMalloc(ptr, bytes);
+  const hipError_t e = pool::device_get(device, ptr, bytes);
   if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();
     return SPEEXHIP_ERR_ALLOC_FAILED;
@@ -106,7 +110,7 @@ Batch *Batch::create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_
     } else {
       b->n_streams_ = n_streams;
       b->channels_ = channels;
-      e = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality, &b->filter_);
+      e = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality, &b->filter_, /*fill_table=*/false);
       if (e == SPEEXHIP_ERR_SUCCESS) e = b->setup();
       if (e != SPEEXHIP_ERR_SUCCESS) {
         delete b;
@@ -141,94 +145,197 @@ int Batch::setup() {
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   if (n_streams_ > static_cast<uint32_t>(kMaxPackedStreams)) {
     const size_t ring_bytes = sizeof(StreamDesc) * n_streams_ * kRing;
-    HIP_TRY(hipHostMalloc(&h_ring_, ring_bytes, hipHostMallocDefault));
-    HIP_TRY(hipMalloc(&d_ring_, ring_bytes));
-    for (int i = 0; i < kRing; i++) HIP_TRY(hipEventCreateWithFlags(&ring_done_[i], hipEventDisableTiming));
+    HIP_TRY(pool::pinned_get(reinterpret_cast<void **>(&h_ring_), ring_bytes));
+    HIP_TRY(pool::device_get(device_, reinterpret_cast<void **>(&d_ring_), ring_bytes));
+    for (int i = 0; i < kRing; i++) HIP_TRY(pool::event_get(device_, &ring_done_[i]));
   }
   HIP_TRY(hipDeviceSynchronize());
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-// Build everything on the device that depends on the filter `f` -- the sinc table, the fast
-// kernels' tap rows, the history buffers (hist = all streams' lines, hist_frames_cap frames each,
-// interleaved; empty = silence) -- and only then replace what the batch holds: a failed
-// allocation leaves the batch exactly as it was (the caller decides what a failure means,
-// resample.c:785-791).
-int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, uint32_t hist_frames_cap) {
-  struct Fresh {
-    float *table = nullptr, *hist[2] = {nullptr, nullptr}, *period = nullptr, *fine = nullptr, *slide = nullptr;
-    ~Fresh() {
-      (void)hipFree(table);
-      (void)hipFree(hist[0]);
-      (void)hipFree(hist[1]);
-      (void)hipFree(period);
-      (void)hipFree(fine);
-      (void)hipFree(slide);
-    }
-  } n;
+DeviceTables::~DeviceTables() {
+  // (whoever dropped the last reference has synchronised: ~Batch, install_filter)
+  pool::device_put(device, table);
+  pool::device_put(device, period_rows);
+  pool::device_put(device, fine_rows);
+  pool::device_put(device, slide_rows);
+}
+
+namespace {
+struct TablesKey {
+  int device;
+  uint32_t num, den, channels;
+  int quality;
+  bool operator==(const TablesKey &o) const {
+    return device == o.device && num == o.num && den == o.den && channels == o.channels && quality == o.quality;
+  }
+};
+struct TablesCache {
+  std::mutex mu;
+  std::list<std::pair<TablesKey, std::shared_ptr<const DeviceTables>>> lru;  // most recent first
+};
+TablesCache &tables_cache() {
+  static TablesCache *c = new TablesCache();  // never destroyed, like the pool
+  return *c;
+}
+const size_t kCachedTables = 24;                           // entries kept beyond the ones in use
+const size_t kCacheableBytes = static_cast<size_t>(64) << 20;  // bigger table sets are built per state
+
+// Design (host, double precision), plan and upload the tables of filter `g` (geometry only: num,
+// den, quality, taps ...) for `channels` channels.
+int build_tables(int device, const FilterSpec &g, uint32_t channels, std::shared_ptr<const DeviceTables> *out) {
+  FilterSpec f;
+  int rc = design_filter_frac(g.num, g.den, g.in_rate, g.out_rate, g.quality, &f);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  auto t = std::make_shared<DeviceTables>();
+  t->device = device;
   auto upload = [&](float **dst, const float *src, size_t count) -> int {
-    const int rc = dev_alloc(reinterpret_cast<void **>(dst), std::max<size_t>(count * sizeof(float), 16));
-    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    const int arc = dev_alloc(device, reinterpret_cast<void **>(dst), std::max<size_t>(count * sizeof(float), 16));
+    if (arc != SPEEXHIP_ERR_SUCCESS) return arc;
     if (count != 0) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
+    t->bytes += count * sizeof(float);
     return SPEEXHIP_ERR_SUCCESS;
   };
-  int rc = upload(&n.table, f.table.data(), f.table_len);
+  rc = upload(&t->table, f.table.data(), f.table_len);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  t->geo = exact_geometry(f, channels, kLdsBudget);
+  t->geo_ch = exact_geometry(f, 1, kLdsBudget);
+  t->period = plan_period(f, channels, kLdsBudget);
+  if (t->period.usable) {
+    std::vector<float> rows;
+    build_period_rows(f, t->period, &rows);
+    rc = upload(&t->period_rows, rows.data(), rows.size());
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  }
+  if (t->period.usable && t->period.r == 10) {
+    static const bool no_fine = std::getenv("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
+    t->fine = plan_period_r(f, channels, kLdsBudget, 5);
+    if (no_fine || t->fine.lane_periods != t->period.lane_periods) t->fine.usable = false;
+    if (t->fine.usable) {
+      std::vector<float> rows;
+      build_period_rows(f, t->fine, &rows);
+      rc = upload(&t->fine_rows, rows.data(), rows.size());
+      if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    }
+  }
+  t->slide = plan_slide(f, channels);
+  if (t->slide.usable && !t->period.usable) {
+    std::vector<float> rows;
+    build_slide_rows(f, t->slide, &rows);
+    rc = upload(&t->slide_rows, rows.data(), rows.size());
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  } else {
+    t->slide.usable = false;
+  }
+  *out = t;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int acquire_tables(int device, const FilterSpec &g, uint32_t channels, std::shared_ptr<const DeviceTables> *out) {
+  static const bool enabled = [] {
+    const char *e = std::getenv("SPEEXHIP_POOL_MB");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  // (an armed allocation-failure hook must see the allocations: no cache then)
+  const bool cacheable = enabled && g_fail_allocs.load() <= 0;
+  const TablesKey key{device, g.num, g.den, channels, g.quality};
+  TablesCache &c = tables_cache();
+  if (cacheable) {
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (auto it = c.lru.begin(); it != c.lru.end(); ++it)
+      if (it->first == key) {
+        c.lru.splice(c.lru.begin(), c.lru, it);
+        *out = it->second;
+        return SPEEXHIP_ERR_SUCCESS;
+      }
+  }
+  std::shared_ptr<const DeviceTables> built;
+  const int rc = build_tables(device, g, channels, &built);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  if (cacheable && built->bytes <= kCacheableBytes) {
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (auto &e : c.lru)
+      if (e.first == key) {  // another thread built the same tables meanwhile: share those
+        *out = e.second;
+        return SPEEXHIP_ERR_SUCCESS;
+      }
+    c.lru.emplace_front(key, built);
+    size_t idle = 0;
+    for (auto it = c.lru.begin(); it != c.lru.end();) {
+      if (it->second.use_count() == 1 && ++idle > kCachedTables)
+        it = c.lru.erase(it);  // nobody uses them: back to the pool
+      else
+        ++it;
+    }
+  }
+  *out = built;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+}  // namespace
+
+size_t release_cached_tables() {
+  TablesCache &c = tables_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  size_t bytes = 0;
+  for (auto it = c.lru.begin(); it != c.lru.end();) {
+    if (it->second.use_count() == 1) {
+      bytes += it->second->bytes;
+      it = c.lru.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  return bytes;
+}
+
+// Put everything on the device that depends on the filter `f` (geometry: the tables are designed
+// here on a cache miss) in place -- the shared tables, the history buffers (hist = all streams'
+// lines, hist_frames_cap frames each, interleaved; empty = silence) -- and only then replace what
+// the batch holds: a failed allocation leaves the batch exactly as it was (the caller decides what
+// a failure means, resample.c:785-791).
+int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, uint32_t hist_frames_cap) {
+  std::shared_ptr<const DeviceTables> tables;
+  int rc = acquire_tables(device_, f, channels_, &tables);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  struct Fresh {
+    int device = 0;
+    float *hist[2] = {nullptr, nullptr};
+    ~Fresh() {
+      pool::device_put(device, hist[0]);
+      pool::device_put(device, hist[1]);
+    }
+  } n;
+  n.device = device_;
   const size_t hist_elems = static_cast<size_t>(hist_frames_cap) * channels_;
   const size_t hist_bytes = std::max<size_t>(hist_elems * n_streams_ * sizeof(float), 16);
   for (int i = 0; i < 2; i++) {
-    rc = dev_alloc(reinterpret_cast<void **>(&n.hist[i]), hist_bytes);
+    rc = dev_alloc(device_, reinterpret_cast<void **>(&n.hist[i]), hist_bytes);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     HIP_TRY(hipMemset(n.hist[i], 0, hist_bytes));
   }
   if (!hist.empty())
     HIP_TRY(hipMemcpy(n.hist[0], hist.data(), hist_elems * n_streams_ * sizeof(float), hipMemcpyHostToDevice));
-  const ExactGeometry geo = exact_geometry(f, channels_, kLdsBudget);
-  const ExactGeometry geo_ch = exact_geometry(f, 1, kLdsBudget);
-  PeriodPlan period = plan_period(f, channels_, kLdsBudget);
-  if (period.usable) {
-    std::vector<float> rows;
-    build_period_rows(f, period, &rows);
-    rc = upload(&n.period, rows.data(), rows.size());
-    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  }
-  PeriodPlan fine;
-  if (period.usable && period.r == 10) {
-    static const bool no_fine = std::getenv("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
-    fine = plan_period_r(f, channels_, kLdsBudget, 5);
-    if (no_fine || fine.lane_periods != period.lane_periods) fine.usable = false;
-    if (fine.usable) {
-      std::vector<float> rows;
-      build_period_rows(f, fine, &rows);
-      rc = upload(&n.fine, rows.data(), rows.size());
-      if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-    }
-  }
-  SlidePlan slide = plan_slide(f, channels_);
-  if (slide.usable && !period.usable) {
-    std::vector<float> rows;
-    build_slide_rows(f, slide, &rows);
-    rc = upload(&n.slide, rows.data(), rows.size());
-    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  } else {
-    slide.usable = false;
-  }
-  // commit: nothing below can fail
-  std::swap(d_table_, n.table);
+  // commit: nothing below can fail.  What the batch held goes back to the pool / the cache, so
+  // nothing in flight may still read it (hipFree used to wait by itself).
+  if (tables_ != nullptr) HIP_TRY(hipDeviceSynchronize());
   std::swap(d_hist_[0], n.hist[0]);
-  std::swap(d_hist_[1], n.hist[1]);
-  std::swap(d_period_rows_, n.period);
-  std::swap(d_period_fine_rows_, n.fine);
-  std::swap(d_slide_rows_, n.slide);  // (~Fresh releases what the batch held before)
+  std::swap(d_hist_[1], n.hist[1]);  // (~Fresh releases the old history buffers)
+  tables_ = tables;
+  d_table_ = tables->table;
+  d_period_rows_ = tables->period_rows;
+  d_period_fine_rows_ = tables->fine_rows;
+  d_slide_rows_ = tables->slide_rows;
+  const std::vector<float> no_table;
   filter_ = f;
+  filter_.table = no_table;  // the host copy of the sinc table lives only while the tables are built
   line_ = std::max(line_, f.taps - 1 + kBlockIn);  // grow-only, resample.c:709-720
   hist_elems_ = hist_elems;
   hist_cur_ = 0;
-  exact_geo_ = geo;
-  exact_geo_ch_ = geo_ch;
-  period_ = period;
-  period_fine_ = fine;
-  slide_ = slide;
+  exact_geo_ = tables->geo;
+  exact_geo_ch_ = tables->geo_ch;
+  period_ = tables->period;
+  period_fine_ = tables->fine;
+  slide_ = tables->slide;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -324,7 +431,8 @@ int Batch::set_rate_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rat
       filter_.den == ratio_den)
     return SPEEXHIP_ERR_SUCCESS;
   FilterSpec next;
-  const int design_rc = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, filter_.quality, &next);
+  const int design_rc =
+      design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, filter_.quality, &next, /*fill_table=*/false);
   if (design_rc != SPEEXHIP_ERR_SUCCESS && design_rc != SPEEXHIP_ERR_ALLOC_FAILED) return design_rc;
   // phase numerators move to the new denominator (resample.c:1130-1139; next.num / next.den are set
   // even when the design failed later on).  On overflow the reference returns with its state
@@ -343,7 +451,7 @@ int Batch::set_quality(int quality) {
   FilterSpec next;
   // the stored ratio is already reduced, so designing from it reproduces num/den
   const int design_rc =
-      design_filter_frac(filter_.num, filter_.den, filter_.in_rate, filter_.out_rate, quality, &next);
+      design_filter_frac(filter_.num, filter_.den, filter_.in_rate, filter_.out_rate, quality, &next, /*fill_table=*/false);
   if (design_rc != SPEEXHIP_ERR_SUCCESS && design_rc != SPEEXHIP_ERR_ALLOC_FAILED) return design_rc;
   return change_filter(next, design_rc, nullptr);
 }
@@ -378,23 +486,20 @@ int Batch::reset_mem() {  // resample.c:1208-1220
 
 Batch::~Batch() {
   DeviceScope device_scope(device_);
-  if (order_ev_) (void)hipEventDestroy(order_ev_);
-  if (own_stream_) (void)hipStreamSynchronize(own_stream_);
-  (void)hipFree(d_table_);
-  (void)hipFree(d_hist_[0]);
-  (void)hipFree(d_hist_[1]);
-  (void)hipFree(d_period_rows_);
-  (void)hipFree(d_period_fine_rows_);
-  (void)hipFree(d_slide_rows_);
-  (void)hipFree(d_ring_);
-  if (h_ring_) (void)hipHostFree(h_ring_);
-  for (int i = 0; i < kRing; i++)
-    if (ring_done_[i]) (void)hipEventDestroy(ring_done_[i]);
-  (void)hipFree(d_stage_in_);
-  (void)hipFree(d_stage_out_);
-  if (h_pin_in_) (void)hipHostFree(h_pin_in_);
-  if (h_pin_out_) (void)hipHostFree(h_pin_out_);
-  if (own_stream_) (void)hipStreamDestroy(own_stream_);
+  // everything goes back to the pool (pool.h) for the next state, once nothing in flight uses it
+  (void)hipDeviceSynchronize();
+  pool::event_put(device_, order_ev_);
+  tables_.reset();  // shared (DeviceTables): the cache keeps them for the next state with this filter
+  pool::device_put(device_, d_hist_[0]);
+  pool::device_put(device_, d_hist_[1]);
+  pool::device_put(device_, d_ring_);
+  pool::pinned_put(h_ring_);
+  for (int i = 0; i < kRing; i++) pool::event_put(device_, ring_done_[i]);
+  pool::device_put(device_, d_stage_in_);
+  pool::device_put(device_, d_stage_out_);
+  pool::pinned_put(h_pin_in_);
+  pool::pinned_put(h_pin_out_);
+  pool::stream_put(device_, own_stream_);
 }
 
 CallPlan Batch::peek(uint32_t s, uint32_t in_len, uint32_t out_capacity, bool float_io) const {
@@ -484,7 +589,7 @@ int Batch::run_channel(uint32_t c, const void *d_in, uint32_t in_stride, uint32_
   const uint32_t walked = plan.magic_used + plan.consumed;
   if (plan.produced == 0 && walked == 0) return SPEEXHIP_ERR_SUCCESS;
   if (have_last_stream_ && stream != last_stream_) {
-    if (order_ev_ == nullptr) HIP_TRY(hipEventCreateWithFlags(&order_ev_, hipEventDisableTiming));
+    if (order_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &order_ev_));
     HIP_TRY(hipEventRecord(order_ev_, last_stream_));
     HIP_TRY(hipStreamWaitEvent(stream, order_ev_, 0));
   }
@@ -595,7 +700,7 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
     // ping-pong buffers alternate): a call enqueued on another stream than the previous one
     // waits for it on the device.
     if (have_last_stream_ && stream != last_stream_) {
-      if (order_ev_ == nullptr) HIP_TRY(hipEventCreateWithFlags(&order_ev_, hipEventDisableTiming));
+      if (order_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &order_ev_));
       HIP_TRY(hipEventRecord(order_ev_, last_stream_));
       HIP_TRY(hipStreamWaitEvent(stream, order_ev_, 0));
     }
@@ -637,30 +742,25 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
 }
 
 int Batch::ensure_stage(size_t in_bytes, size_t out_bytes) {
-  if (own_stream_ == nullptr) HIP_TRY(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
-  if (in_bytes > stage_in_cap_) {  // grow-only, like the wrapper's heap buffers (src/index.ts:71-87)
-    (void)hipFree(d_stage_in_);
-    if (h_pin_in_) (void)hipHostFree(h_pin_in_);
-    d_stage_in_ = nullptr;
-    h_pin_in_ = nullptr;
-    stage_in_cap_ = 0;
-    const size_t cap = std::max<size_t>(in_bytes + in_bytes / 4, 8192);
-    HIP_TRY(hipMalloc(&d_stage_in_, cap));
-    HIP_TRY(hipHostMalloc(&h_pin_in_, cap, hipHostMallocDefault));
-    stage_in_cap_ = cap;
-  }
-  if (out_bytes > stage_out_cap_) {
-    (void)hipFree(d_stage_out_);
-    if (h_pin_out_) (void)hipHostFree(h_pin_out_);
-    d_stage_out_ = nullptr;
-    h_pin_out_ = nullptr;
-    stage_out_cap_ = 0;
-    const size_t cap = std::max<size_t>(out_bytes + out_bytes / 4, 8192);
-    HIP_TRY(hipMalloc(&d_stage_out_, cap));
-    HIP_TRY(hipHostMalloc(&h_pin_out_, cap, hipHostMallocDefault));
-    stage_out_cap_ = cap;
-  }
-  return SPEEXHIP_ERR_SUCCESS;
+  if (own_stream_ == nullptr) HIP_TRY(pool::stream_get(device_, &own_stream_));
+  // grow-only, like the wrapper's heap buffers (src/index.ts:71-87); the host-buffer calls are
+  // synchronous, so nothing in flight uses the buffers that go back to the pool here
+  auto grow = [&](char **dev, char **pin, size_t *cap_now, size_t want) -> int {
+    if (want <= *cap_now) return SPEEXHIP_ERR_SUCCESS;
+    pool::device_put(device_, *dev);
+    pool::pinned_put(*pin);
+    *dev = nullptr;
+    *pin = nullptr;
+    *cap_now = 0;
+    const size_t cap = pool::size_class(std::max<size_t>(want, 8192));
+    HIP_TRY(pool::device_get(device_, reinterpret_cast<void **>(dev), cap));
+    HIP_TRY(pool::pinned_get(reinterpret_cast<void **>(pin), cap));
+    *cap_now = cap;
+    return SPEEXHIP_ERR_SUCCESS;
+  };
+  int rc = grow(&d_stage_in_, &h_pin_in_, &stage_in_cap_, in_bytes);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  return grow(&d_stage_out_, &h_pin_out_, &stage_out_cap_, out_bytes);
 }
 
 int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io) {

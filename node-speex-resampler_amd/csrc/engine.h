@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,29 @@ namespace speexhip {
 const char *last_device_error();  // text of the most recent HIP failure on this thread
 // Test hook: the n-th next device allocation of a filter install fails (resample.c:785-791 path); 0 = off.
 void debug_fail_device_allocs(int n);
+
+// Everything on the device that depends only on (filter, channel count): the reference-layout sinc
+// table, the fast kernels' tap rows and the launch geometry.  Immutable once built, so states with
+// the same (num, den, quality, channels) share one copy (a cache in engine.cpp keeps the most recent
+// ones alive between states): a second `new SpeexResampler(2, 44100, 48000, 7)` designs nothing and
+// uploads nothing.
+struct DeviceTables {
+  int device = 0;
+  float *table = nullptr;        // reference layout (exact kernel)
+  float *period_rows = nullptr;  // kernels_period.hip, R = 10
+  float *fine_rows = nullptr;    // ... R = 5 (launches of one generation)
+  float *slide_rows = nullptr;   // kernels_slide.hip
+  ExactGeometry geo, geo_ch;     // exact kernel, all channels / one channel per launch
+  PeriodPlan period, fine;
+  SlidePlan slide;
+  size_t bytes = 0;
+  DeviceTables() = default;
+  DeviceTables(const DeviceTables &) = delete;
+  DeviceTables &operator=(const DeviceTables &) = delete;
+  ~DeviceTables();
+};
+// Idle cache entries back to the pool (speexhip_release_cached_memory); the bytes they held.
+size_t release_cached_tables();
 
 class Batch {
  public:
@@ -114,6 +138,7 @@ class Batch {
   uint32_t line_ = 0;             // frames per channel line, grow-only (resample.c
                                   // "mem_alloc_size", :709-720): block size = line_-(taps-1)
 
+  std::shared_ptr<const DeviceTables> tables_;  // owns the four table pointers below
   float *d_table_ = nullptr;
   float *d_hist_[2] = {nullptr, nullptr};  // float, like the reference's `mem`
   size_t hist_elems_ = 0;  // per stream: (taps-1 + room for pending frames)*channels

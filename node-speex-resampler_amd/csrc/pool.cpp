@@ -1,0 +1,243 @@
+// pool.cpp -- see pool.h.
+#include "pool.h"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace speexhip {
+namespace pool {
+namespace {
+
+// Size classes: 4 KiB, then powers of two with a half step in between (4, 6, 8, 12, 16 ... KiB): a
+// request is served with at most 1.5x its size.  Requests above kMaxPooled bypass the pool.
+const size_t kMinClass = 4096;
+const size_t kMaxPooled = static_cast<size_t>(256) << 20;
+
+struct Shelf {
+  std::map<size_t, std::vector<void *>> idle;  // size class -> buffers
+  size_t idle_bytes = 0;
+};
+
+struct State {
+  std::mutex mu;
+  std::map<int, Shelf> device;  // per device
+  Shelf pinned;
+  std::unordered_map<void *, size_t> live;  // every buffer handed out or idle -> its size class (0: not pooled)
+  std::map<int, std::vector<hipStream_t>> streams;
+  std::map<int, std::vector<hipEvent_t>> events;
+  size_t device_cap, pinned_cap;
+  State() {
+    size_t mb = 1024;
+    if (const char *e = std::getenv("SPEEXHIP_POOL_MB")) mb = static_cast<size_t>(std::strtoull(e, nullptr, 10));
+    device_cap = mb << 20;
+    pinned_cap = (mb / 4) << 20;
+  }
+};
+
+// never destroyed: HIP may already be gone when static destructors run
+State &st() {
+  static State *s = new State();
+  return *s;
+}
+
+void *take(Shelf &sh, size_t cls) {
+  auto it = sh.idle.find(cls);
+  if (it == sh.idle.end() || it->second.empty()) return nullptr;
+  void *p = it->second.back();
+  it->second.pop_back();
+  sh.idle_bytes -= cls;
+  return p;
+}
+
+}  // namespace
+
+size_t size_class(size_t bytes) {
+  if (bytes <= kMinClass) return kMinClass;
+  size_t c = kMinClass;
+  while (c < bytes) {
+    if (c + c / 2 >= bytes) return c + c / 2;
+    c *= 2;
+  }
+  return c;
+}
+
+hipError_t device_get(int device, void **ptr, size_t bytes) {
+  State &s = st();
+  *ptr = nullptr;
+  const bool pooled = s.device_cap != 0 && bytes <= kMaxPooled;
+  const size_t cls = pooled ? size_class(bytes) : bytes;
+  if (pooled) {
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (void *p = take(s.device[device], cls)) {
+      *ptr = p;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(ptr, cls);
+  if (e == hipErrorOutOfMemory && release_idle() != 0) {  // the pool itself may be what fills the device
+    (void)hipGetLastError();
+    e = hipMalloc(ptr, cls);
+  }
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(s.mu);
+  s.live[*ptr] = pooled ? cls : 0;
+  return hipSuccess;
+}
+
+void device_put(int device, void *ptr) {
+  if (ptr == nullptr) return;
+  State &s = st();
+  {
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto it = s.live.find(ptr);
+    const size_t cls = it == s.live.end() ? 0 : it->second;
+    Shelf &sh = s.device[device];
+    if (cls != 0 && sh.idle_bytes + cls <= s.device_cap) {
+      sh.idle[cls].push_back(ptr);
+      sh.idle_bytes += cls;
+      return;
+    }
+    if (it != s.live.end()) s.live.erase(it);
+  }
+  (void)hipFree(ptr);
+}
+
+hipError_t pinned_get(void **ptr, size_t bytes) {
+  State &s = st();
+  *ptr = nullptr;
+  const bool pooled = s.pinned_cap != 0 && bytes <= kMaxPooled;
+  const size_t cls = pooled ? size_class(bytes) : bytes;
+  if (pooled) {
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (void *p = take(s.pinned, cls)) {
+      *ptr = p;
+      return hipSuccess;
+    }
+  }
+  const hipError_t e = hipHostMalloc(ptr, cls, hipHostMallocDefault);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(s.mu);
+  s.live[*ptr] = pooled ? cls : 0;
+  return hipSuccess;
+}
+
+void pinned_put(void *ptr) {
+  if (ptr == nullptr) return;
+  State &s = st();
+  {
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto it = s.live.find(ptr);
+    const size_t cls = it == s.live.end() ? 0 : it->second;
+    if (cls != 0 && s.pinned.idle_bytes + cls <= s.pinned_cap) {
+      s.pinned.idle[cls].push_back(ptr);
+      s.pinned.idle_bytes += cls;
+      return;
+    }
+    if (it != s.live.end()) s.live.erase(it);
+  }
+  (void)hipHostFree(ptr);
+}
+
+hipError_t stream_get(int device, hipStream_t *out) {
+  State &s = st();
+  {
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto &v = s.streams[device];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void stream_put(int device, hipStream_t h) {
+  if (h == nullptr) return;
+  State &s = st();
+  {
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto &v = s.streams[device];
+    if (s.device_cap != 0 && v.size() < 64) {
+      v.push_back(h);
+      return;
+    }
+  }
+  (void)hipStreamDestroy(h);
+}
+
+hipError_t event_get(int device, hipEvent_t *out) {
+  State &s = st();
+  {
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto &v = s.events[device];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+
+void event_put(int device, hipEvent_t h) {
+  if (h == nullptr) return;
+  State &s = st();
+  {
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto &v = s.events[device];
+    if (s.device_cap != 0 && v.size() < 2048) {
+      v.push_back(h);
+      return;
+    }
+  }
+  (void)hipEventDestroy(h);
+}
+
+size_t release_idle() {
+  State &s = st();
+  std::vector<void *> dev, pin;
+  std::vector<hipStream_t> streams;
+  std::vector<hipEvent_t> events;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lock(s.mu);
+    for (auto &d : s.device) {
+      for (auto &c : d.second.idle)
+        for (void *p : c.second) {
+          dev.push_back(p);
+          s.live.erase(p);
+        }
+      bytes += d.second.idle_bytes;
+      d.second.idle.clear();
+      d.second.idle_bytes = 0;
+    }
+    for (auto &c : s.pinned.idle)
+      for (void *p : c.second) {
+        pin.push_back(p);
+        s.live.erase(p);
+      }
+    bytes += s.pinned.idle_bytes;
+    s.pinned.idle.clear();
+    s.pinned.idle_bytes = 0;
+    for (auto &v : s.streams) {
+      streams.insert(streams.end(), v.second.begin(), v.second.end());
+      v.second.clear();
+    }
+    for (auto &v : s.events) {
+      events.insert(events.end(), v.second.begin(), v.second.end());
+      v.second.clear();
+    }
+  }
+  for (void *p : dev) (void)hipFree(p);
+  for (void *p : pin) (void)hipHostFree(p);
+  for (hipStream_t h : streams) (void)hipStreamDestroy(h);
+  for (hipEvent_t h : events) (void)hipEventDestroy(h);
+  return bytes;
+}
+
+}  // namespace pool
+}  // namespace speexhip

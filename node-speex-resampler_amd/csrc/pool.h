@@ -1,0 +1,44 @@
+// pool.h -- process-wide recycling of what a state holds on the device (product code).
+//
+// The reference's state is a few hundred bytes of heap: callers create one per file or per
+// connection and drop it (src/test.ts:27, one `new SpeexResampler` per file).  Here a state owns
+// device buffers, pinned staging buffers, a stream and events, and the HIP calls that make and
+// release those -- hipHostMalloc / hipHostFree above all -- cost more than resampling a whole
+// 10-second file: a fresh state's first 1.7 MB call took 0.5-1.0 ms and its destruction 1.0-1.5 ms
+// against 0.2 ms for the call itself (tools/init_cost.py).  So nothing goes back to the driver when
+// a state dies: buffers, streams and events return here, rounded to size classes, and the next state
+// takes them.  Idle memory is bounded (SPEEXHIP_POOL_MB, default 1024 device + 256 pinned; 0 turns
+// the pool off) and speexhip_release_cached_memory() hands everything idle back.
+//
+// A buffer may only be put back once nothing in flight touches it: callers synchronise first
+// (~Batch and the filter changes do).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace speexhip {
+namespace pool {
+
+// Device memory on `device` (the calling thread's current device must be `device`).
+hipError_t device_get(int device, void **ptr, size_t bytes);
+void device_put(int device, void *ptr);  // nullptr is fine
+
+// Pinned host memory (hipHostMallocDefault).
+hipError_t pinned_get(void **ptr, size_t bytes);
+void pinned_put(void *ptr);
+
+// A non-blocking stream / a timing-disabled event of `device`.
+hipError_t stream_get(int device, hipStream_t *s);
+void stream_put(int device, hipStream_t s);
+hipError_t event_get(int device, hipEvent_t *e);
+void event_put(int device, hipEvent_t e);
+
+// Returns everything idle to the driver; the number of bytes released.
+size_t release_idle();
+
+// Rounded size a request of `bytes` is served with (tests).
+size_t size_class(size_t bytes);
+
+}  // namespace pool
+}  // namespace speexhip

@@ -44,6 +44,7 @@ EXPORTS = [
     "speexhip_resampler_set_input_stride", "speexhip_resampler_get_input_stride",
     "speexhip_resampler_set_output_stride", "speexhip_resampler_get_output_stride",
     "speexhip_resampler_get_channel_position", "speexhip_debug_fail_device_allocs",
+    "speexhip_release_cached_memory",
 ]
 
 
@@ -160,6 +161,8 @@ def lib():
         L.speexhip_resampler_get_channel_position.argtypes = [p, u32, pi32, pu32, pu32]
         L.speexhip_debug_fail_device_allocs.restype = None
         L.speexhip_debug_fail_device_allocs.argtypes = [i32]
+        L.speexhip_release_cached_memory.restype = C.c_uint64
+        L.speexhip_release_cached_memory.argtypes = []
         _lib = L
     return _lib
 

@@ -1024,3 +1024,30 @@ def test_bench_n_rank_path_end_to_end_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_states_recycle_device_resources_through_the_pool():
+    """Destroying a state hands its device / pinned buffers, stream and events to the process-wide
+    pool (csrc/pool.h) and the next state takes them: results must not depend on what a recycled
+    buffer held before, and speexhip_release_cached_memory() must give the idle memory back."""
+    L = speexhip.lib()
+    rng = np.random.RandomState(5)
+    cfgs = [(2, 44100, 48000, 7), (1, 24000, 48000, 10), (8, 48000, 44100, 5), (2, 48000, 8000, 4), (3, 44100, 48000, 3)]
+    for rep in range(3):
+        for ch, i, o, q in cfgs:
+            frames = int(rng.randint(1000, 200000))
+            x = rng.randint(-32768, 32768, size=(frames, ch)).astype(np.int16)
+            want, wu = orc.Oracle(ch, i, o, q).process(x, frames * 7)
+            r = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT)
+            got, used = r.process(x, frames * 7)
+            assert used == wu and np.array_equal(got, want), (rep, ch, i, o, q)
+            r.close()
+    assert L.speexhip_release_cached_memory() > 0          # the closed states' buffers were idle in the pool
+    assert L.speexhip_release_cached_memory() == 0         # ... and are gone now
+    r = speexhip.Resampler(2, 44100, 48000, 7)             # a state after the release allocates afresh
+    x = orc.tone_pcm(50000, 2, seed=3)
+    got, used = r.process(x, 1 << 20)
+    want, wu = orc.Oracle(2, 44100, 48000, 7).process(x, 1 << 20)
+    assert used == wu
+    assert_close(got, want, "after release")
+    r.close()
