@@ -779,8 +779,8 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   // Large buffers go straight from / to the caller's pageable memory: the HIP runtime stages such
   // copies itself and does it 2.2-2.5x faster than memcpy -> pinned -> DMA in one thread (2^20
-  // stereo frames: 0.46 -> 0.21 ms per call, 8 channels 1.57 -> 0.63 ms).  Small ones keep the
-  // pinned bounce buffers (a few % faster below ~256 KB).
+  // stereo frames: 0.46 -> 0.21 ms per call, 8 channels 1.57 -> 0.63 ms).  Small ones go through
+  // the pinned bounce buffers (below).
   // What was tried in round 2 to get below this (2^20 stereo frames, 207 us per call; tools/ubench_copy.hip):
   // PCIe is full duplex -- both copies at once from pinned memory take 103 us instead of 175 -- but
   //   * H2D / kernel / D2H of 2-8 pieces on three streams chained by events: +30 us per piece (a
@@ -793,6 +793,24 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   //     shippable; removed.
   // So the call stays three in-order steps on one stream.
   const bool direct_in = in_bytes >= kDirectCopyBytes, direct_out = out_bytes >= kDirectCopyBytes && !split;
+  // Small calls -- a Transform's 64 KiB chunks, a realtime caller's 10-20 ms frames -- are all latency:
+  // the kernels read the pinned bounce buffer and write the pinned result buffer straight through PCIe
+  // (pool-owned hipHostMalloc memory, coherent; one launch and one wait instead of copy / launch / copy
+  // / wait): 480-960 stereo frames 26.5 -> 22.7 us per call, 16384 frames 41.7 -> 30.1, 65536 frames
+  // 70.4 -> 53.7 (tools/small_call_latency.py).  SPEEXHIP_ZERO_COPY_BELOW=0 turns it off (A/B).
+  static const size_t zero_copy_below = [] {
+    const char *e = std::getenv("SPEEXHIP_ZERO_COPY_BELOW");
+    return e != nullptr ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kDirectCopyBytes;
+  }();
+  if (!split && in_bytes < zero_copy_below && out_bytes < zero_copy_below) {
+    if (in != nullptr && in_bytes != 0) std::memcpy(h_pin_in_, in, in_bytes);
+    rc = process_device(in != nullptr ? h_pin_in_ : nullptr, 0, in_len, h_pin_out_, 0, out_len, float_io, own_stream_);
+    if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
+    HIP_TRY(hipStreamSynchronize(own_stream_));
+    const size_t made = static_cast<size_t>(*out_len) * channels_ * es;
+    if (made != 0) std::memcpy(out, h_pin_out_, made);
+    return rc;
+  }
   if (in != nullptr && in_bytes != 0) {
     if (direct_in) {
       HIP_TRY(hipMemcpyAsync(d_stage_in_, in, in_bytes, hipMemcpyHostToDevice, own_stream_));
