@@ -26,7 +26,8 @@ Prints ONE JSON line on rank 0 (contract in the task description): value = whole
 Msamples/s, plus "roofline" (algorithmic HBM bytes per launch / launch time measured with HIP
 events on the launch stream, vs the 8 TB/s HBM peak), "parity" (first chunk of up to four
 streams checked against the CPU oracle) and, at N=1, "cpu_baseline" (the reference's own C
-timed on the host cores).
+timed on the host cores) and "end_to_end" (the host-buffer call a Node caller makes, PCIe
+included -- reported beside `value`, never as it).
 """
 import argparse
 import json
@@ -120,6 +121,47 @@ def parity_block(cfg, frames, first_chunks, float_io):
         blk["tolerance_lsb"] = 1
         ok = counters and worst <= 1
     return blk, ok
+
+
+def end_to_end(speexhip, cfg, frames, mode, float_io, base_stream, calls=30):
+    """The call a host-buffer caller makes (speexhip_resampler_process_interleaved_*: what index.js's
+    processChunk runs): pageable buffers in and out, synchronous, PCIe both ways inside the timed call.
+    Reported beside the kernel-resident `value`, never as it."""
+    import numpy as np
+    ch, fi, fo, q = cfg
+    x = base_stream if not float_io else (base_stream.astype(np.float32) / np.float32(32768.0))
+    import ctypes as C
+    x = np.ascontiguousarray(x)
+    r = speexhip.Resampler(ch, fi, fo, q, mode=mode)
+    cap = wrapper_capacity(frames * ch * 2, fi, fo, ch)
+    # the C call itself on preallocated buffers: no numpy allocation or page faults in the timed calls
+    y = np.zeros((cap, ch), np.float32 if float_io else np.int16)
+    ctype = C.c_float if float_io else C.c_int16
+    fn = (speexhip.lib().speexhip_resampler_process_interleaved_float if float_io
+          else speexhip.lib().speexhip_resampler_process_interleaved_int)
+    px, py = x.ctypes.data_as(C.POINTER(ctype)), y.ctypes.data_as(C.POINTER(ctype))
+    used = 0
+
+    def call():
+        il, ol = C.c_uint32(frames), C.c_uint32(cap)
+        rc = fn(r._h, px, C.byref(il), py, C.byref(ol))
+        assert rc == 0, rc
+        return il.value
+
+    for _ in range(3):
+        call()
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        used = call()
+        ts.append(time.perf_counter() - t0)
+    r.close()
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"ms_per_chunk": round(med * 1e3, 4), "ms_min": round(ts[0] * 1e3, 4),
+            "input_msamples_per_s": round(used * ch / med / 1e6, 1), "calls": calls,
+            "what": "one stream, host (pageable) buffers in and out through the C ABI's synchronous call, "
+                    "%d-frame chunk: H2D + kernel + D2H + wait (PCIe-inclusive; not `value`)" % frames}
 
 
 def cpu_baseline(cfg, frames, budget_s=12.0, max_chunks=32):
@@ -396,6 +438,7 @@ def main():
             if not ok:
                 rc = 3
         if world == 1 and not args.no_cpu_baseline:
+            line["end_to_end"] = end_to_end(speexhip, cfg, F, mode, fio, base[0])
             line["cpu_baseline"] = cpu_baseline(cfg, F)
         print(json.dumps(line), flush=True)
         if rc:

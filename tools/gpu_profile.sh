@@ -77,6 +77,9 @@ python bench.py --io float --steps 300 --no-cpu-baseline >> $O/r${N}_bench_lines
 python bench.py --io float --streams 32 --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_form.json 2>/dev/null
 python tools/host_path_bench.py > $O/r${N}_host_path.json 2>/dev/null
+python tools/small_call_latency.py > $O/r${N}_small_call_latency.txt 2>/dev/null
+python tools/init_cost.py > $O/r${N}_init_cost.txt 2>/dev/null
+(cd node-speex-resampler_amd && node test/bench.js $O/r${N}_node_bench.json > /dev/null 2>&1)
 python3 - "$N" <<'PY'
 import json, os, sys
 N = sys.argv[1]
