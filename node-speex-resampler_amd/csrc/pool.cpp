@@ -1,6 +1,8 @@
 // pool.cpp -- see pool.h.
 #include "pool.h"
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -26,7 +28,8 @@ struct State {
   std::map<int, Shelf> device;  // per device
   Shelf pinned;
   std::unordered_map<void *, size_t> live;  // every buffer handed out or idle -> its size class (0: not pooled)
-  std::map<int, std::vector<hipStream_t>> streams;
+  std::map<int, std::vector<hipStream_t>> streams;  // shared, see stream_get
+  std::map<int, size_t> next_stream;
   std::map<int, std::vector<hipEvent_t>> events;
   size_t device_cap, pinned_cap;
   State() {
@@ -42,6 +45,23 @@ State &st() {
   static State *s = new State();
   return *s;
 }
+
+// SPEEXHIP_POOL_TRACE=1: every request the pool could not serve, with the time the driver took (stderr)
+struct MissTimer {
+  const char *what;
+  size_t bytes;
+  std::chrono::steady_clock::time_point t0;
+  static bool on() {
+    static const bool v = std::getenv("SPEEXHIP_POOL_TRACE") != nullptr;
+    return v;
+  }
+  MissTimer(const char *w, size_t b) : what(w), bytes(b), t0(std::chrono::steady_clock::now()) {}
+  ~MissTimer() {
+    if (!on()) return;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(stderr, "speexhip pool miss: %s %zu bytes, %.1f us\n", what, bytes, us);
+  }
+};
 
 void *take(Shelf &sh, size_t cls) {
   auto it = sh.idle.find(cls);
@@ -76,6 +96,7 @@ hipError_t device_get(int device, void **ptr, size_t bytes) {
       return hipSuccess;
     }
   }
+  MissTimer timer("hipMalloc", cls);
   hipError_t e = hipMalloc(ptr, cls);
   if (e == hipErrorOutOfMemory && release_idle() != 0) {  // the pool itself may be what fills the device
     (void)hipGetLastError();
@@ -117,6 +138,7 @@ hipError_t pinned_get(void **ptr, size_t bytes) {
       return hipSuccess;
     }
   }
+  MissTimer timer("hipHostMalloc", cls);
   const hipError_t e = hipHostMalloc(ptr, cls, hipHostMallocDefault);
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> lock(s.mu);
@@ -141,33 +163,37 @@ void pinned_put(void *ptr) {
   (void)hipHostFree(ptr);
 }
 
+// Streams are SHARED, not lent: creating one costs 2.6-8 ms in a process that has made few (a hardware
+// queue each; measured from Node, SPEEXHIP_POOL_TRACE=1) -- more than a hundred 64 KiB calls.  A state's
+// host-buffer calls are synchronous (each ends with a wait on its stream), so states can take turns on a
+// handful of streams: state i of a device runs on stream i % kSharedStreams, made on first use and kept
+// for the life of the process.  Four, so that calls of different states on different threads
+// (processChunkAsync on the libuv pool) still overlap.
+const size_t kSharedStreams = 4;
+
 hipError_t stream_get(int device, hipStream_t *out) {
   State &s = st();
-  {
-    std::lock_guard<std::mutex> lock(s.mu);
-    auto &v = s.streams[device];
-    if (!v.empty()) {
-      *out = v.back();
-      v.pop_back();
-      return hipSuccess;
+  std::lock_guard<std::mutex> lock(s.mu);  // (held across the creation: at most kSharedStreams times per device)
+  auto &v = s.streams[device];
+  size_t &next = s.next_stream[device];
+  const size_t slot = next++ % kSharedStreams;
+  if (slot >= v.size()) {
+    MissTimer timer("hipStreamCreate", 0);
+    hipStream_t h = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&h, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      next--;
+      return e;
     }
+    v.push_back(h);
+    *out = h;
+    return hipSuccess;
   }
-  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  *out = v[slot];
+  return hipSuccess;
 }
 
-void stream_put(int device, hipStream_t h) {
-  if (h == nullptr) return;
-  State &s = st();
-  {
-    std::lock_guard<std::mutex> lock(s.mu);
-    auto &v = s.streams[device];
-    if (s.device_cap != 0 && v.size() < 64) {
-      v.push_back(h);
-      return;
-    }
-  }
-  (void)hipStreamDestroy(h);
-}
+void stream_put(int, hipStream_t) {}  // shared: nothing to give back
 
 hipError_t event_get(int device, hipEvent_t *out) {
   State &s = st();
@@ -180,6 +206,7 @@ hipError_t event_get(int device, hipEvent_t *out) {
       return hipSuccess;
     }
   }
+  MissTimer timer("hipEventCreate", 0);
   return hipEventCreateWithFlags(out, hipEventDisableTiming);
 }
 
@@ -200,7 +227,6 @@ void event_put(int device, hipEvent_t h) {
 size_t release_idle() {
   State &s = st();
   std::vector<void *> dev, pin;
-  std::vector<hipStream_t> streams;
   std::vector<hipEvent_t> events;
   size_t bytes = 0;
   {
@@ -223,10 +249,6 @@ size_t release_idle() {
     bytes += s.pinned.idle_bytes;
     s.pinned.idle.clear();
     s.pinned.idle_bytes = 0;
-    for (auto &v : s.streams) {
-      streams.insert(streams.end(), v.second.begin(), v.second.end());
-      v.second.clear();
-    }
     for (auto &v : s.events) {
       events.insert(events.end(), v.second.begin(), v.second.end());
       v.second.clear();
@@ -234,7 +256,6 @@ size_t release_idle() {
   }
   for (void *p : dev) (void)hipFree(p);
   for (void *p : pin) (void)hipHostFree(p);
-  for (hipStream_t h : streams) (void)hipStreamDestroy(h);
   for (hipEvent_t h : events) (void)hipEventDestroy(h);
   return bytes;
 }

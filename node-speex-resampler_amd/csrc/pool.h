@@ -3,8 +3,8 @@
 // The reference's state is a few hundred bytes of heap: callers create one per file or per
 // connection and drop it (src/test.ts:27, one `new SpeexResampler` per file).  Here a state owns
 // device buffers, pinned staging buffers, a stream and events, and the HIP calls that make and
-// release those -- hipHostMalloc / hipHostFree above all -- cost more than resampling a whole
-// 10-second file: a fresh state's first 1.7 MB call took 0.5-1.0 ms and its destruction 1.0-1.5 ms
+// release those -- hipStreamCreate, hipHostMalloc / hipHostFree above all -- cost more than resampling
+// a whole 10-second file: a fresh state's first 1.7 MB call took 0.5-1.0 ms and its destruction 1.0-1.5 ms
 // against 0.2 ms for the call itself (tools/init_cost.py).  So nothing goes back to the driver when
 // a state dies: buffers, streams and events return here, rounded to size classes, and the next state
 // takes them.  Idle memory is bounded (SPEEXHIP_POOL_MB, default 1024 device + 256 pinned; 0 turns
@@ -28,9 +28,12 @@ void device_put(int device, void *ptr);  // nullptr is fine
 hipError_t pinned_get(void **ptr, size_t bytes);
 void pinned_put(void *ptr);
 
-// A non-blocking stream / a timing-disabled event of `device`.
+// A non-blocking stream of `device` for a state's synchronous host-buffer calls.  Shared with other
+// states (one of four per device, kept for the life of the process: see pool.cpp), so anything queued
+// on it must be waited for by the call that queued it.
 hipError_t stream_get(int device, hipStream_t *s);
 void stream_put(int device, hipStream_t s);
+// A timing-disabled event of `device` (lent, returned with event_put).
 hipError_t event_get(int device, hipEvent_t *e);
 void event_put(int device, hipEvent_t e);
 
