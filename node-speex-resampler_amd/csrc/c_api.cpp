@@ -1,12 +1,34 @@
 // c_api.cpp -- the extern "C" boundary declared in include/speexhip_resampler.h.
 #include <cstring>
+#include <exception>
 #include <new>
+#include <string>
 
 #include "../../include/speexhip_resampler.h"
 #include "engine.h"
 #include "pool.h"
 
 using speexhip::Batch;
+
+namespace {
+// No C++ exception may cross the C boundary: a host allocation that fails inside a call (descriptor
+// vectors, the history image of a filter change, a multi-gigabyte sinc table) becomes the
+// reference's RESAMPLER_ERR_ALLOC_FAILED, anything else the device error code with its text.
+template <typename F>
+int guarded(F &&f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    return SPEEXHIP_ERR_ALLOC_FAILED;
+  } catch (const std::exception &e) {
+    speexhip::set_last_device_error(std::string("internal error: ") + e.what());
+    return SPEEXHIP_ERR_DEVICE;
+  } catch (...) {
+    speexhip::set_last_device_error("internal error: unknown exception");
+    return SPEEXHIP_ERR_DEVICE;
+  }
+}
+}  // namespace
 
 struct SpeexHipResamplerState_ {
   Batch *batch;
@@ -19,7 +41,13 @@ extern "C" {
 
 SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channels, uint32_t in_rate,
                                                 uint32_t out_rate, int quality, int *err) {
-  Batch *b = Batch::create(1, nb_channels, in_rate, out_rate, quality, err);
+  Batch *b = nullptr;
+  int code = SPEEXHIP_ERR_SUCCESS;
+  const int rc = guarded([&] {
+    b = Batch::create(1, nb_channels, in_rate, out_rate, quality, &code);
+    return code;
+  });
+  if (err) *err = rc;
   if (b == nullptr) return nullptr;
   SpeexHipResamplerState *st = new (std::nothrow) SpeexHipResamplerState_{b};
   if (st == nullptr) {
@@ -32,7 +60,13 @@ SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channels, uint32_t i
 SpeexHipResamplerState *speexhip_resampler_init_frac(uint32_t nb_channels, uint32_t ratio_num,
                                                      uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate,
                                                      int quality, int *err) {
-  Batch *b = Batch::create_frac(1, nb_channels, ratio_num, ratio_den, in_rate, out_rate, quality, err);
+  Batch *b = nullptr;
+  int code = SPEEXHIP_ERR_SUCCESS;
+  const int rc = guarded([&] {
+    b = Batch::create_frac(1, nb_channels, ratio_num, ratio_den, in_rate, out_rate, quality, &code);
+    return code;
+  });
+  if (err) *err = rc;
   if (b == nullptr) return nullptr;
   SpeexHipResamplerState *st = new (std::nothrow) SpeexHipResamplerState_{b};
   if (st == nullptr) {
@@ -43,18 +77,18 @@ SpeexHipResamplerState *speexhip_resampler_init_frac(uint32_t nb_channels, uint3
 }
 
 int speexhip_resampler_set_rate(SpeexHipResamplerState *st, uint32_t in_rate, uint32_t out_rate) {
-  return st ? st->batch->set_rate_frac(in_rate, out_rate, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return st ? st->batch->set_rate_frac(in_rate, out_rate, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG; });
 }
 int speexhip_resampler_set_rate_frac(SpeexHipResamplerState *st, uint32_t ratio_num, uint32_t ratio_den,
                                      uint32_t in_rate, uint32_t out_rate) {
-  return st ? st->batch->set_rate_frac(ratio_num, ratio_den, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return st ? st->batch->set_rate_frac(ratio_num, ratio_den, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG; });
 }
 void speexhip_resampler_get_ratio(SpeexHipResamplerState *st, uint32_t *ratio_num, uint32_t *ratio_den) {
   *ratio_num = st->batch->filter().num;
   *ratio_den = st->batch->filter().den;
 }
 int speexhip_resampler_set_quality(SpeexHipResamplerState *st, int quality) {
-  return st ? st->batch->set_quality(quality) : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return st ? st->batch->set_quality(quality) : SPEEXHIP_ERR_INVALID_ARG; });
 }
 void speexhip_resampler_get_quality(SpeexHipResamplerState *st, int *quality) {
   *quality = st->batch->filter().quality;
@@ -62,24 +96,24 @@ void speexhip_resampler_get_quality(SpeexHipResamplerState *st, int *quality) {
 int speexhip_resampler_get_input_latency(SpeexHipResamplerState *st) { return st->batch->input_latency(); }
 int speexhip_resampler_get_output_latency(SpeexHipResamplerState *st) { return st->batch->output_latency(); }
 int speexhip_resampler_skip_zeros(SpeexHipResamplerState *st) {
-  return st ? st->batch->skip_zeros() : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return st ? st->batch->skip_zeros() : SPEEXHIP_ERR_INVALID_ARG; });
 }
 int speexhip_resampler_reset_mem(SpeexHipResamplerState *st) {
-  return st ? st->batch->reset_mem() : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return st ? st->batch->reset_mem() : SPEEXHIP_ERR_INVALID_ARG; });
 }
 
 int speexhip_batch_set_rate_frac(SpeexHipBatch *b, uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate,
                                  uint32_t out_rate) {
-  return b ? b->batch->set_rate_frac(ratio_num, ratio_den, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return b ? b->batch->set_rate_frac(ratio_num, ratio_den, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG; });
 }
 int speexhip_batch_set_quality(SpeexHipBatch *b, int quality) {
-  return b ? b->batch->set_quality(quality) : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return b ? b->batch->set_quality(quality) : SPEEXHIP_ERR_INVALID_ARG; });
 }
-int speexhip_batch_skip_zeros(SpeexHipBatch *b) { return b ? b->batch->skip_zeros() : SPEEXHIP_ERR_INVALID_ARG; }
-int speexhip_batch_reset_mem(SpeexHipBatch *b) { return b ? b->batch->reset_mem() : SPEEXHIP_ERR_INVALID_ARG; }
+int speexhip_batch_skip_zeros(SpeexHipBatch *b) { return guarded([&] { return b ? b->batch->skip_zeros() : SPEEXHIP_ERR_INVALID_ARG; }); }
+int speexhip_batch_reset_mem(SpeexHipBatch *b) { return guarded([&] { return b ? b->batch->reset_mem() : SPEEXHIP_ERR_INVALID_ARG; }); }
 int speexhip_batch_get_history(SpeexHipBatch *b, uint32_t stream, float *dst) {
   if (b == nullptr || dst == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return b->batch->history(stream, dst);
+  return guarded([&] { return b->batch->history(stream, dst); });
 }
 
 void speexhip_resampler_destroy(SpeexHipResamplerState *st) {
@@ -92,30 +126,30 @@ int speexhip_resampler_process_interleaved_int(SpeexHipResamplerState *st, const
                                                uint32_t *in_len, int16_t *out, uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
     return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_host(in, in_len, out, out_len, false);
+  return guarded([&] { return st->batch->process_host(in, in_len, out, out_len, false); });
 }
 
 int speexhip_resampler_process_interleaved_int_device(SpeexHipResamplerState *st, const int16_t *d_in,
                                                       uint32_t *in_len, int16_t *d_out,
                                                       uint32_t *out_len, void *hip_stream) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_device(d_in, 0, in_len, d_out, 0, out_len, false,
-                                   static_cast<hipStream_t>(hip_stream));
+  return guarded([&] { return st->batch->process_device(d_in, 0, in_len, d_out, 0, out_len, false,
+                                   static_cast<hipStream_t>(hip_stream)); });
 }
 
 int speexhip_resampler_process_interleaved_float(SpeexHipResamplerState *st, const float *in,
                                                  uint32_t *in_len, float *out, uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
     return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_host(in, in_len, out, out_len, true);
+  return guarded([&] { return st->batch->process_host(in, in_len, out, out_len, true); });
 }
 
 int speexhip_resampler_process_interleaved_float_device(SpeexHipResamplerState *st, const float *d_in,
                                                         uint32_t *in_len, float *d_out, uint32_t *out_len,
                                                         void *hip_stream) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_device(d_in, 0, in_len, d_out, 0, out_len, true,
-                                   static_cast<hipStream_t>(hip_stream));
+  return guarded([&] { return st->batch->process_device(d_in, 0, in_len, d_out, 0, out_len, true,
+                                   static_cast<hipStream_t>(hip_stream)); });
 }
 
 int speexhip_batch_process_interleaved_float_device(SpeexHipBatch *b, const float *d_in,
@@ -123,38 +157,38 @@ int speexhip_batch_process_interleaved_float_device(SpeexHipBatch *b, const floa
                                                     uint64_t out_stream_stride, uint32_t *out_len,
                                                     void *hip_stream) {
   if (b == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return b->batch->process_device(d_in, in_stream_stride, in_len, d_out, out_stream_stride, out_len, true,
-                                  static_cast<hipStream_t>(hip_stream));
+  return guarded([&] { return b->batch->process_device(d_in, in_stream_stride, in_len, d_out, out_stream_stride, out_len, true,
+                                  static_cast<hipStream_t>(hip_stream)); });
 }
 
 int speexhip_resampler_process_chunks_int(SpeexHipResamplerState *st, uint32_t n_chunks,
                                           const int16_t *const *in, uint32_t *in_len, int16_t *out,
                                           uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_host_chunks(n_chunks, reinterpret_cast<const void *const *>(in), in_len, out,
-                                        out_len, false);
+  return guarded([&] { return st->batch->process_host_chunks(n_chunks, reinterpret_cast<const void *const *>(in), in_len, out,
+                                        out_len, false); });
 }
 
 int speexhip_resampler_process_chunks_float(SpeexHipResamplerState *st, uint32_t n_chunks,
                                             const float *const *in, uint32_t *in_len, float *out,
                                             uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_host_chunks(n_chunks, reinterpret_cast<const void *const *>(in), in_len, out,
-                                        out_len, true);
+  return guarded([&] { return st->batch->process_host_chunks(n_chunks, reinterpret_cast<const void *const *>(in), in_len, out,
+                                        out_len, true); });
 }
 
 int speexhip_resampler_process_int(SpeexHipResamplerState *st, uint32_t channel_index, const int16_t *in,
                                    uint32_t *in_len, int16_t *out, uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
     return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_channel_host(channel_index, in, in_len, out, out_len, false);
+  return guarded([&] { return st->batch->process_channel_host(channel_index, in, in_len, out, out_len, false); });
 }
 
 int speexhip_resampler_process_float(SpeexHipResamplerState *st, uint32_t channel_index, const float *in,
                                      uint32_t *in_len, float *out, uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
     return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->process_channel_host(channel_index, in, in_len, out, out_len, true);
+  return guarded([&] { return st->batch->process_channel_host(channel_index, in, in_len, out, out_len, true); });
 }
 
 void speexhip_resampler_set_input_stride(SpeexHipResamplerState *st, uint32_t stride) {
@@ -214,7 +248,7 @@ int speexhip_resampler_peek(SpeexHipResamplerState *st, uint32_t in_len, uint32_
 }
 
 int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode) {
-  return st ? st->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return st ? st->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG; });
 }
 
 int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info) {
@@ -225,12 +259,18 @@ int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info) 
 
 int speexhip_resampler_get_history(SpeexHipResamplerState *st, float *dst) {
   if (st == nullptr || dst == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return st->batch->history(0, dst);
+  return guarded([&] { return st->batch->history(0, dst); });
 }
 
 SpeexHipBatch *speexhip_batch_init(uint32_t n_streams, uint32_t nb_channels, uint32_t in_rate,
                                    uint32_t out_rate, int quality, int *err) {
-  Batch *b = Batch::create(n_streams, nb_channels, in_rate, out_rate, quality, err);
+  Batch *b = nullptr;
+  int code = SPEEXHIP_ERR_SUCCESS;
+  const int rc = guarded([&] {
+    b = Batch::create(n_streams, nb_channels, in_rate, out_rate, quality, &code);
+    return code;
+  });
+  if (err) *err = rc;
   if (b == nullptr) return nullptr;
   SpeexHipBatch *h = new (std::nothrow) SpeexHipBatch_{b};
   if (h == nullptr) {
@@ -247,7 +287,7 @@ void speexhip_batch_destroy(SpeexHipBatch *b) {
 }
 
 int speexhip_batch_set_mode(SpeexHipBatch *b, int mode) {
-  return b ? b->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return b ? b->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG; });
 }
 
 int speexhip_batch_get_info(SpeexHipBatch *b, uint32_t stream, SpeexHipInfo *info) {
@@ -261,8 +301,8 @@ int speexhip_batch_process_interleaved_int_device(SpeexHipBatch *b, const int16_
                                                   int16_t *d_out, uint64_t out_stream_stride,
                                                   uint32_t *out_len, void *hip_stream) {
   if (b == nullptr || in_len == nullptr || out_len == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
-  return b->batch->process_device(d_in, in_stream_stride, in_len, d_out, out_stream_stride, out_len, false,
-                                  static_cast<hipStream_t>(hip_stream));
+  return guarded([&] { return b->batch->process_device(d_in, in_stream_stride, in_len, d_out, out_stream_stride, out_len, false,
+                                  static_cast<hipStream_t>(hip_stream)); });
 }
 
 int speexhip_design_filter(uint32_t in_rate, uint32_t out_rate, int quality, SpeexHipInfo *info,
@@ -274,8 +314,9 @@ int speexhip_design_filter(uint32_t in_rate, uint32_t out_rate, int quality, Spe
 int speexhip_design_filter_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate,
                                 int quality, SpeexHipInfo *info, float *table, uint32_t table_capacity) {
   speexhip::FilterSpec f;
-  const int rc = speexhip::design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality, &f,
-                                              table != nullptr);
+  const int rc = guarded([&] {
+    return speexhip::design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality, &f, table != nullptr);
+  });
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   if (info != nullptr) {
     std::memset(info, 0, sizeof(*info));

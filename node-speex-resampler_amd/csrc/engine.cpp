@@ -73,6 +73,7 @@ const size_t kDirectCopyBytes = 256 * 1024;  // host buffers at least this big s
 }  // namespace
 
 const char *last_device_error() { return g_last_error.c_str(); }
+void set_last_device_error(const std::string &text) { g_last_error = text; }
 void debug_fail_device_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
 
 bool Batch::uniform(uint32_t s) const {

@@ -17,6 +17,7 @@
 namespace speexhip {
 
 const char *last_device_error();  // text of the most recent HIP failure on this thread
+void set_last_device_error(const std::string &text);
 // Test hook: the n-th next device allocation of a filter install fails (resample.c:785-791 path); 0 = off.
 void debug_fail_device_allocs(int n);
 
