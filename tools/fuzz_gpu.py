@@ -6,7 +6,9 @@ Random (channels, in_rate, out_rate, quality) -- common audio rates, rates that 
 ratios (the slide kernel's shapes), near-unity and coprime oddballs (long periods, the exact kernel) --
 driven through a random call sequence: chunk sizes from 0 to a few hundred thousand frames, output
 capacities that are sometimes too small (unconsumed input, reference resample.c:1061-1082), int16 and
-float calls mixed on one state, occasional set_rate / set_quality / skip_zeros / reset_mem in between.
+float calls mixed on one state, per-channel calls with strides (after which the interleaved calls run
+channel by channel), runs of coalesced chunks, occasional set_rate / set_quality / skip_zeros / reset_mem
+in between.
 EXACT mode must be bit-identical (samples, counters, positions); FAST mode within +-1 LSB (int16) /
 the float bound of tests/test_gpu_parity.py, counters and positions identical.  A trial ends at a
 set_rate that returns RESAMPLER_ERR_OVERFLOW in both (the one documented deviation: DESIGN 3.5).
@@ -117,6 +119,60 @@ def one_trial(seed, max_frames):
         in_r, out_r = ref.rate()
         full = int(frames * out_r / max(in_r, 1)) + 64
         cap = full if rng.rand() < 0.7 else int(rng.randint(0, full + 1))
+        kind = "float" if as_float else "int"
+        uniform = len(set(ref.positions())) == 1
+        op = rng.rand()
+        if op < 0.15 and frames <= 40000:
+            # one channel through the per-channel entry point with strides (resample.c:927-1036, 1170-1188):
+            # the exact kernel in either mode, so the whole sentinel-filled buffers must be identical
+            c = int(rng.randint(0, ch))
+            ins, outs = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+            xc = x[:, c] if frames else x.reshape(-1)[:0]
+            a = ref.channel_call(kind, c, xc, cap, ins, outs)
+            b = got_r.channel_call(kind, c, xc, cap, ins, outs)
+            tag = "call %d (channel %d, %s, %d frames, cap %d, strides %d/%d)" % (call, c, kind, frames, cap, ins, outs)
+            if a[:3] != b[:3]:
+                return "%s: rc/used/made %s, oracle %s" % (tag, b[:3], a[:3]), what
+            if not np.array_equal(a[3], b[3]):
+                return "%s: buffers differ in %d places" % (tag, int((a[3] != b[3]).sum())), what
+            if got_r.positions() != ref.positions():
+                return "%s: positions %s, oracle %s" % (tag, got_r.positions(), ref.positions()), what
+            continue
+        if op < 0.27 and uniform and not as_float and frames >= 4:
+            # 2-4 consecutive calls as one launch (speexhip_resampler_process_chunks_int) against the
+            # oracle's separate calls, each with a capacity of its own
+            n = int(rng.randint(2, 5))
+            cuts = sorted(set(int(v) for v in rng.randint(0, frames + 1, size=n - 1)))
+            parts = np.split(x, cuts)
+            caps = [int(len(p_) * out_r / max(in_r, 1)) + 8 if rng.rand() < 0.7 else int(rng.randint(0, len(p_) + 9))
+                    for p_ in parts]
+            wants = [ref.process(p_, c_) for p_, c_ in zip(parts, caps)]
+            gouts, gused = got_r.process_chunks(parts, caps)
+            tag = "call %d (%d coalesced chunks of %s frames, caps %s)" % (call, len(parts), [len(p_) for p_ in parts], caps)
+            for i, ((w, wu), g, gu) in enumerate(zip(wants, gouts, gused)):
+                if gu != wu or g.shape != w.shape:
+                    return "%s: chunk %d consumed/produced %d/%d, oracle %d/%d" % (tag, i, gu, g.shape[0], wu, w.shape[0]), what
+                if g.size == 0:
+                    continue
+                d = np.abs(g.astype(np.int32) - w.astype(np.int32))
+                if d.max() > (0 if mode == speexhip.MODE_EXACT else 1):
+                    return "%s: chunk %d off by %d LSB" % (tag, i, d.max()), what
+            if tuple(got_r.position()) != tuple(ref.position()):
+                return "%s: position %s, oracle %s" % (tag, got_r.position(), ref.position()), what
+            continue
+        if not uniform:
+            # channels stand apart (per-channel calls before): interleaved calls go channel by channel on
+            # the exact kernel -- whole buffers identical in either mode (resample.c:1061-1082)
+            a = ref.raw_call(kind, x, cap)
+            b = got_r.raw_call(kind, x, cap)
+            tag = "call %d (split %s, %d frames, cap %d)" % (call, kind, frames, cap)
+            if a[:3] != b[:3]:
+                return "%s: rc/used/made %s, oracle %s" % (tag, b[:3], a[:3]), what
+            if not np.array_equal(a[3], b[3]):
+                return "%s: buffers differ in %d places" % (tag, int((a[3] != b[3]).sum())), what
+            if got_r.positions() != ref.positions():
+                return "%s: positions %s, oracle %s" % (tag, got_r.positions(), ref.positions()), what
+            continue
         if as_float:
             want, wu = ref.process_float(x, cap)
             got, gu = got_r.process_float(x, cap)
