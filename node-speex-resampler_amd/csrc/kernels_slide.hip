@@ -1,4 +1,5 @@
-// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6 with num <= 5, and n:1 for n <= 10 and 12):
+// kernels_slide.hip -- fast gfx950 kernel for small rational ratios (den <= 6 with num <= 6, 8:3, and n:1 for
+// n <= 10, 12, 16, 20, 24):
 // integer up-sampling 24k->48k, 16k->48k, 8k->48k, same-rate, 2:1 / 3:1 / 4:1 decimation, 3:2,
 // 2:3 ... (BASELINE configs[2]; the reference picks resampler_basic_direct_* for
 // most of these, deps/speex/resample.c:331-435).  +-1 LSB.
@@ -142,11 +143,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
     G<float> *o0 = out_ptr<float>(d) + (static_cast<int64_t>(K0) - static_cast<int64_t>(d.k_shift)) * C;
     const bool dense = PAIR_CH ? (C == 2) : (C == 1 && p.den == 2u * NP);
     if (dense && inside) {  // the lane's P*NP pairs are 2*P*NP consecutive floats
-      static_assert((P * NP) % 2 == 0, "pairs per lane come in groups of 2");
 #pragma unroll
-      for (int q = 0; q < P * NP; q += 2) {
+      for (int q = 0; q + 1 < P * NP; q += 2) {
         const f32x2 a = acc[q / NP][q % NP], b = acc[(q + 1) / NP][(q + 1) % NP];
         *(G<f32x4_a4> *)(o0 + 2 * q) = f32x4_a4{a.x, a.y, b.x, b.y};
+      }
+      if constexpr ((P * NP) % 2 != 0) {  // (one period per lane, one pair per period: the n:1 shapes)
+        o0[2 * (P * NP - 1)] = acc[P - 1][NP - 1].x;
+        o0[2 * (P * NP - 1) + 1] = acc[P - 1][NP - 1].y;
       }
       return;
     }
@@ -175,7 +179,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   const bool dense = PAIR_CH ? (C == 2) : (C == 1 && p.den == 2u * NP);
   g_i16 *o0 = out_ptr<int16_t>(d) + (static_cast<int64_t>(K0) - static_cast<int64_t>(d.k_shift)) * C;
   if (dense && inside && (reinterpret_cast<uintptr_t>(o0) & 3u) == 0) {
-    static_assert((P * NP) % 2 == 0, "pairs per lane come in groups of 2 or 4");
     if constexpr ((P * NP) % 4 == 0) {
 #pragma unroll
       for (int q = 0; q < P * NP; q += 4)
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
       typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
       typedef __attribute__((address_space(1))) u32x2_a4 g_u32x2_a4;
 #pragma unroll
-      for (int q = 0; q < P * NP; q += 2) *(g_u32x2_a4 *)(o0 + 2 * q) = u32x2_a4{v[q], v[q + 1]};
+      for (int q = 0; q + 1 < P * NP; q += 2) *(g_u32x2_a4 *)(o0 + 2 * q) = u32x2_a4{v[q], v[q + 1]};
+      if constexpr ((P * NP) % 2 != 0) *(G<uint32_t> *)(o0 + 2 * (P * NP - 1)) = v[P * NP - 1];
     }
     return;
   }
@@ -237,7 +241,7 @@ hipError_t launch_up(const SlideParams &p, const StreamDesc *d_descs, const Desc
 namespace {
 struct SlideShape { uint32_t num, np; bool pair_ch; uint32_t p; };
 // the instantiated (num, accumulator pairs per period, packing) -> periods per lane.  Bounds kept:
-// tap floats per iteration <= 48, window (2P-1)*num <= 42 frames, P*np <= 24 accumulator pairs.
+// tap floats per iteration <= 60, window (2P-1)*num <= 42 frames, P*np <= 24 accumulator pairs.
 const SlideShape kShapes[] = {
     {1, 1, true, 8}, {1, 2, true, 8}, {1, 3, true, 8}, {1, 4, true, 4}, {1, 6, true, 4},
     {1, 1, false, 8}, {1, 2, false, 8}, {1, 3, false, 4},
@@ -256,8 +260,26 @@ const SlideShape kShapes[] = {
     {7, 1, true, 2}, {7, 1, false, 2}, {9, 1, true, 2}, {9, 1, false, 2}, {10, 1, true, 2}, {10, 1, false, 2},
     // 5:2, 5:3, 5:4 (40k -> 16k / 24k / 32k)
     {5, 2, true, 2}, {5, 3, true, 2}, {5, 4, true, 2}, {5, 2, false, 2},
+    // 16:1, 20:1, 24:1 (128k -> 8k, 160k -> 8k, 192k -> 8k): ONE period per lane, its num frames the whole
+    // register window -- one FMA per sample read, but still SGPR taps and no double arithmetic: 32 streams of
+    // 192k -> 8k stereo q7 142 us against 1269 us on the exact kernel they used to fall back to, 16:1 156
+    // against 1850.  (11:1 measured no gain -- 244 vs 230 us -- and stays on the exact kernel.)
+    {16, 1, true, 1}, {16, 1, false, 1},
+    {20, 1, true, 1}, {20, 1, false, 1}, {24, 1, true, 1}, {24, 1, false, 1},
+    // 8:3 (32k -> 12k, 64k -> 24k, 128k -> 48k), 6:5 (48k -> 40k) and 5:6 (40k -> 48k): 68 / 64 / 67 us
+    // against 408 / 535 / 550 on the exact kernel (stereo q7, 32 streams of 2^18 frames)
+    {8, 3, true, 2}, {8, 2, false, 2}, {6, 5, true, 1}, {6, 3, false, 1}, {5, 6, true, 1}, {5, 3, false, 1},
 };
 }  // namespace
+
+// LDS of a workgroup of `waves` waves: one row per lane block + the rows the last lane's window runs into
+// (+ 16 floats: the image starts on the input's 16-byte grid and ends on a whole load)
+static size_t slide_lds_bytes(const SlidePlan &t, uint32_t waves) {
+  const uint32_t steps = t.p * t.num;
+  const size_t rows_needed = static_cast<size_t>(64 / t.cgroups) * waves + t.row_len / steps + 2;
+  return (rows_needed * t.row_stride + 16) * 4;
+}
+const size_t kSlideLdsLimit = 160 * 1024;  // what one workgroup can have on gfx950
 
 SlidePlan plan_slide(const FilterSpec &f, uint32_t channels) {
   SlidePlan t;
@@ -283,6 +305,9 @@ SlidePlan plan_slide(const FilterSpec &f, uint32_t channels) {
   } else {
     if (t.row_stride % 2 == 0) t.row_stride += 1;
   }
+  // a long filter on many channels (12:1 q10 on 8 channels: 200 KB with 8 waves) runs smaller workgroups
+  // (launch_slide); one that does not even fit two waves runs the exact kernel
+  if (slide_lds_bytes(t, 2) > kSlideLdsLimit) t.usable = false;
   return t;
 }
 
@@ -320,6 +345,7 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   uint32_t waves = max_waves;
   while (waves > 2 && static_cast<uint64_t>(max_periods) * n_streams < 512ull * waves * blocks_per_wave * t.p)
     waves /= 2;
+  while (waves > 2 && slide_lds_bytes(t, waves) > kSlideLdsLimit) waves /= 2;  // (fits with 2: plan_slide)
   SlideParams p;
   p.rows = d_rows;
   p.den = f.den;
@@ -336,10 +362,7 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   const uint32_t tile_periods = p.blocks_per_tile * t.p;
   const uint32_t tiles = (max_periods + tile_periods - 1) / tile_periods;
   // LDS: one row per lane block, + the rows the last lane's window runs into
-  const uint32_t steps = t.p * f.num;
-  const size_t rows_needed = p.blocks_per_tile + t.row_len / steps + 2;
-  // (+ 16 floats: the image starts on the input's 16-byte grid and ends on a whole load)
-  const size_t lds = (rows_needed * t.row_stride + 16) * 4;
+  const size_t lds = slide_lds_bytes(t, waves);
   dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
   const uint32_t threads = waves * 64;
   p.threads = threads;
@@ -389,6 +412,18 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   SPEEXHIP_SLIDE_CASE(2, 5, 3, true)
   SPEEXHIP_SLIDE_CASE(2, 5, 4, true)
   SPEEXHIP_SLIDE_CASE(2, 5, 2, false)
+  SPEEXHIP_SLIDE_CASE(1, 16, 1, true)
+  SPEEXHIP_SLIDE_CASE(1, 16, 1, false)
+  SPEEXHIP_SLIDE_CASE(1, 20, 1, true)
+  SPEEXHIP_SLIDE_CASE(1, 20, 1, false)
+  SPEEXHIP_SLIDE_CASE(1, 24, 1, true)
+  SPEEXHIP_SLIDE_CASE(1, 24, 1, false)
+  SPEEXHIP_SLIDE_CASE(2, 8, 3, true)
+  SPEEXHIP_SLIDE_CASE(2, 8, 2, false)
+  SPEEXHIP_SLIDE_CASE(1, 6, 5, true)
+  SPEEXHIP_SLIDE_CASE(1, 6, 3, false)
+  SPEEXHIP_SLIDE_CASE(1, 5, 6, true)
+  SPEEXHIP_SLIDE_CASE(1, 5, 3, false)
 #undef SPEEXHIP_SLIDE_CASE
   return hipErrorInvalidValue;
 }

@@ -280,7 +280,10 @@ def test_small_ratio_sliding_window_kernel_variants():
              (2, 24000, 40000, 6), (3, 24000, 40000, 4), (2, 32000, 40000, 8), (1, 32000, 40000, 9),
              # 5:2, 5:3, 5:4
              (2, 40000, 16000, 5), (1, 40000, 16000, 7), (2, 40000, 24000, 4), (1, 40000, 24000, 6),
-             (2, 40000, 32000, 10), (1, 40000, 32000, 2)]
+             (2, 40000, 32000, 10), (1, 40000, 32000, 2),
+             # 8:3, 6:5, 5:6 (one period per lane for the last two)
+             (2, 32000, 12000, 7), (1, 64000, 24000, 5), (4, 32000, 12000, 3), (2, 48000, 40000, 6),
+             (1, 48000, 40000, 9), (3, 48000, 40000, 4), (2, 40000, 48000, 8), (1, 40000, 48000, 5), (6, 40000, 48000, 2)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -377,10 +380,10 @@ def test_eight_channel_padded_window_and_odd_channel_counts():
 
 
 def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
-    """Ratios no fast kernel covers (11:1, 5:6, filters too long for LDS) must still be right:
+    """Ratios no fast kernel covers (11:1, 7:6, filters too long for LDS) must still be right:
     FAST mode falls back to the bit-exact kernel (fast_path == 0), staged in LDS or streaming
     straight from L2 when the filter does not fit."""
-    for (ch, i, o, q, frames) in [(1, 88000, 8000, 5, 30000), (2, 40000, 48000, 4, 4000),
+    for (ch, i, o, q, frames) in [(1, 88000, 8000, 5, 30000), (2, 56000, 48000, 4, 4000),
                                   (1, 192000, 1000, 10, 120000), (2, 96000, 1500, 3, 90000)]:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -405,7 +408,11 @@ def test_n_to_one_decimation_takes_the_slide_kernel():
                           (4, 192000, 16000, 3),
                           # 7:1, 9:1, 10:1
                           (2, 56000, 8000, 6), (1, 56000, 8000, 9), (2, 72000, 8000, 4), (1, 72000, 8000, 7),
-                          (2, 44100, 4410, 8), (1, 80000, 8000, 10)]:
+                          (2, 44100, 4410, 8), (1, 80000, 8000, 10),
+                          # 16:1, 20:1, 24:1: one period per lane, up to 6144 taps
+                          (2, 128000, 8000, 7), (1, 128000, 8000, 10),
+                          (2, 160000, 8000, 4), (3, 160000, 8000, 6), (2, 192000, 8000, 10), (1, 192000, 8000, 7),
+                          (4, 192000, 8000, 3)]:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
         assert r.info()["fast_path"] == 3, (ch, i, o, q)
@@ -414,10 +421,35 @@ def test_n_to_one_decimation_takes_the_slide_kernel():
             got, used = r.process(x, 1 << 20)
             want, wu = ref.process(x, 1 << 20)
             assert used == wu and r.position() == ref.position(), (ch, i, o, q, call)
-            assert_close(got, want, "n:1 %s call %d" % ((ch, i, o, q), call))
+            # (the share of samples that differ by 1 grows like sqrt(taps): DESIGN 4)
+            assert_close(got, want, "n:1 %s call %d" % ((ch, i, o, q), call),
+                         rate=MISMATCH_RATE * max(1.0, (r.taps / 256.0) ** 0.5))
         for c in range(ch):
             assert np.array_equal(r.history()[:, c], ref.history(c))
         r.close()
+
+
+def test_slide_kernel_workgroups_shrink_to_the_lds():
+    """A long decimation filter on many channels needs more LDS than a CU has with the usual eight
+    waves per workgroup (12:1 q10 on 8 channels: 200 KB): the launch takes smaller workgroups -- and only
+    launches big enough to want eight waves ever got there (found in round 2: `invalid argument`)."""
+    import torch
+    ch, i, o, q, S, F = 8, 96000, 8000, 10, 24, 96000
+    b = speexhip.Batch(S, ch, i, o, q)
+    assert b.info()["fast_path"] == 3
+    x = np.stack([orc.lcg_pcm(F * ch, 50 + s).reshape(F, ch) for s in range(S)])
+    d_in = torch.from_numpy(x).cuda()
+    cap = F // 12 + 16
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    used, made = b.process_device(d_in.data_ptr(), F * ch, F, d_out.data_ptr(), cap * ch, cap,
+                                  torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for s in (0, 11, 23):
+        want, wu = orc.Oracle(ch, i, o, q).process(x[s], cap)
+        assert used[s] == wu and made[s] == want.shape[0]
+        assert_close(out[s, : made[s]], want, "stream %d" % s, rate=MISMATCH_RATE * (3072 / 256.0) ** 0.5)
+    b.close()
 
 
 def test_float_entry_point_exact_and_fast(golden):

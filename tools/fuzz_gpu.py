@@ -38,7 +38,7 @@ def pick_rates(rng):
     if kind < 5:
         return int(rng.choice(COMMON)), int(rng.choice(COMMON))
     if kind < 7:  # small ratios a:b times a base
-        a, b = int(rng.randint(1, 13)), int(rng.randint(1, 13))
+        a, b = int(rng.choice(list(range(1, 13)) + [16, 20, 24])), int(rng.randint(1, 13))
         base = int(rng.choice([1000, 4000, 8000, 11025]))
         return a * base, b * base
     if kind < 9:  # near unity / oddballs with long periods
