@@ -13,7 +13,10 @@ EXACT mode must be bit-identical (samples, counters, positions); FAST mode withi
 the float bound of tests/test_gpu_parity.py, counters and positions identical.  A trial ends at a
 set_rate that returns RESAMPLER_ERR_OVERFLOW in both (the one documented deviation: DESIGN 3.5).
 
-usage: python tools/fuzz_gpu.py [--seconds 240] [--seed 1] [--max-frames 300000]
+With --batch every third trial drives 1-48 ragged streams of one configuration through the batched
+device-pointer call instead.
+
+usage: python tools/fuzz_gpu.py [--seconds 240] [--seed 1] [--max-frames 300000] [--batch]
 Prints one line per failing trial (with the seed that reproduces it) and a summary; exit code 1 on
 any failure.
 """
@@ -208,12 +211,72 @@ def one_trial(seed, max_frames):
     return None, what
 
 
+def batch_trial(seed, max_frames):
+    """Many independent streams of one configuration through speexhip.Batch.process_device (device
+    pointers, one launch per call): ragged lengths and capacities, 1-3 consecutive calls, every stream
+    checked against an oracle state of its own."""
+    import torch
+    rng = np.random.RandomState(seed)
+    ch = int(rng.choice([1, 2, 2, 3, 4, 6, 8]))
+    i, o = pick_rates(rng)
+    q = int(rng.randint(0, 11))
+    S = int(rng.choice([1, 2, 5, 8, 9, 17, 33, 48]))
+    mode = speexhip.MODE_EXACT if rng.rand() < 0.3 else speexhip.MODE_FAST
+    as_float = rng.rand() < 0.25
+    what = "seed=%d BATCH S=%d ch=%d %d->%d q=%d %s %s" % (seed, S, ch, i, o, q, "exact" if mode == speexhip.MODE_EXACT else "fast",
+                                                           "float" if as_float else "int16")
+    try:
+        refs = [orc.Oracle(ch, i, o, q) for _ in range(S)]
+    except Exception:
+        return None, what + " (oracle refuses)"
+    if refs[0].den > 4000 and refs[0].taps > 300:
+        return None, what + " (skipped: slow on the oracle)"
+    b = speexhip.Batch(S, ch, i, o, q, mode=mode)
+    fmax = max(16, min(max_frames, int(3e6 / (S * ch))))
+    dt = np.float32 if as_float else np.int16
+    for call in range(int(rng.randint(1, 4))):
+        F = int(rng.randint(1, fmax + 1))
+        lens = [F if rng.rand() < 0.5 else int(rng.randint(0, F + 1)) for _ in range(S)]
+        full = int(F * refs[0].rate()[1] / max(refs[0].rate()[0], 1)) + 64
+        caps = [full if rng.rand() < 0.8 else int(rng.randint(0, full + 1)) for _ in range(S)]
+        x = np.stack([signal(rng, F, ch, as_float) for _ in range(S)])
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.zeros((S, full, ch), dtype=torch.float32 if as_float else torch.int16, device="cuda")
+        used, made = b.process_device(d_in.data_ptr(), F * ch, lens, d_out.data_ptr(), full * ch, caps,
+                                      torch.cuda.current_stream().cuda_stream, float_io=as_float)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        for s_ in range(S):
+            want, wu = (refs[s_].process_float if as_float else refs[s_].process)(x[s_, : lens[s_]].astype(dt), caps[s_])
+            tag = "call %d stream %d (%d of %d frames, cap %d)" % (call, s_, lens[s_], F, caps[s_])
+            if used[s_] != wu or made[s_] != want.shape[0]:
+                return "%s: consumed/produced %d/%d, oracle %d/%d" % (tag, used[s_], made[s_], wu, want.shape[0]), what
+            got = out[s_, : made[s_]]
+            if got.size == 0:
+                continue
+            if mode == speexhip.MODE_EXACT:
+                if not np.array_equal(got, want):
+                    return "%s: EXACT differs in %d samples" % (tag, int((got != want).sum())), what
+            elif as_float:
+                scale = max(1.0, float(np.abs(want).max()))
+                err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+                if err > 4e-6 * scale * 8:
+                    return "%s: float error %.3g at scale %.3g" % (tag, err, scale), what
+            else:
+                d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+                if d.max() > 1:
+                    return "%s: %d LSB" % (tag, d.max()), what
+    b.close()
+    return None, what
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-frames", type=int, default=300000)
     ap.add_argument("--only", type=int, default=None, help="run exactly this trial seed")
+    ap.add_argument("--batch", action="store_true", help="every third trial: many streams through Batch.process_device")
     args = ap.parse_args()
     orc.build()
     t0 = time.time()
@@ -221,7 +284,10 @@ def main():
     seed = args.seed * 1000003
     while time.time() - t0 < args.seconds:
         s = args.only if args.only is not None else seed + trials
-        err, what = one_trial(s, args.max_frames)
+        if args.batch and (s % 3 == 0):
+            err, what = batch_trial(s, args.max_frames)
+        else:
+            err, what = one_trial(s, args.max_frames)
         trials += 1
         if err:
             fails += 1
