@@ -60,6 +60,11 @@ declare class SpeexResampler {
     flush(): Buffer;
     /** release the GPU state now instead of at garbage collection */
     destroy(): void;
+    /**
+     * Extension: hand the idle device / pinned memory that destroyed states left in the process-wide
+     * pool (kept for the next `new SpeexResampler`) back to the driver; returns the bytes released.
+     */
+    static releaseCachedMemory(): number;
 }
 
 /** `stream.Transform` around a SpeexResampler; misaligned trailing bytes wait for the next chunk. */

@@ -208,6 +208,17 @@ class SpeexResampler {
   }
 }
 SpeexResampler.initPromise = globalModulePromise;
+/**
+ * Extension.  Destroyed (or collected) states leave their device buffers, pinned staging buffers and
+ * filter tables in a process-wide pool for the next `new SpeexResampler` (DESIGN 3.5); this hands
+ * whatever is idle there back to the driver and returns the number of bytes.
+ */
+SpeexResampler.releaseCachedMemory = () => {
+  if (!speexModule) {
+    throw new Error('You need to wait for SpeexResampler.initPromise before calling this method');
+  }
+  return speexModule.releaseCachedMemory();
+};
 
 const EMPTY_BUFFER = Buffer.alloc(0);
 

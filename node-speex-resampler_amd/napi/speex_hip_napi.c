@@ -514,6 +514,14 @@ static napi_value Version(napi_env env, napi_callback_info info) {
   return s;
 }
 
+/* releaseCachedMemory() -> bytes handed back to the driver (speexhip_release_cached_memory) */
+static napi_value ReleaseCachedMemory(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value v;
+  NAPI_OK(napi_create_double(env, (double)speexhip_release_cached_memory(), &v));
+  return v;
+}
+
 static napi_value ModuleInit(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"init", NULL, Init, NULL, NULL, NULL, napi_default, NULL},
@@ -532,6 +540,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
       {"getRate", NULL, GetRate, NULL, NULL, NULL, napi_default, NULL},
       {"strerror", NULL, StrError, NULL, NULL, NULL, napi_default, NULL},
       {"version", NULL, Version, NULL, NULL, NULL, napi_default, NULL},
+      {"releaseCachedMemory", NULL, ReleaseCachedMemory, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props) != napi_ok)
     napi_throw_error(env, NULL, "speexhip: cannot define exports");

@@ -274,6 +274,25 @@ async function extensionsTest() {
   assert(msg === 'Invalid argument.', 'setQuality(42) must throw the reference message');
 }
 
+// States are cheap to make and drop: a destroyed state's device resources wait in a pool for the next
+// one, and releaseCachedMemory() hands them back; bytes out must not depend on any of that.
+function poolTest() {
+  const chunk = lcg(20000, 2, 99);
+  const first = new SpeexResampler(2, 44100, 48000, 7);
+  const want = sha1(first.processChunk(chunk));
+  first.destroy();
+  for (let k = 0; k < 20; k++) {
+    const r = new SpeexResampler(2, 44100, 48000, 7);
+    assert(sha1(r.processChunk(chunk)) === want, 'a recycled state must produce the same bytes');
+    if (k % 2) r.destroy();  // the others wait for the garbage collector
+  }
+  assert(SpeexResampler.releaseCachedMemory() > 0, 'destroyed states left memory in the pool');
+  const r = new SpeexResampler(2, 44100, 48000, 7);
+  assert(sha1(r.processChunk(chunk)) === want, 'a state made after the release must produce the same bytes');
+  r.destroy();
+  console.log('state pool: recycled and released, bytes unchanged');
+}
+
 (async () => {
   const early = (() => { try { new SpeexResampler(1, 8000, 8000).processChunk(Buffer.alloc(2)); return null; } catch (e) { return e.message; } })();
   assert(early === 'You need to wait for SpeexResampler.initPromise before calling this method', 'initPromise guard');
@@ -283,5 +302,6 @@ async function extensionsTest() {
   goldenTest();
   errorTest();
   await extensionsTest();
+  poolTest();
   console.log('ALL NODE TESTS PASSED');
 })().catch((e) => { console.error(e); process.exit(1); });

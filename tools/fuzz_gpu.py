@@ -232,7 +232,10 @@ def batch_trial(seed, max_frames):
     if refs[0].den > 4000 and refs[0].taps > 300:
         return None, what + " (skipped: slow on the oracle)"
     b = speexhip.Batch(S, ch, i, o, q, mode=mode)
-    fmax = max(16, min(max_frames, int(3e6 / (S * ch))))
+    # (one trial in eight is big enough for launches of several generations of workgroups: other tile
+    #  shapes, the mono image stores, eight-wave slide workgroups)
+    budget = 24e6 if rng.rand() < 0.125 else 3e6
+    fmax = max(16, min(max_frames if budget < 4e6 else 1 << 20, int(budget / (S * ch))))
     dt = np.float32 if as_float else np.int16
     for call in range(int(rng.randint(1, 4))):
         F = int(rng.randint(1, fmax + 1))
