@@ -559,18 +559,22 @@ const size_t kSlack = 16;  // floats: window starts on the input's 16-byte grid,
 // box).  R = 5 pads its rows by 4 instead of 9 steps and
 // gives a tile twice as many wave-sized pieces -- what a launch of a single generation of workgroups
 // needs -- at half the FMAs per sample read and 20-byte instead of 40-byte store pieces per lane.
-uint32_t default_r() {
-  static const uint32_t r = [] {
+// A ratio with few phases (den <= 80: 44.1k -> 8k = 441:80, 88.2k -> 48k = 147:80, 88.2k -> 16k ...) has at
+// most 8 groups of 10: 8 FIR waves per workgroup, 2-4 per SIMD.  Groups of 5 double the waves: 32 streams
+// of 44.1k -> 8k stereo q7 193 -> 88 us, 88.2k -> 48k 69 -> 63, 4 channels 44.1k -> 8k 156 -> 127 (same box).
+uint32_t default_r(const FilterSpec &f) {
+  static const uint32_t forced = [] {
     const char *e = std::getenv("SPEEXHIP_R");
-    return e != nullptr && std::atoi(e) == 5 ? 5u : 10u;
+    return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
   }();
-  return r;
+  if (forced == 5 || forced == 10) return forced;
+  return (f.den + 9) / 10 <= 8 ? 5u : 10u;
 }
 
 }  // namespace
 
 PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget) {
-  PeriodPlan t = plan_period_r(f, channels, lds_budget, default_r());
+  PeriodPlan t = plan_period_r(f, channels, lds_budget, default_r(f));
   if (!t.usable && t.r != 10) t = plan_period_r(f, channels, lds_budget, 10);
   return t;
 }
