@@ -742,26 +742,33 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-int Batch::ensure_stage(size_t in_bytes, size_t out_bytes) {
+// Staging buffers of the host-buffer calls, each grow-only (like the wrapper's heap buffers,
+// src/index.ts:71-87) and taken only when a call needs it: small calls run on the pinned pair alone,
+// large ones on the device pair alone (the runtime copies straight from / to the caller's memory).
+// The calls are synchronous, so nothing in flight uses a buffer that goes back to the pool here.
+int Batch::ensure_stage(size_t dev_in, size_t dev_out, size_t pin_in, size_t pin_out) {
   if (own_stream_ == nullptr) HIP_TRY(pool::stream_get(device_, &own_stream_));
-  // grow-only, like the wrapper's heap buffers (src/index.ts:71-87); the host-buffer calls are
-  // synchronous, so nothing in flight uses the buffers that go back to the pool here
-  auto grow = [&](char **dev, char **pin, size_t *cap_now, size_t want) -> int {
+  auto grow = [&](char **buf, size_t *cap_now, size_t want, bool pinned) -> int {
     if (want <= *cap_now) return SPEEXHIP_ERR_SUCCESS;
-    pool::device_put(device_, *dev);
-    pool::pinned_put(*pin);
-    *dev = nullptr;
-    *pin = nullptr;
+    if (pinned)
+      pool::pinned_put(*buf);
+    else
+      pool::device_put(device_, *buf);
+    *buf = nullptr;
     *cap_now = 0;
     const size_t cap = pool::size_class(std::max<size_t>(want, 8192));
-    HIP_TRY(pool::device_get(device_, reinterpret_cast<void **>(dev), cap));
-    HIP_TRY(pool::pinned_get(reinterpret_cast<void **>(pin), cap));
+    if (pinned)
+      HIP_TRY(pool::pinned_get(reinterpret_cast<void **>(buf), cap));
+    else
+      HIP_TRY(pool::device_get(device_, reinterpret_cast<void **>(buf), cap));
     *cap_now = cap;
     return SPEEXHIP_ERR_SUCCESS;
   };
-  int rc = grow(&d_stage_in_, &h_pin_in_, &stage_in_cap_, in_bytes);
-  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  return grow(&d_stage_out_, &h_pin_out_, &stage_out_cap_, out_bytes);
+  int rc = grow(&d_stage_in_, &stage_in_cap_, dev_in, false);
+  if (rc == SPEEXHIP_ERR_SUCCESS) rc = grow(&d_stage_out_, &stage_out_cap_, dev_out, false);
+  if (rc == SPEEXHIP_ERR_SUCCESS) rc = grow(&h_pin_in_, &pin_in_cap_, pin_in, true);
+  if (rc == SPEEXHIP_ERR_SUCCESS) rc = grow(&h_pin_out_, &pin_out_cap_, pin_out, true);
+  return rc;
 }
 
 int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io) {
@@ -776,8 +783,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     will_make = std::max(will_make, produced_closed_form(filter_.num, filter_.den, frames, *out_len, P(0, c)));
   const size_t in_bytes = static_cast<size_t>(frames) * channels_ * es;
   const size_t out_bytes = static_cast<size_t>(will_make) * channels_ * es;
-  int rc = ensure_stage(in_bytes, out_bytes);
-  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  int rc = SPEEXHIP_ERR_SUCCESS;
   // Large buffers go straight from / to the caller's pageable memory: the HIP runtime stages such
   // copies itself and does it 2.2-2.5x faster than memcpy -> pinned -> DMA in one thread (2^20
   // stereo frames: 0.46 -> 0.21 ms per call, 8 channels 1.57 -> 0.63 ms).  Small ones go through
@@ -804,6 +810,8 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     return e != nullptr ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kDirectCopyBytes;
   }();
   if (!split && in_bytes < zero_copy_below && out_bytes < zero_copy_below) {
+    rc = ensure_stage(0, 0, in_bytes, out_bytes);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     if (in != nullptr && in_bytes != 0) std::memcpy(h_pin_in_, in, in_bytes);
     rc = process_device(in != nullptr ? h_pin_in_ : nullptr, 0, in_len, h_pin_out_, 0, out_len, float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
@@ -812,6 +820,8 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     if (made != 0) std::memcpy(out, h_pin_out_, made);
     return rc;
   }
+  rc = ensure_stage(in_bytes, out_bytes, direct_in ? 0 : in_bytes, direct_out ? 0 : out_bytes);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   if (in != nullptr && in_bytes != 0) {
     if (direct_in) {
       HIP_TRY(hipMemcpyAsync(d_stage_in_, in, in_bytes, hipMemcpyHostToDevice, own_stream_));
@@ -864,7 +874,8 @@ int Batch::process_channel_host(uint32_t c, const void *in, uint32_t *in_len, vo
   const uint32_t frames = *in_len;
   const CallPlan plan = plan_call(filter_.num, filter_.den, frames, *out_len, P(0, c), rules);
   if (frames != 0 && *out_len != 0) started_[0] = 1;
-  int rc = ensure_stage(static_cast<size_t>(frames) * es, static_cast<size_t>(plan.produced) * es);
+  const size_t line_in = static_cast<size_t>(frames) * es, line_out = static_cast<size_t>(plan.produced) * es;
+  int rc = ensure_stage(line_in, line_out, line_in, line_out);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   if (in != nullptr && frames != 0) {
     for (uint32_t j = 0; j < frames; j++)
@@ -952,7 +963,8 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
     }
     if (frames > 0x7fffffffull || made > 0x7fffffffull) return SPEEXHIP_ERR_OVERFLOW;
   }
-  int rc = ensure_stage(frames * fb, made * fb);
+  const bool direct_out = made * fb >= kDirectCopyBytes;
+  int rc = ensure_stage(frames * fb, made * fb, frames * fb, direct_out ? 0 : made * fb);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   size_t off = 0;
   for (uint32_t i = 0; i < n_chunks; i++) {  // frames a call drops never reach the GPU
@@ -969,7 +981,6 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
                    float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
-  const bool direct_out = made * fb >= kDirectCopyBytes;
   if (made != 0)
     HIP_TRY(hipMemcpyAsync(direct_out ? out : h_pin_out_, d_stage_out_, made * fb, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));

@@ -120,7 +120,7 @@ class Batch {
                     hipStream_t stream, std::vector<CallPlan> *plans_out);
   int fetch_history(std::vector<float> *host);
   uint32_t block_in() const { return line_ - (filter_.taps - 1); }
-  int ensure_stage(size_t in_bytes, size_t out_bytes);
+  int ensure_stage(size_t dev_in, size_t dev_out, size_t pin_in, size_t pin_out);
   int run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_frames, void *d_out,
                 uint64_t out_stride, const CallPlan *plans, bool float_io, hipStream_t stream);
 
@@ -170,7 +170,7 @@ class Batch {
   hipStream_t own_stream_ = nullptr;
   char *d_stage_in_ = nullptr, *d_stage_out_ = nullptr;
   char *h_pin_in_ = nullptr, *h_pin_out_ = nullptr;
-  size_t stage_in_cap_ = 0, stage_out_cap_ = 0;  // bytes
+  size_t stage_in_cap_ = 0, stage_out_cap_ = 0, pin_in_cap_ = 0, pin_out_cap_ = 0;  // bytes
 };
 
 }  // namespace speexhip
