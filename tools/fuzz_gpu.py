@@ -68,9 +68,9 @@ def signal(rng, frames, ch, as_float):
     return x
 
 
-def one_trial(seed, max_frames):
+def one_trial(seed, max_frames, many_channels=False):
     rng = np.random.RandomState(seed)
-    ch = int(rng.choice([1, 1, 2, 2, 2, 3, 4, 5, 6, 7, 8]))
+    ch = int(rng.choice([1, 1, 2, 2, 2, 3, 4, 5, 6, 7, 8] + ([9, 12, 16, 24, 32, 64, 65, 100] if many_channels else [])))
     i, o = pick_rates(rng)
     q = int(rng.randint(0, 11))
     mode = speexhip.MODE_EXACT if rng.rand() < 0.35 else speexhip.MODE_FAST
@@ -114,8 +114,8 @@ def one_trial(seed, max_frames):
             got_r.reset_mem()
         as_float = rng.rand() < 0.3
         size_kind = rng.randint(0, 6)
-        frames = [0, 1, int(rng.randint(2, 200)), int(rng.randint(200, 5000)), int(rng.randint(5000, 60000)),
-                  int(rng.randint(60000, max_frames + 1))][size_kind]
+        frames = [0, 1, int(rng.randint(2, 200)), int(rng.randint(200, 5000)), int(rng.randint(5000, 60000)) if max_frames >= 60000 else int(rng.randint(200, max_frames + 1)),
+                  int(rng.randint(min(60000, max_frames), max_frames + 1))][size_kind]
         frames = min(frames, max(0, max_frames * 2 - frames_done))
         frames_done += frames
         x = signal(rng, frames, ch, as_float)
@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-frames", type=int, default=300000)
     ap.add_argument("--only", type=int, default=None, help="run exactly this trial seed")
+    ap.add_argument("--many-channels", action="store_true", help="channel counts up to 100 (shorter calls)")
     ap.add_argument("--batch", action="store_true", help="every third trial: many streams through Batch.process_device")
     args = ap.parse_args()
     orc.build()
@@ -290,7 +291,7 @@ def main():
         if args.batch and (s % 3 == 0):
             err, what = batch_trial(s, args.max_frames)
         else:
-            err, what = one_trial(s, args.max_frames)
+            err, what = one_trial(s, args.max_frames if not args.many_channels else min(args.max_frames, 30000), args.many_channels)
         trials += 1
         if err:
             fails += 1
