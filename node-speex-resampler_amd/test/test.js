@@ -286,7 +286,8 @@ function poolTest() {
     assert(sha1(r.processChunk(chunk)) === want, 'a recycled state must produce the same bytes');
     if (k % 2) r.destroy();  // the others wait for the garbage collector
   }
-  assert(SpeexResampler.releaseCachedMemory() > 0, 'destroyed states left memory in the pool');
+  const released = SpeexResampler.releaseCachedMemory();
+  assert(released > 0 || process.env.SPEEXHIP_POOL_MB === '0', 'destroyed states left memory in the pool');
   const r = new SpeexResampler(2, 44100, 48000, 7);
   assert(sha1(r.processChunk(chunk)) === want, 'a state made after the release must produce the same bytes');
   r.destroy();
