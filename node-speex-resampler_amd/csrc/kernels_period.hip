@@ -175,7 +175,10 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   //  count, which it keeps in a VGPR -- v_add_co, branch on vcc -- because no SGPR is left under the cap.
   //  Forcing the count into an SGPR, or running two iterations per trip (one address step, scalar count:
   //  1 in 81), pushes SGPR spills past the 64 VGPRs into scratch in every instantiation: 32 streams
-  //  208 -> 219 us, 8 channels 607 -> 667, float 273 -> 337.)
+  //  208 -> 219 us, 8 channels 607 -> 667, float 273 -> 337.  Re-reading the parameters and the descriptor
+  //  from memory after the loop, so that they need not live across it, takes the headline instance from
+  //  18 to 3 spilled SGPRs -- and the scalar count still spills: it is the loop's own 40 taps + pointers +
+  //  temporaries that fill the budget.)
   auto run = [&](uint32_t count, auto lo_c, auto hi_c) {
     for (uint32_t left = count; left != 0; left--) {
       touch_bank(ta, xa);
