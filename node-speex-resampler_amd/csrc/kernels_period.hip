@@ -79,15 +79,20 @@ struct LaneCtx {
   uint64_t K_lane;  // canonical output index of the lane's period, phase 0
 };
 
-template <int CT, bool ONE_GROUP, bool PADDED>
+template <int CT, bool ONE_GROUP, bool PADDED, int CGF = 0>
 __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshift, uint32_t m_lo,
                                             uint32_t m_cnt, uint32_t lane) {
   // ONE_GROUP: the frame is exactly one channel group (mono, stereo): the sample stride is a
   // compile-time constant and the LDS reads of an iteration share one address register.
+  // CGF != 0: a frame of CGF channel groups (4, 6, 8 channels as 2, 3, 4 pairs) known at compile time:
+  // the same for the common multi-channel layouts -- the FIR loop of 8 channels spent 4 vector adds per
+  // 40 FMAs on LDS addresses with the stride in a register.
+  constexpr uint32_t kGroups = ONE_GROUP ? 1u : static_cast<uint32_t>(CGF);
+  const uint32_t cgroups = kGroups != 0 ? kGroups : p.cgroups;
   LaneCtx c;
-  c.C = ONE_GROUP ? static_cast<uint32_t>(CT) : p.channels;
-  c.cg = ONE_GROUP ? 0 : lane % p.cgroups;
-  const uint32_t pl = ONE_GROUP ? lane : lane / p.cgroups;  // period of this lane inside the tile
+  c.C = kGroups != 0 ? kGroups * CT : p.channels;
+  c.cg = ONE_GROUP ? 0 : lane % cgroups;
+  const uint32_t pl = ONE_GROUP ? lane : lane / cgroups;  // period of this lane inside the tile
   // CT == 1 (odd channel counts): a packed FMA has no second channel to work on, so the lane takes
   // a second PERIOD instead, half a tile further (p.half_periods): .x = period pl, .y = pl + half.
   const uint32_t lane_max = CT == 1 ? p.half_periods : p.lane_periods;
@@ -343,12 +348,12 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
 
 // FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
 // followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0>
 __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__restrict__ rows,
                                          const StreamDesc &d, const float *xs, uint32_t xshift,
                                          uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
                                          uint32_t zsplit, uint32_t nsplit) {
-  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED>(p, xshift, m_lo, m_cnt, lane);
+  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p, xshift, m_lo, m_cnt, lane);
   const uint32_t g_step = p.wave_groups * nsplit;
   for (uint32_t g = zsplit * p.wave_groups + wave; g < p.groups; g += g_step) {
     f32x2 acc[R];  // .x = first channel of the pair, .y = second (unused when CT == 1)
@@ -477,7 +482,7 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
 //
 // Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
 // shares of its phase groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T, int CGF = 0>
 __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -536,25 +541,25 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
       return;
     }
   }
-  fir_tile<R, CT, ONE_GROUP, PADDED, T>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
+  fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
                                         blockIdx.z, gridDim.z);
 }
 
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
   if (pack != nullptr)
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T>, seen_packed);
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF>, seen_packed);
   else
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T>, seen_ring);
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF>, seen_ring);
   if (pack != nullptr)
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T>), grid, dim3(threads), lds_bytes, stream, p,
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, nullptr, *pack);
   else
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T>), grid, dim3(threads), lds_bytes, stream, p,
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF>), grid, dim3(threads), lds_bytes, stream, p,
                        p.rows, d_descs, empty);
   return hipGetLastError();
 }
@@ -890,7 +895,27 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 #define SPEEXHIP_PERIOD_CASE_R(RV, CTV, ONE, PADV)                                                            \
   return float_io ? launch_rc<RV, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, stream)   \
                   : launch_rc<RV, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
+  // 4 / 6 / 8 channels: channel pairs per frame as a compile-time constant (lane_ctx)
+#define SPEEXHIP_PERIOD_CASE_CG(RV, PADV, CGV)                                                                        \
+  return float_io ? launch_rc<RV, 2, false, PADV, float, CGV>(p, d_descs, pack, grid, threads, t.window_bytes, stream)   \
+                  : launch_rc<RV, 2, false, PADV, int16_t, CGV>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
   const bool padded = t.pad != 0;
+  if (t.ct == 2 && t.cgroups >= 2 && t.cgroups <= 4) {
+    if (t.r == 5) {
+      if (t.cgroups == 2) SPEEXHIP_PERIOD_CASE_CG(5, false, 2);
+      if (t.cgroups == 3) SPEEXHIP_PERIOD_CASE_CG(5, false, 3);
+      SPEEXHIP_PERIOD_CASE_CG(5, false, 4);
+    }
+    if (!padded) {
+      if (t.cgroups == 2) SPEEXHIP_PERIOD_CASE_CG(10, false, 2);
+      if (t.cgroups == 3) SPEEXHIP_PERIOD_CASE_CG(10, false, 3);
+      SPEEXHIP_PERIOD_CASE_CG(10, false, 4);
+    }
+    if (t.cgroups == 2) SPEEXHIP_PERIOD_CASE_CG(10, true, 2);
+    if (t.cgroups == 3) SPEEXHIP_PERIOD_CASE_CG(10, true, 3);
+    SPEEXHIP_PERIOD_CASE_CG(10, true, 4);
+  }
+#undef SPEEXHIP_PERIOD_CASE_CG
   if (t.r == 5) {  // never padded (plan_period_r)
     if (t.ct == 2 && t.cgroups == 1) SPEEXHIP_PERIOD_CASE_R(5, 2, true, false);
     if (t.ct == 2) SPEEXHIP_PERIOD_CASE_R(5, 2, false, false);
