@@ -310,6 +310,15 @@ SPEEXHIP_API int speexhip_resampler_get_channel_position(SpeexHipResamplerState 
                                                          int32_t *last_sample, uint32_t *samp_frac_num,
                                                          uint32_t *magic_samples);
 
+/* Host-only (no GPU needed, used by the CPU tests): which fast kernel a (ratio, quality, channel count)
+ * gets and with what geometry.  out[0] = fast path (2 period kernel, 3 slide kernel, 0 exact kernel only),
+ * period kernel: out[1] = phases per wave (10 / 5), out[2] = periods per tile, out[3] = row length (steps),
+ * out[4] = LDS window bytes, out[5] = bank padding (floats per period), out[6] = 1 if a second plan with 5
+ * phases per wave serves launches of one generation; slide kernel: out[1] = periods per lane, out[3] = row
+ * length (steps), out[4] = LDS bytes of a two-wave workgroup, out[7] = tap steps per iteration. */
+SPEEXHIP_API int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
+                                     uint32_t out[8]);
+
 /* Test hook: the n-th next device allocation made while installing a filter fails, as if the
  * device were out of memory (exercises the resampler_basic_zero fallback, and the release of what
  * an aborted install had already allocated, without exhausting HBM); 0 = off. */

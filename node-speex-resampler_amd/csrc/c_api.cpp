@@ -214,6 +214,36 @@ int speexhip_resampler_get_channel_position(SpeexHipResamplerState *st, uint32_t
   return SPEEXHIP_ERR_SUCCESS;
 }
 
+int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels, uint32_t out[8]) {
+  if (out == nullptr || channels == 0) return SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] {
+    speexhip::FilterSpec f;
+    const int rc = speexhip::design_filter_frac(ratio_num, ratio_den, ratio_num, ratio_den, quality, &f, false);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    std::memset(out, 0, 8 * sizeof(uint32_t));
+    const speexhip::PeriodPlan t = speexhip::plan_period(f, channels, speexhip::lds_budget());
+    const speexhip::SlidePlan sl = speexhip::plan_slide(f, channels);
+    if (t.usable) {
+      out[0] = 2;
+      out[1] = t.r;
+      out[2] = t.lane_periods;
+      out[3] = t.row_len;
+      out[4] = static_cast<uint32_t>(t.window_bytes);
+      out[5] = t.pad;
+      if (t.r == 10) {
+        const speexhip::PeriodPlan fine = speexhip::plan_period_r(f, channels, speexhip::lds_budget(), 5);
+        out[6] = fine.usable && fine.lane_periods == t.lane_periods;
+      }
+    } else if (sl.usable) {
+      out[0] = 3;
+      out[1] = sl.p;
+      out[3] = sl.row_len;
+      out[4] = static_cast<uint32_t>(speexhip::slide_lds_bytes(sl, 2));
+      out[7] = sl.p * sl.num;
+    }
+    return static_cast<int>(SPEEXHIP_ERR_SUCCESS);
+  });
+}
 void speexhip_debug_fail_device_allocs(int n) { speexhip::debug_fail_device_allocs(n); }
 uint64_t speexhip_release_cached_memory(void) {
   const uint64_t tables = speexhip::release_cached_tables();  // first: they return their buffers to the pool

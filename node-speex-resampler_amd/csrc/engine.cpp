@@ -74,6 +74,7 @@ const size_t kDirectCopyBytes = 256 * 1024;  // host buffers at least this big s
 
 const char *last_device_error() { return g_last_error.c_str(); }
 void set_last_device_error(const std::string &text) { g_last_error = text; }
+size_t lds_budget() { return kLdsBudget; }
 void debug_fail_device_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
 
 bool Batch::uniform(uint32_t s) const {

@@ -18,6 +18,7 @@ namespace speexhip {
 
 const char *last_device_error();  // text of the most recent HIP failure on this thread
 void set_last_device_error(const std::string &text);
+size_t lds_budget();  // LDS the planners may give one workgroup (of the CU's 160 KiB)
 // Test hook: the n-th next device allocation of a filter install fails (resample.c:785-791 path); 0 = off.
 void debug_fail_device_allocs(int n);
 

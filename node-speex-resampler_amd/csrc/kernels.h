@@ -84,6 +84,7 @@ struct SlidePlan {
   uint32_t p = 8, num = 1, np = 1, cgroups = 1, row_stride = 0, row_len = 0;
 };
 SlidePlan plan_slide(const FilterSpec &f, uint32_t channels);
+size_t slide_lds_bytes(const SlidePlan &t, uint32_t waves);  // LDS of a workgroup of `waves` waves
 void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float> *rows);
 hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
                         const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,

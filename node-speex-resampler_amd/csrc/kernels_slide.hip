@@ -58,7 +58,7 @@ const SlideShape kShapes[] = {
 
 // LDS of a workgroup of `waves` waves: one row per lane block + the rows the last lane's window runs into
 // (+ 16 floats: the image starts on the input's 16-byte grid and ends on a whole load)
-static size_t slide_lds_bytes(const SlidePlan &t, uint32_t waves) {
+size_t slide_lds_bytes(const SlidePlan &t, uint32_t waves) {
   const uint32_t steps = t.p * t.num;
   const size_t rows_needed = static_cast<size_t>(64 / t.cgroups) * waves + t.row_len / steps + 2;
   return (rows_needed * t.row_stride + 16) * 4;

@@ -44,7 +44,7 @@ EXPORTS = [
     "speexhip_resampler_set_input_stride", "speexhip_resampler_get_input_stride",
     "speexhip_resampler_set_output_stride", "speexhip_resampler_get_output_stride",
     "speexhip_resampler_get_channel_position", "speexhip_debug_fail_device_allocs",
-    "speexhip_release_cached_memory",
+    "speexhip_release_cached_memory", "speexhip_debug_plan",
 ]
 
 
@@ -161,6 +161,8 @@ def lib():
         L.speexhip_resampler_get_channel_position.argtypes = [p, u32, pi32, pu32, pu32]
         L.speexhip_debug_fail_device_allocs.restype = None
         L.speexhip_debug_fail_device_allocs.argtypes = [i32]
+        L.speexhip_debug_plan.restype = C.c_int
+        L.speexhip_debug_plan.argtypes = [u32, u32, i32, u32, C.POINTER(u32)]
         L.speexhip_release_cached_memory.restype = C.c_uint64
         L.speexhip_release_cached_memory.argtypes = []
         _lib = L
@@ -215,6 +217,17 @@ def plan_call_ex(num, den, in_len, out_cap, float_entry, block_in, last, frac, m
     if rc != 0:
         raise ValueError(strerror(rc))
     return c.value, p.value, l.value, f.value, m.value
+
+
+def debug_plan(ratio_num, ratio_den, quality, channels):
+    """host-only: which fast kernel this configuration gets and its geometry (speexhip_debug_plan)"""
+    out = (C.c_uint32 * 8)()
+    rc = lib().speexhip_debug_plan(ratio_num, ratio_den, quality, channels, out)
+    if rc:
+        raise ValueError(strerror(rc))
+    v = list(out)
+    return {"fast_path": v[0], "r_or_p": v[1], "lane_periods": v[2], "row_len": v[3], "lds_bytes": v[4],
+            "pad": v[5], "fine_plan": bool(v[6]), "steps_per_iteration": v[7]}
 
 
 def plan_filter_change(old_taps, new_taps, magic, phase=None, old_den=1, new_den=1):

@@ -370,3 +370,51 @@ def test_per_channel_planner_and_failed_filter_counters_match_the_reference_scri
             assert got == want, (c["name"], k, op, got, want)
             checked += 1
     assert checked == 624
+
+
+def test_planner_invariants_over_rates_qualities_and_channel_counts():
+    """speexhip_debug_plan (host-only): whatever fast kernel a configuration gets, its geometry must fit
+    the machine -- the period kernel's window inside the LDS budget, the slide kernel's smallest
+    workgroup inside a CU's 160 KiB (a plan that did not was found on the GPU in round 2: 12:1 q10 on 8
+    channels), its rows an even number of iterations (the carry loop runs two per trip)."""
+    rates = [8000, 11025, 12000, 16000, 22050, 24000, 32000, 40000, 44100, 48000, 56000, 64000, 72000, 80000,
+             88200, 96000, 128000, 160000, 176400, 192000]
+    seen = {0: 0, 2: 0, 3: 0}
+    for i in rates:
+        for o in rates:
+            for q in (0, 5, 10):
+                for ch in (1, 2, 3, 4, 8):
+                    try:
+                        t = speexhip.debug_plan(i, o, q, ch)
+                    except ValueError:
+                        continue  # a filter the reference refuses too (length overflow)
+                    seen[t["fast_path"]] += 1
+                    if t["fast_path"] == 2:
+                        assert t["r_or_p"] in (5, 10) and t["lane_periods"] >= 1, (i, o, q, ch, t)
+                        assert t["lds_bytes"] <= 150 * 1024, (i, o, q, ch, t)
+                        assert t["pad"] % 4 == 0 and not (t["r_or_p"] == 5 and t["pad"]), (i, o, q, ch, t)
+                    elif t["fast_path"] == 3:
+                        assert t["lds_bytes"] <= 160 * 1024, (i, o, q, ch, t)
+                        assert t["row_len"] % (2 * t["steps_per_iteration"]) == 0, (i, o, q, ch, t)
+                        assert t["r_or_p"] in (1, 2, 4, 8), (i, o, q, ch, t)
+    assert min(seen.values()) > 0, seen  # the sweep reached all three outcomes
+
+
+def test_planner_choices_for_the_named_configurations():
+    """The BASELINE configurations and the rules added in round 2."""
+    plan = speexhip.debug_plan
+    cfg2 = plan(44100, 48000, 7, 2)
+    assert (cfg2["fast_path"], cfg2["r_or_p"], cfg2["fine_plan"], cfg2["pad"]) == (2, 10, True, 0)
+    cfg4 = plan(48000, 44100, 5, 8)
+    assert (cfg4["fast_path"], cfg4["r_or_p"], cfg4["lane_periods"]) == (2, 10, 15) and cfg4["pad"] != 0
+    assert plan(24000, 48000, 10, 1)["fast_path"] == 3 and plan(24000, 48000, 5, 1)["r_or_p"] == 8
+    # few phases (den <= 80): groups of 5 in every launch
+    for i, o in ((44100, 8000), (88200, 48000), (88200, 16000), (176400, 8000)):
+        assert plan(i, o, 7, 2)["r_or_p"] == 5, (i, o)
+    # n:1 shapes: one period per lane from 16:1 on; 11:1 and 7:6 have no fast kernel
+    assert plan(192000, 8000, 7, 2)["r_or_p"] == 1 and plan(96000, 8000, 7, 2)["r_or_p"] == 2
+    assert plan(48000, 8000, 7, 2)["r_or_p"] == 4 and plan(48000, 24000, 7, 2)["r_or_p"] == 8
+    assert plan(88000, 8000, 5, 1)["fast_path"] == 0 and plan(56000, 48000, 4, 2)["fast_path"] == 0
+    # a filter too long for even a two-wave workgroup falls back to the exact kernel
+    assert plan(192000, 8000, 10, 8)["fast_path"] in (0, 3)
+    assert plan(192000, 1000, 10, 1)["fast_path"] == 0
