@@ -223,12 +223,17 @@ def launch_ranks(args):
     port = s.getsockname()[1]
     s.close()
     procs = []
+    # rank 0's stdout goes to a temporary file, not a pipe: nobody reads a pipe until every rank has
+    # exited, and a rank 0 that printed more than the pipe holds (library warnings) would block on it
+    # while the others wait for it at the next barrier
+    import tempfile
+    rank0_out = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, WORLD_SIZE=str(args.gpus), RANK=str(r), LOCAL_RANK=str(r),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=rank0_out if r == 0 else subprocess.DEVNULL))
     rc = 0
     live = list(procs)
     while live:
@@ -242,7 +247,8 @@ def launch_ranks(args):
                 for q in live:  # the others would wait for it at the rendezvous forever
                     q.terminate()
         time.sleep(0.05)
-    out = procs[0].stdout.read().decode()
+    rank0_out.seek(0)
+    out = rank0_out.read().decode()
     sys.stdout.write(out)
     sys.stdout.flush()
     if rc != 0:

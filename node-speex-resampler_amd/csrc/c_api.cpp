@@ -84,8 +84,8 @@ int speexhip_resampler_set_rate_frac(SpeexHipResamplerState *st, uint32_t ratio_
   return guarded([&] { return st ? st->batch->set_rate_frac(ratio_num, ratio_den, in_rate, out_rate) : SPEEXHIP_ERR_INVALID_ARG; });
 }
 void speexhip_resampler_get_ratio(SpeexHipResamplerState *st, uint32_t *ratio_num, uint32_t *ratio_den) {
-  *ratio_num = st->batch->filter().num;
-  *ratio_den = st->batch->filter().den;
+  *ratio_num = st->batch->rates().num;
+  *ratio_den = st->batch->rates().den;
 }
 int speexhip_resampler_set_quality(SpeexHipResamplerState *st, int quality) {
   return guarded([&] { return st ? st->batch->set_quality(quality) : SPEEXHIP_ERR_INVALID_ARG; });
@@ -252,8 +252,8 @@ uint64_t speexhip_release_cached_memory(void) {
 }
 
 void speexhip_resampler_get_rate(SpeexHipResamplerState *st, uint32_t *in_rate, uint32_t *out_rate) {
-  *in_rate = st->batch->filter().in_rate;
-  *out_rate = st->batch->filter().out_rate;
+  *in_rate = st->batch->rates().in_rate;
+  *out_rate = st->batch->rates().out_rate;
 }
 
 const char *speexhip_resampler_strerror(int err) {

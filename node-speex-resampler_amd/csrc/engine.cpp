@@ -59,12 +59,72 @@ int dev_alloc(int device, void **ptr, size_t bytes) {
   *ptr = nullptr;
   // test hook: a countdown -- the allocation that brings it to zero fails
   if (g_fail_allocs.load() > 0 && g_fail_allocs.fetch_sub(1) == 1) return SPEEXHIP_ERR_ALLOC_FAILED;
-  const hipError_t e = pool::device_get(device, ptr, bytes);
+  hipError_t e = pool::device_get(device, ptr, bytes);
+  if (e == hipErrorOutOfMemory) {
+    // (pool::device_get has already given the pool's idle buffers back and tried again.)  Table sets
+    // that no state references any more are reclaimable too: evict them, empty the pool, try once more.
+    (void)hipGetLastError();
+    if (release_cached_tables() != 0) {
+      (void)pool::release_idle();
+      e = pool::device_get(device, ptr, bytes);
+    }
+  }
   if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();
     return SPEEXHIP_ERR_ALLOC_FAILED;
   }
   if (hip_failed(e, "hipMalloc")) return SPEEXHIP_ERR_DEVICE;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+// The host-buffer calls are synchronous, and their staging buffers and the (shared) stream go on to the
+// next call or to another state: on EVERY exit nothing they enqueued may still be in flight.  The normal
+// path waits explicitly (and checks the result); this guard covers the early error returns.
+struct DrainOnExit {
+  hipStream_t *stream;  // (pointer: the stream is taken from the pool after the guard is set up)
+  bool armed = true;
+  explicit DrainOnExit(hipStream_t *s) : stream(s) {}
+  ~DrainOnExit() {
+    if (armed && *stream != nullptr) (void)hipStreamSynchronize(*stream);
+  }
+};
+
+// Control-plane copies (histories of a filter change, table uploads).  The runtime performs copies of
+// <= 16 KiB with a blit KERNEL, and a kernel of this stream is dispatched only once the kernels other
+// states have running let go of the CUs: 2 KB beside a 5 ms launch took 5 ms, 16 385 bytes 9 us
+// (tools/ubench_ctl.hip, profiles/r03_ubench_ctl.txt).  So every control copy is at least kCtlCopyMin bytes
+// -- the device buffers involved are allocated at least that big -- and runs on the copy engines from / to a
+// pinned image, beside whatever the device is doing.
+const size_t kCtlCopyMin = 20 * 1024;
+struct PinnedImage {
+  char *p = nullptr;
+  size_t bytes = 0;
+  ~PinnedImage() { pool::pinned_put(p); }
+  hipError_t get(size_t want) {
+    bytes = std::max(want, kCtlCopyMin);
+    return pool::pinned_get(reinterpret_cast<void **>(&p), bytes);
+  }
+};
+// host `src` (bytes) -> device `dst` (capacity >= max(bytes, kCtlCopyMin)); waits for the copy
+int ctl_upload(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+  PinnedImage img;
+  HIP_TRY(img.get(bytes));
+  std::memset(img.p, 0, img.bytes);
+  if (bytes != 0) std::memcpy(img.p, src, bytes);
+  HIP_TRY(hipMemcpyAsync(dst, img.p, img.bytes, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return SPEEXHIP_ERR_SUCCESS;
+}
+// device buffer `base` of `total` bytes (>= kCtlCopyMin): bytes [off, off+len) -> host `dst`; waits
+int ctl_download(void *dst, const char *base, size_t total, size_t off, size_t len, hipStream_t stream) {
+  if (len == 0) return SPEEXHIP_ERR_SUCCESS;
+  const size_t span = std::min(total, std::max(len, kCtlCopyMin));
+  const size_t first = std::min(off, total - span);
+  PinnedImage img;
+  HIP_TRY(img.get(span));
+  HIP_TRY(hipMemcpyAsync(img.p, base + first, span, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  std::memcpy(dst, img.p + (off - first), len);
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -100,13 +160,15 @@ Batch *Batch::create(uint32_t n_streams, uint32_t channels, uint32_t in_rate, ui
 Batch *Batch::create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_num, uint32_t ratio_den,
                           uint32_t in_rate, uint32_t out_rate, int quality, int *err) {
   int e = SPEEXHIP_ERR_SUCCESS;
-  Batch *b = nullptr;
+  // (owned until it is handed out: an exception below -- a bad_alloc in a position vector, in the design
+  //  or in the tap rows; c_api.cpp maps it to a code -- must not leak the batch and what it already took)
+  std::unique_ptr<Batch> b;
   // argument checks first, like the reference (resample.c:804-809)
   if (n_streams == 0 || channels == 0 || ratio_num == 0 || ratio_den == 0 || quality > 10 ||
       quality < 0) {
     e = SPEEXHIP_ERR_INVALID_ARG;
   } else {
-    b = new (std::nothrow) Batch();
+    b.reset(new (std::nothrow) Batch());
     if (b == nullptr) {
       e = SPEEXHIP_ERR_ALLOC_FAILED;
     } else {
@@ -114,14 +176,11 @@ Batch *Batch::create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_
       b->channels_ = channels;
       e = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality, &b->filter_, /*fill_table=*/false);
       if (e == SPEEXHIP_ERR_SUCCESS) e = b->setup();
-      if (e != SPEEXHIP_ERR_SUCCESS) {
-        delete b;
-        b = nullptr;
-      }
+      if (e != SPEEXHIP_ERR_SUCCESS) b.reset();
     }
   }
   if (err) *err = e;
-  return b;
+  return b.release();
 }
 
 int Batch::setup() {
@@ -151,8 +210,7 @@ int Batch::setup() {
     HIP_TRY(pool::device_get(device_, reinterpret_cast<void **>(&d_ring_), ring_bytes));
     for (int i = 0; i < kRing; i++) HIP_TRY(pool::event_get(device_, &ring_done_[i]));
   }
-  HIP_TRY(hipDeviceSynchronize());
-  return SPEEXHIP_ERR_SUCCESS;
+  return SPEEXHIP_ERR_SUCCESS;  // (install_filter waited for its own uploads)
 }
 
 DeviceTables::~DeviceTables() {
@@ -180,22 +238,29 @@ TablesCache &tables_cache() {
   static TablesCache *c = new TablesCache();  // never destroyed, like the pool
   return *c;
 }
-const size_t kCachedTables = 24;                           // entries kept beyond the ones in use
+const size_t kCachedTables = 24;                           // entries kept beyond the ones in use ...
+const size_t kCachedTableBytes = static_cast<size_t>(256) << 20;  // ... and their bytes (most recent first)
 const size_t kCacheableBytes = static_cast<size_t>(64) << 20;  // bigger table sets are built per state
 
 // Design (host, double precision), plan and upload the tables of filter `g` (geometry only: num,
 // den, quality, taps ...) for `channels` channels.
-int build_tables(int device, const FilterSpec &g, uint32_t channels, std::shared_ptr<const DeviceTables> *out) {
+// Uploads run on `stream` (the installing state's control stream) and are waited for before the tables
+// are published: never on the null stream, whose copies would wait for every blocking stream of the process.
+int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t stream,
+                 std::shared_ptr<const DeviceTables> *out) {
   FilterSpec f;
   int rc = design_filter_frac(g.num, g.den, g.in_rate, g.out_rate, g.quality, &f);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   auto t = std::make_shared<DeviceTables>();
   t->device = device;
   auto upload = [&](float **dst, const float *src, size_t count) -> int {
-    const int arc = dev_alloc(device, reinterpret_cast<void **>(dst), std::max<size_t>(count * sizeof(float), 16));
+    const int arc = dev_alloc(device, reinterpret_cast<void **>(dst), std::max(count * sizeof(float), kCtlCopyMin));
     if (arc != SPEEXHIP_ERR_SUCCESS) return arc;
-    if (count != 0) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
-    t->bytes += count * sizeof(float);
+    if (count != 0) {
+      const int urc = ctl_upload(*dst, src, count * sizeof(float), stream);
+      if (urc != SPEEXHIP_ERR_SUCCESS) return urc;
+    }
+    t->bytes += std::max(count * sizeof(float), kCtlCopyMin);
     return SPEEXHIP_ERR_SUCCESS;
   };
   rc = upload(&t->table, f.table.data(), f.table_len);
@@ -233,7 +298,8 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, std::shared
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-int acquire_tables(int device, const FilterSpec &g, uint32_t channels, std::shared_ptr<const DeviceTables> *out) {
+int acquire_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t stream,
+                   std::shared_ptr<const DeviceTables> *out) {
   static const bool enabled = [] {
     const char *e = std::getenv("SPEEXHIP_POOL_MB");
     return e == nullptr || std::atoi(e) != 0;
@@ -252,7 +318,7 @@ int acquire_tables(int device, const FilterSpec &g, uint32_t channels, std::shar
       }
   }
   std::shared_ptr<const DeviceTables> built;
-  const int rc = build_tables(device, g, channels, &built);
+  const int rc = build_tables(device, g, channels, stream, &built);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   if (cacheable && built->bytes <= kCacheableBytes) {
     std::lock_guard<std::mutex> lock(c.mu);
@@ -262,9 +328,10 @@ int acquire_tables(int device, const FilterSpec &g, uint32_t channels, std::shar
         return SPEEXHIP_ERR_SUCCESS;
       }
     c.lru.emplace_front(key, built);
-    size_t idle = 0;
+    size_t idle = 0, idle_bytes = 0;
     for (auto it = c.lru.begin(); it != c.lru.end();) {
-      if (it->second.use_count() == 1 && ++idle > kCachedTables)
+      if (it->second.use_count() == 1 &&
+          (++idle > kCachedTables || (idle_bytes += it->second->bytes) > kCachedTableBytes))
         it = c.lru.erase(it);  // nobody uses them: back to the pool
       else
         ++it;
@@ -296,8 +363,9 @@ size_t release_cached_tables() {
 // the batch holds: a failed allocation leaves the batch exactly as it was (the caller decides what
 // a failure means, resample.c:785-791).
 int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, uint32_t hist_frames_cap) {
+  if (own_stream_ == nullptr) HIP_TRY(pool::stream_get(device_, &own_stream_));
   std::shared_ptr<const DeviceTables> tables;
-  int rc = acquire_tables(device_, f, channels_, &tables);
+  int rc = acquire_tables(device_, f, channels_, own_stream_, &tables);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   struct Fresh {
     int device = 0;
@@ -309,17 +377,31 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   } n;
   n.device = device_;
   const size_t hist_elems = static_cast<size_t>(hist_frames_cap) * channels_;
-  const size_t hist_bytes = std::max<size_t>(hist_elems * n_streams_ * sizeof(float), 16);
+  const size_t hist_bytes = std::max(hist_elems * n_streams_ * sizeof(float), kCtlCopyMin);
   for (int i = 0; i < 2; i++) {
     rc = dev_alloc(device_, reinterpret_cast<void **>(&n.hist[i]), hist_bytes);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-    HIP_TRY(hipMemset(n.hist[i], 0, hist_bytes));
   }
-  if (!hist.empty())
-    HIP_TRY(hipMemcpy(n.hist[0], hist.data(), hist_elems * n_streams_ * sizeof(float), hipMemcpyHostToDevice));
-  // commit: nothing below can fail.  What the batch held goes back to the pool / the cache, so
-  // nothing in flight may still read it (hipFree used to wait by itself).
-  if (tables_ != nullptr) HIP_TRY(hipDeviceSynchronize());
+  {
+    // Both buffers start from one pinned image of the histories (zeros = silence) through the copy
+    // engines (see kCtlCopyMin; not hipMemsetAsync either: a fill kernel queues behind other states'
+    // kernels just the same -- set_quality beside another state's 6 ms launch took 6 ms).
+    PinnedImage image;
+    HIP_TRY(image.get(hist_bytes));
+    std::memset(image.p, 0, hist_bytes);
+    if (!hist.empty()) std::memcpy(image.p, hist.data(), hist_elems * n_streams_ * sizeof(float));
+    for (int i = 0; i < 2; i++)
+      HIP_TRY(hipMemcpyAsync(n.hist[i], image.p, hist_bytes, hipMemcpyHostToDevice, own_stream_));
+    HIP_TRY(hipStreamSynchronize(own_stream_));  // the new buffers are in place for a launch on any stream
+  }
+  hist_bytes_ = hist_bytes;
+  // What the batch held goes back to the pool / the cache below, so nothing in flight may still read it:
+  // wait for this batch's own last call -- not for the device: other states' launches keep running.
+  if (tables_ != nullptr) {
+    rc = quiesce();
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  }
+  // commit: nothing below can fail
   std::swap(d_hist_[0], n.hist[0]);
   std::swap(d_hist_[1], n.hist[1]);  // (~Fresh releases the old history buffers)
   tables_ = tables;
@@ -341,12 +423,24 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   return SPEEXHIP_ERR_SUCCESS;
 }
 
+// Wait for what THIS batch has enqueued.  Calls on one batch are ordered (a call on another stream
+// than the previous one waits for it on the device, run_plans), so the previous call's stream ends
+// with the batch's last piece of work; the control stream's own copies are waited for where they are
+// issued.  Contract for the device-pointer calls: the stream of a state's most recent call stays
+// valid until the state's next call, control call or destruction (include/speexhip_resampler.h).
+int Batch::quiesce() {
+  if (have_last_stream_) HIP_TRY(hipStreamSynchronize(last_stream_));
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
 int Batch::fetch_history(std::vector<float> *host) {
   ON_DEVICE();
-  HIP_TRY(hipDeviceSynchronize());  // every enqueued call has left its history
+  int rc = quiesce();  // every enqueued call of this batch has left its history
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   host->assign(hist_elems_ * n_streams_, 0.f);
   if (!host->empty())
-    HIP_TRY(hipMemcpy(host->data(), d_hist_[hist_cur_], host->size() * sizeof(float), hipMemcpyDeviceToHost));
+    return ctl_download(host->data(), reinterpret_cast<const char *>(d_hist_[hist_cur_]), hist_bytes_, 0,
+                        host->size() * sizeof(float), own_stream_);
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -429,22 +523,34 @@ int Batch::change_filter(const FilterSpec &next, int design_rc, const std::vecto
 int Batch::set_rate_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate) {
   if (ratio_num == 0 || ratio_den == 0) return SPEEXHIP_ERR_INVALID_ARG;
   // resample.c:1116-1117 (compares the given ratio with the REDUCED one it stores, as there)
-  if (filter_.in_rate == in_rate && filter_.out_rate == out_rate && filter_.num == ratio_num &&
-      filter_.den == ratio_den)
+  const RateView now = rates();
+  if (now.in_rate == in_rate && now.out_rate == out_rate && now.num == ratio_num && now.den == ratio_den)
     return SPEEXHIP_ERR_SUCCESS;
   FilterSpec next;
   const int design_rc =
       design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, filter_.quality, &next, /*fill_table=*/false);
   if (design_rc != SPEEXHIP_ERR_SUCCESS && design_rc != SPEEXHIP_ERR_ALLOC_FAILED) return design_rc;
   // phase numerators move to the new denominator (resample.c:1130-1139; next.num / next.den are set
-  // even when the design failed later on).  On overflow the reference returns with its state
-  // half-updated; here nothing has been touched yet.
+  // even when the design failed later on).  On overflow the reference returns RESAMPLER_ERR_OVERFLOW from
+  // the middle of that loop: it has ALREADY stored the new rates and the reduced ratio (:1119-1127), so
+  // get_rate / get_ratio report them and a repeat of the same call is a no-op (:1116), while its filter,
+  // its advances and the phase numerators of the failing and later channels are still the old ones --
+  // a state in which its own processing indexes the old sinc table with numerators on two denominators.
+  // Mirrored here: what a caller can SEE (rates, ratio, the no-op repeat).  Not mirrored: processing goes
+  // on with the old ratio and filter, consistently, until a later set_rate succeeds (named deviation,
+  // pinned by test_set_rate_overflow_leaves_the_reference_s_visible_state).
   std::vector<uint32_t> frac(pos_.size());
   for (size_t i = 0; i < pos_.size(); i++) {
     frac[i] = pos_[i].frac;
-    if (!scale_phase(&frac[i], next.den, filter_.den)) return SPEEXHIP_ERR_OVERFLOW;
+    if (!scale_phase(&frac[i], next.den, filter_.den)) {
+      shown_ = RateView{in_rate, out_rate, next.num, next.den};
+      shown_valid_ = true;
+      return SPEEXHIP_ERR_OVERFLOW;
+    }
   }
-  return change_filter(next, design_rc, &frac);
+  const int rc = change_filter(next, design_rc, &frac);
+  if (rc == SPEEXHIP_ERR_SUCCESS || rc == SPEEXHIP_ERR_ALLOC_FAILED) shown_valid_ = false;  // filter_ holds the truth again
+  return rc;
 }
 
 int Batch::set_quality(int quality) {
@@ -481,15 +587,21 @@ int Batch::reset_mem() {  // resample.c:1208-1220
     }
     for (uint32_t c = 0; c < channels_; c++) P(s, c) = StreamPos();
   }
-  if (!h.empty())
-    HIP_TRY(hipMemcpy(d_hist_[hist_cur_], h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (!h.empty()) {
+    // the whole buffer (>= kCtlCopyMin) from an image: what lies behind the histories is never read
+    std::vector<float> image(hist_bytes_ / sizeof(float), 0.f);
+    std::copy(h.begin(), h.end(), image.begin());
+    return ctl_upload(d_hist_[hist_cur_], image.data(), hist_bytes_, own_stream_);
+  }
   return SPEEXHIP_ERR_SUCCESS;
 }
 
 Batch::~Batch() {
   DeviceScope device_scope(device_);
-  // everything goes back to the pool (pool.h) for the next state, once nothing in flight uses it
-  (void)hipDeviceSynchronize();
+  // everything goes back to the pool (pool.h) for the next state, once nothing in flight uses it:
+  // this batch's calls are chained, so the tail of its last stream is all there is to wait for
+  // (a device-wide wait here stalled a server's every other state behind one state's garbage collection)
+  (void)quiesce();
   pool::event_put(device_, order_ev_);
   tables_.reset();  // shared (DeviceTables): the cache keeps them for the next state with this filter
   pool::device_put(device_, d_hist_[0]);
@@ -544,10 +656,12 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
 int Batch::history(uint32_t s, float *dst) {
   if (s >= n_streams_) return SPEEXHIP_ERR_INVALID_ARG;
   ON_DEVICE();
-  HIP_TRY(hipDeviceSynchronize());
+  int rc = quiesce();
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   const size_t n = static_cast<size_t>(filter_.taps - 1 + max_magic(s)) * channels_;
   if (n)
-    HIP_TRY(hipMemcpy(dst, d_hist_[hist_cur_] + s * hist_elems_, n * sizeof(float), hipMemcpyDeviceToHost));
+    return ctl_download(dst, reinterpret_cast<const char *>(d_hist_[hist_cur_]), hist_bytes_,
+                        s * hist_elems_ * sizeof(float), n * sizeof(float), own_stream_);
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -785,6 +899,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   const size_t in_bytes = static_cast<size_t>(frames) * channels_ * es;
   const size_t out_bytes = static_cast<size_t>(will_make) * channels_ * es;
   int rc = SPEEXHIP_ERR_SUCCESS;
+  DrainOnExit drain(&own_stream_);
   // Large buffers go straight from / to the caller's pageable memory: the HIP runtime stages such
   // copies itself and does it 2.2-2.5x faster than memcpy -> pinned -> DMA in one thread (2^20
   // stereo frames: 0.46 -> 0.21 ms per call, 8 channels 1.57 -> 0.63 ms).  Small ones go through
@@ -817,6 +932,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     rc = process_device(in != nullptr ? h_pin_in_ : nullptr, 0, in_len, h_pin_out_, 0, out_len, float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
     HIP_TRY(hipStreamSynchronize(own_stream_));
+    drain.armed = false;
     const size_t made = static_cast<size_t>(*out_len) * channels_ * es;
     if (made != 0) std::memcpy(out, h_pin_out_, made);
     return rc;
@@ -843,6 +959,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     const size_t bytes = static_cast<size_t>(most) * channels_ * es;
     if (bytes != 0) HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, bytes, hipMemcpyDeviceToHost, own_stream_));
     HIP_TRY(hipStreamSynchronize(own_stream_));
+    drain.armed = false;
     for (uint32_t c = 0; c < channels_; c++)
       for (uint32_t j = 0; j < plans[c].produced; j++)
         std::memcpy(static_cast<char *>(out) + (static_cast<size_t>(j) * channels_ + c) * es,
@@ -856,6 +973,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   if (made != 0)
     HIP_TRY(hipMemcpyAsync(direct_out ? out : h_pin_out_, d_stage_out_, made, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
+  drain.armed = false;
   if (made != 0 && !direct_out) std::memcpy(out, h_pin_out_, made);
   return rc;
 }
@@ -876,6 +994,7 @@ int Batch::process_channel_host(uint32_t c, const void *in, uint32_t *in_len, vo
   const CallPlan plan = plan_call(filter_.num, filter_.den, frames, *out_len, P(0, c), rules);
   if (frames != 0 && *out_len != 0) started_[0] = 1;
   const size_t line_in = static_cast<size_t>(frames) * es, line_out = static_cast<size_t>(plan.produced) * es;
+  DrainOnExit drain(&own_stream_);
   int rc = ensure_stage(line_in, line_out, line_in, line_out);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   if (in != nullptr && frames != 0) {
@@ -891,6 +1010,7 @@ int Batch::process_channel_host(uint32_t c, const void *in, uint32_t *in_len, vo
     HIP_TRY(hipMemcpyAsync(h_pin_out_, d_stage_out_, static_cast<size_t>(plan.produced) * es, hipMemcpyDeviceToHost,
                            own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
+  drain.armed = false;
   for (uint32_t j = 0; j < plan.produced; j++)
     std::memcpy(static_cast<char *>(out) + static_cast<size_t>(j) * out_stride_ * es,
                 h_pin_out_ + static_cast<size_t>(j) * es, es);
@@ -965,6 +1085,7 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
     if (frames > 0x7fffffffull || made > 0x7fffffffull) return SPEEXHIP_ERR_OVERFLOW;
   }
   const bool direct_out = made * fb >= kDirectCopyBytes;
+  DrainOnExit drain(&own_stream_);
   int rc = ensure_stage(frames * fb, made * fb, frames * fb, direct_out ? 0 : made * fb);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   size_t off = 0;
@@ -985,6 +1106,7 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
   if (made != 0)
     HIP_TRY(hipMemcpyAsync(direct_out ? out : h_pin_out_, d_stage_out_, made * fb, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
+  drain.armed = false;
   if (made != 0 && !direct_out) std::memcpy(out, h_pin_out_, made * fb);
   for (uint32_t i = 0; i < n_chunks; i++) {
     in_len[i] = plans[i].consumed;

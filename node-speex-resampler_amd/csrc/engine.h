@@ -101,6 +101,14 @@ class Batch {
   void info(uint32_t stream, SpeexHipInfo *out) const;
   int history(uint32_t stream, float *dst);
   const FilterSpec &filter() const { return filter_; }
+  // What speex_resampler_get_rate / get_ratio report: the filter's rates, except after a set_rate_frac that
+  // returned RESAMPLER_ERR_OVERFLOW -- the reference has stored the new ones by then (resample.c:1119-1127).
+  struct RateView {
+    uint32_t in_rate, out_rate, num, den;
+  };
+  RateView rates() const {
+    return shown_valid_ ? shown_ : RateView{filter_.in_rate, filter_.out_rate, filter_.num, filter_.den};
+  }
   uint32_t n_streams() const { return n_streams_; }
   uint32_t channels() const { return channels_; }
 
@@ -120,6 +128,7 @@ class Batch {
   int process_split(const void *d_in, uint32_t *in_len, void *d_out, uint32_t *out_len, bool float_io,
                     hipStream_t stream, std::vector<CallPlan> *plans_out);
   int fetch_history(std::vector<float> *host);
+  int quiesce();  // waits for this batch's own enqueued work (never for the whole device)
   uint32_t block_in() const { return line_ - (filter_.taps - 1); }
   int ensure_stage(size_t dev_in, size_t dev_out, size_t pin_in, size_t pin_out);
   int run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_frames, void *d_out,
@@ -134,6 +143,8 @@ class Batch {
   bool zero_mode_ = false;        // resampler_ptr == resampler_basic_zero (resample.c:785-791): the last
                                   // filter change failed; outputs are zeros until one succeeds
   uint32_t in_stride_ = 1, out_stride_ = 1;  // resample.c:842-843, 1170-1188 (per-channel entry points)
+  RateView shown_ = {0, 0, 0, 0};  // see rates()
+  bool shown_valid_ = false;
   ExactGeometry exact_geo_ch_;    // the exact kernel's geometry for one-channel launches
   std::vector<uint8_t> started_;  // per stream: a block has run (resample.c:886), so a filter
                                   // change must re-align the history instead of clearing it
@@ -144,6 +155,7 @@ class Batch {
   float *d_table_ = nullptr;
   float *d_hist_[2] = {nullptr, nullptr};  // float, like the reference's `mem`
   size_t hist_elems_ = 0;  // per stream: (taps-1 + room for pending frames)*channels
+  size_t hist_bytes_ = 0;  // allocation of each history buffer (>= the copy-engine minimum, engine.cpp kCtlCopyMin)
   int hist_cur_ = 0;
 
   ExactGeometry exact_geo_;

@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("SPEEXHIP_LIB_PATH") or os.path.join(PKG_DIR, "libspee
 
 MODE_FAST, MODE_EXACT = 0, 1
 KERNEL_NAMES = ("direct_single", "direct_double", "interpolate_single", "interpolate_double")
+# reference codes (deps/speex/speex_resampler.h:104-113) + 6 = HIP failure
+ERR_SUCCESS, ERR_ALLOC_FAILED, ERR_BAD_STATE, ERR_INVALID_ARG, ERR_PTR_OVERLAP, ERR_OVERFLOW = 0, 1, 2, 3, 4, 5
 ERR_DEVICE = 6
 
 EXPORTS = [

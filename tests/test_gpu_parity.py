@@ -1086,3 +1086,114 @@ def test_states_recycle_device_resources_through_the_pool():
     assert used == wu
     assert_close(got, want, "after release")
     r.close()
+
+
+def test_set_rate_overflow_leaves_the_reference_s_visible_state():
+    """speex_resampler_set_rate_frac returns RESAMPLER_ERR_OVERFLOW when a channel's phase numerator
+    cannot be carried to the new denominator (resample.c:1130-1134) -- AFTER it has stored the new rates
+    and the reduced ratio (:1119-1127).  What a caller can see afterwards is mirrored: get_rate / get_ratio
+    report the new values and a repeat of the same call is a no-op returning SUCCESS (:1116).  NAMED
+    DEVIATION: the reference then keeps processing with its old filter and advances against
+    the new denominator, phase numerators on two denominators (for a direct-kind filter it indexes its
+    sinc table out of bounds); this library keeps processing on the OLD ratio and filter, consistently,
+    until a later set_rate succeeds."""
+    ch, a, b = 2, 100003, 99991                      # coprime: den = 99991, numerators up to ~1e5
+    big = (99989, 100019, 99989, 100019)             # frac * 100019 >= 2^32 once frac > 42941
+    r = speexhip.Resampler(ch, a, b, 3, mode=speexhip.MODE_EXACT)
+    ref = orc.Oracle(ch, a, b, 3)
+    twin = orc.Oracle(ch, a, b, 3)                   # never sees the failing call
+    seed = 1
+    while True:
+        x = orc.lcg_pcm(777 * ch, seed).reshape(777, ch)
+        got, used = r.process(x, 5000)
+        want, wu = ref.process(x, 5000)
+        twin.process(x, 5000)
+        assert used == wu and np.array_equal(got, want) and r.position() == ref.position()
+        seed += 1
+        if ref.position()[1] * big[1] >= 1 << 32:
+            break
+        assert seed < 50
+    assert ref.set_rate_frac(*big) == speexhip.ERR_OVERFLOW
+    assert r.set_rate_frac(*big) == speexhip.ERR_OVERFLOW
+    assert r.rate() == ref.rate() == (big[2], big[3])
+    assert r.ratio() == ref.ratio() == (big[0], big[1])
+    assert r.set_rate_frac(*big) == ref.set_rate_frac(*big) == 0          # resample.c:1116: nothing to do
+    # the deviation: the stream goes on exactly as if the failing call had never been made
+    x = orc.lcg_pcm(3000 * ch, 99).reshape(3000, ch)
+    got, used = r.process(x, 5000)
+    want, wu = twin.process(x, 5000)
+    assert used == wu and np.array_equal(got, want) and r.position() == twin.position()
+    # a change that succeeds puts rates, ratio and filter back in step
+    assert r.set_rate(44100, 48000) == 0
+    assert r.rate() == (44100, 48000) and r.ratio() == (147, 160)
+    r.close()
+
+
+def test_control_calls_and_destruction_do_not_wait_for_other_states():
+    """A server holds one state per connection (src/test.ts:27 makes one per file).  A state's set_quality,
+    reset_mem, get-history and destruction wait for THAT state's own last call only -- never for the device:
+    another state's launch of several milliseconds stays in flight while they run (round 2 used
+    hipDeviceSynchronize in all four), and both states' results are what they would have been alone."""
+    import time
+    import torch
+    ch, i, o, q, frames, S = 2, 44100, 48000, 7, 1 << 20, 96
+    x = orc.lcg_pcm(frames * ch, 4242).reshape(frames, ch)
+    d_in = torch.from_numpy(x).cuda()
+    cap = int(frames * o / i) + 64
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    big = speexhip.Batch(S, ch, i, o, q, mode=speexhip.MODE_EXACT)   # ~60 us per stream in EXACT mode: >= 5 ms per call
+    side = torch.cuda.Stream()
+    # warm: tables of every filter used below exist in the cache, pool buffers exist
+    for qq in (q, 5, 3):
+        w = speexhip.Resampler(ch, i, o, qq)
+        w.process(x[:5000], 8000)
+        w.close()
+    small = speexhip.Resampler(ch, i, o, q)
+    ref = orc.Oracle(ch, i, o, q)
+    got, used = small.process(x[:20000], 30000)
+    want, wu = ref.process(x[:20000], 30000)
+    assert used == wu
+    assert_close(got, want, "before")
+    doomed = speexhip.Resampler(ch, i, o, 3)
+    doomed.process(x[:5000], 8000)
+    torch.cuda.synchronize()
+    timings = {}
+    for attempt in range(3):
+        used_b, made_b = big.process_device(d_in.data_ptr(), 0, [frames] * S, d_out.data_ptr(), cap * ch, [cap] * S,
+                                            side.cuda_stream)
+        t0 = time.perf_counter()
+        assert small.set_quality(5) == 0
+        t1 = time.perf_counter()
+        h = small.history()
+        t2 = time.perf_counter()
+        if doomed is not None:
+            doomed.close()
+            doomed = None
+        t3 = time.perf_counter()
+        in_flight = not side.query()
+        side.synchronize()
+        t4 = time.perf_counter()
+        assert ref.set_quality(5) == 0
+        assert np.array_equal(h[:, 0], ref.history(0))
+        timings[attempt] = dict(set_quality_us=(t1 - t0) * 1e6, history_us=(t2 - t1) * 1e6, close_us=(t3 - t2) * 1e6,
+                                other_launch_ms=(t4 - t0) * 1e3, still_in_flight=in_flight)
+        assert small.set_quality(q) == 0 and ref.set_quality(q) == 0
+        if attempt == 0:
+            torch.cuda.synchronize()
+            out = d_out.cpu().numpy()
+            want_b, wu_b = orc.Oracle(ch, i, o, q).process(x, cap)
+            for s in (0, S // 2, S - 1):
+                assert (used_b[s], made_b[s]) == (wu_b, want_b.shape[0])
+                assert np.array_equal(out[s, : made_b[s]], want_b), s
+    print("control calls beside another state's launch:", timings)
+    best = min(timings.values(), key=lambda t: t["set_quality_us"])
+    assert all(t["still_in_flight"] for t in timings.values()), timings   # the other launch outlived all three calls
+    assert best["other_launch_ms"] >= 3.0, timings
+    # returned long before the other state's launch ended (a device-wide wait would have taken its whole length)
+    assert best["set_quality_us"] + best["history_us"] + best["close_us"] < 0.25 * best["other_launch_ms"] * 1e3, timings
+    got, used = small.process(x[20000:60000], 60000)
+    want, wu = ref.process(x[20000:60000], 60000)
+    assert used == wu
+    assert_close(got, want, "after")
+    small.close()
+    big.close()
