@@ -69,6 +69,28 @@ __device__ __forceinline__ void fma_tap(f32x2 &acc, const f32x2 &tap_pair, const
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
 }
 
+#include "fir_loop_asm.inc"
+
+// Wave priority of the FIR loop (and of whatever follows it).  The two workgroups that share a CU are
+// dispatched together, do the same work and therefore finish together: left alone they stay in lockstep
+// for the whole launch -- both staging, then both in their FIR loops, then both storing -- so the CU's
+// vector ALUs idle through every staging / store / turnover phase (tools/probe_slots.hip shows the pairs
+// starting within 0.2 us of each other generation after generation; and a workgroup that falls behind
+// catches up, because it runs alone once its partner has left: lockstep is the stable state).  With
+// different priorities the pair cannot stay together: the workgroup in the CU's second slot (HW_ID.TG_ID,
+// the slot the dispatcher gave it) issues ahead of the first one, finishes early, and from then on one
+// of the two is in its FIR loop while the other stages or stores.
+__device__ __forceinline__ void set_fir_priority(const PeriodParams &p) {
+  if (p.prio & 4u) {
+    const uint32_t tg_id = (__builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11)));  // HW_REG_HW_ID bits [19:16]
+    if (tg_id & 1u) {
+      __builtin_amdgcn_s_setprio(1);
+      return;
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
 // What a lane needs to know about its place in a tile.
 struct LaneCtx {
   uint32_t C;       // channels per frame
@@ -107,13 +129,38 @@ __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshi
 }
 
 // acc[i] += group g's taps times the lane's samples, over the iterations the host tabulated for g.
-template <int R, int CT, bool PADDED>
+// CF: floats per frame when that is a compile-time constant (mono, stereo, 4 / 6 / 8 channels), else 0.
+template <int R, int CT, bool PADDED, int CF = 0>
 __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
                                           const LaneCtx &c, uint32_t g, bool skip_all, f32x2 (&acc)[R]) {
   const uint32_t C = c.C;
   const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
   // (delta_g < num: no padding boundary before the group's first sample)
   const float *xp = xs + c.xlane + delta_g * C;
+#ifndef SPEEXHIP_CXX_FIR_LOOP
+  // The loop in ISA (csrc/gen_fir_loop.py) for the layouts it is generated for; the C++ loop below is
+  // its reference -- same taps, same samples, same order per accumulator -- and runs the other layouts
+  // (odd channel counts >= 3, more than 8 channels).  -DSPEEXHIP_CXX_FIR_LOOP builds the A/B library.
+  using Isa = FirLoopAsm<R, CT, CF, PADDED, false>;
+  if constexpr (CF != 0 && Isa::available) {
+    constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
+    static_assert(kStepsPerTrip * R == 2 * bank_taps(R), "the ISA loop and the tap rows disagree on the trip");
+    const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+    const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u;
+    const float *rows_g = rows + static_cast<size_t>(g) * p.l4 * (2 * bank_taps(R));
+    const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xp));
+    // (wave-uniform values all of them, but hipcc keeps some of them in VGPRs -- the group index is a loop
+    //  counter it moved to the vector side -- and will not copy them back by itself)
+    auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+    const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
+    const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
+                                                          static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
+    Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 4u : 0u, sgpr(head), sgpr((trips >> 8) - head - tail),
+             sgpr(tail), sgpr(PADDED ? p.delta[p.groups + g] : 0u), sgpr(p.wrap_step),
+             sgpr((kStepsPerTrip * CF + p.pad) * 4u));
+    return;
+  }
+#endif
   // padded layout: the host shifted this group's start by <= 3 frames so that the one padding
   // boundaries its window crosses fall between iterations (the first before iteration wrap_it)
   // (counted DOWN to the next boundary, like the loop itself: with 80 SGPRs there is no register to
@@ -362,7 +409,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 #ifdef SPEEXHIP_STAMPS
     const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime(), fir_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    fir_group<R, CT, PADDED>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+    fir_group<R, CT, PADDED, ONE_GROUP ? CT : 2 * CGF>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
 #ifdef SPEEXHIP_STAMPS
     {
       asm volatile("" ::"v"(acc[0]));
@@ -379,7 +426,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
     if ((p.skip & 8u) || !c.live) continue;
     if (p.prio & 2u) __builtin_amdgcn_s_setprio(2);
     store_group<R, CT, ONE_GROUP, T>(p, d, c, g, acc);
-    if (p.prio & 2u) __builtin_amdgcn_s_setprio(0);
+    if (p.prio & 2u) set_fir_priority(p);
     STAMP(6);
   }
 }
@@ -411,7 +458,7 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
   f32x2 acc[R];
 #pragma unroll
   for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
-  if (valid) fir_group<R, 1, PADDED>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+  if (valid) fir_group<R, 1, PADDED, 1>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
   __syncthreads();  // every wave is done with the window
   if (p.skip & 8u) return;
 
@@ -530,7 +577,7 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
   }
   STAMP(3);
   __syncthreads();
-  if (p.prio & 1u) __builtin_amdgcn_s_setprio(0);
+  if (p.prio & 7u) set_fir_priority(p);
   STAMP(4);
   if (p.skip & 128u) return;  // diagnostics: prologue + staging only
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -875,7 +922,8 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   //  streams and slower beyond (8: 219 vs 213 us; 4 shares always slower), 64 streams 404 -> 407: a share
   //  stages the whole window again and leaves its CU with half the FIR waves; removed.)
   p.threads = 0;  // set below
-  static const int env_prio = std::getenv("SPEEXHIP_PRIO") ? std::atoi(std::getenv("SPEEXHIP_PRIO")) : 3;
+  // bit 0: prologue + staging raised, bit 1: stores raised, bit 2: the two workgroups of a CU at different FIR priorities
+  static const int env_prio = std::getenv("SPEEXHIP_PRIO") ? std::atoi(std::getenv("SPEEXHIP_PRIO")) : 7;
   p.prio = static_cast<uint32_t>(env_prio);
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;

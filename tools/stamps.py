@@ -92,6 +92,28 @@ for launch in range(a.launches):
         # slot turnover: the n-th end is followed by the (n+2)-th start when two slots alternate
         if len(starts) > 2:
             gaps.extend(list(starts[2:] - ends[: len(starts) - 2]))
+    # how the workgroups that share a CU stand to each other: time with 0 / 1 / 2 of them inside their FIR loops
+    # (between stamps 4 and 5), and the start offset of every workgroup to the one resident beside it
+    in_fir = np.zeros(3)
+    offs = []
+    for k in keys:
+        sel = rel[cu_key == k]
+        ev = sorted([(t, +1) for t in sel[:, 4]] + [(t, -1) for t in sel[:, 5]])
+        cur, last_t = 0, sel[:, 0].min()
+        for t, dlt in ev:
+            in_fir[min(cur, 2)] += t - last_t
+            cur += dlt
+            last_t = t
+        in_fir[0] += sel[:, 6].max() - last_t
+        for row in sel:
+            mates = sel[(sel[:, 0] < row[6]) & (sel[:, 6] > row[0]) & (sel[:, 0] != row[0])]
+            if len(mates):
+                offs.append(np.abs(mates[:, 0] - row[0]).min())
+    in_fir /= in_fir.sum()
+    o = np.array(offs)
+    print("  per CU, share of the launch with 0 / 1 / 2 workgroups inside their FIR loops: %.3f / %.3f / %.3f" % tuple(in_fir))
+    print("  start offset between a workgroup and the nearest one resident beside it: median %.2f p10 %.2f p90 %.2f us" % (
+        np.median(o), np.percentile(o, 10), np.percentile(o, 90)))
     print("  %d CUs seen; workgroups of this launch resident per CU (time average): median %.2f min %.2f max %.2f" % (
         len(keys), np.median(conc), np.min(conc), np.max(conc)))
     if gaps:
