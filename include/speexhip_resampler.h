@@ -315,7 +315,9 @@ SPEEXHIP_API int speexhip_resampler_get_channel_position(SpeexHipResamplerState 
  * period kernel: out[1] = phases per wave (10 / 5), out[2] = periods per tile, out[3] = row length (steps),
  * out[4] = LDS window bytes, out[5] = bank padding (floats per period), out[6] = 1 if a second plan with 5
  * phases per wave serves launches of one generation; slide kernel: out[1] = periods per lane, out[3] = row
- * length (steps), out[4] = LDS bytes of a two-wave workgroup, out[7] = tap steps per iteration. */
+ * length (steps), out[4] = LDS bytes of a two-wave workgroup, out[7] = tap steps per iteration; period kernel:
+ * out[7] = periods per tile of the int16-window plan that int16 calls take instead (0 = none: the float window
+ * already holds a full tile, or the layout has no such plan). */
 SPEEXHIP_API int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
                                      uint32_t out[8]);
 

@@ -234,6 +234,8 @@ int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uin
         const speexhip::PeriodPlan fine = speexhip::plan_period_r(f, channels, speexhip::lds_budget(), 5);
         out[6] = fine.usable && fine.lane_periods == t.lane_periods;
       }
+      const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, speexhip::lds_budget(), t);
+      out[7] = w16.usable ? w16.lane_periods : 0;
     } else if (sl.usable) {
       out[0] = 3;
       out[1] = sl.p;

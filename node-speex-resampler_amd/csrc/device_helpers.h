@@ -240,6 +240,125 @@ __device__ __forceinline__ void window_commit(float *xs, const StreamDesc &d, co
     xs[g.pad ? padded_pos(g, j) : j] = rel_sample<T>(d, g.q_base + j, g.hist_elems, g.in_elems);
 }
 
+// ---- the same for a "plain" window: no bank padding, every 16-byte group wholly inside the call's input
+// (no history in front, no silence behind: all tiles of a call but its first and last few), at most UNR
+// groups per lane.  Round 3: the general path above spends ~20 vector instructions per group on 64-bit
+// addresses, clamps and the three-way split of the image; here the loads are buffer loads (one 32-bit lane
+// offset for all of them, the group index of each load a scalar offset; a group past the end reads as zeros
+// by the descriptor's bounds check, so nothing is clamped) and the LDS address is one add per group:
+// 10 vector instructions per group, 8 of them the conversions.  A vector instruction costs a wave the issue
+// slot of a v_pk_fma_f32 whatever it does, and staging was 100 of the ~260 that a wave spends outside its
+// FIR loop (1313 inside) on BASELINE configs[1].
+template <int UNR, typename T>
+__device__ __forceinline__ bool window_is_plain(const WindowGeom &g) {
+  constexpr uint32_t GS = PerLoad<T>::value;
+  return g.pad == 0 && g.head_end == 0 && g.tail_begin == g.total && g.n_wide * GS == g.total &&
+         g.n_wide <= static_cast<uint32_t>(UNR) * g.nthr;
+}
+
+template <int UNR, typename T>
+__device__ __forceinline__ void window_fetch_plain(const WindowGeom &g, u32x4 (&w)[UNR]) {
+  // raw buffer descriptor over the window's groups: base, stride 0, bytes, gfx9 data format word
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(g.src), 0, static_cast<int>(g.n_wide * 16u), 0x00020000);
+  const int lane_off = static_cast<int>(threadIdx.x * 16u);
+#pragma unroll
+  for (int u = 0; u < UNR; u++)
+    w[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, static_cast<int>(u * g.nthr * 16u), 0);
+}
+
+template <int UNR, typename T>
+__device__ __forceinline__ void window_commit_plain(float *xs, const WindowGeom &g, const u32x4 (&w)[UNR]) {
+  constexpr int GS = PerLoad<T>::value;
+  float *lane_xs = xs + threadIdx.x * GS;
+#pragma unroll
+  for (int u = 0; u < UNR; u++) {
+    const uint32_t first = u * g.nthr;  // scalar: group index of lane 0's load
+    if (first >= g.n_wide || threadIdx.x >= g.n_wide - first) continue;
+    float f[GS];
+    unpack_group(w[u], f, T());
+    float *dst = lane_xs + first * GS;
+#pragma unroll
+    for (int k = 0; k < GS; k += 4) *reinterpret_cast<float4 *>(dst + k) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
+  }
+}
+
+// ---- an int16 LDS window (round 3, "W16"): the image holds the samples as they come from HBM, two bytes
+// each, and the FIR loop converts behind its LDS reads (csrc/gen_fir_loop.py).  Half the bytes per period:
+// the wide windows of down-sampling ratios (num = 320, 441, 640 input frames per period) fit twice the
+// periods per tile, i.e. twice the lanes of every wave.  Only for int16 calls on a stream whose history
+// holds integer-valued samples (the engine knows: no float call so far); same geometry (WindowGeom counts
+// ELEMENTS, whatever their size), same three-way split, same padding rule as the float image above.
+__device__ __forceinline__ int16_t pcm_of(float v) { return static_cast<int16_t>(static_cast<int>(v)); }
+
+__device__ __forceinline__ void commit_group16(int16_t *xs, const WindowGeom &g, uint32_t j, const u32x4 &w) {
+  uint32_t a = j;
+  bool contiguous = true;
+  if (g.pad != 0) {
+    a = padded_pos(g, j);
+    contiguous = padded_pos(g, j + 7) - a == 7;
+  }
+  if (contiguous && (a & 7u) == 0) {
+    *reinterpret_cast<u32x4 *>(xs + a) = w;
+  } else if (contiguous && (a & 3u) == 0) {
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2_t *>(xs + a) = u32x2_t{w.x, w.y};
+    *reinterpret_cast<u32x2_t *>(xs + a + 4) = u32x2_t{w.z, w.w};
+  } else if (contiguous && (a & 1u) == 0) {
+    uint32_t *o = reinterpret_cast<uint32_t *>(xs + a);
+    o[0] = w.x;
+    o[1] = w.y;
+    o[2] = w.z;
+    o[3] = w.w;
+  } else {
+    const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      xs[padded_pos(g, j + k)] = static_cast<int16_t>((k & 1) ? v[k >> 1] >> 16 : v[k >> 1] & 0xffffu);
+  }
+}
+
+template <int UNR>
+__device__ __forceinline__ void window_commit16(int16_t *xs, const StreamDesc &d, const WindowGeom &g,
+                                                const u32x4 (&w)[UNR]) {
+#pragma unroll
+  for (int u = 0; u < UNR; u++) {
+    const uint32_t unit = u * g.nthr + threadIdx.x;
+    if (unit < g.n_wide) commit_group16(xs, g, 8 * (g.u_begin + unit), w[u]);
+  }
+  for (uint32_t base = UNR * g.nthr; base < g.n_wide; base += UNR * g.nthr) {
+    u32x4 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const uint32_t unit = base + u * g.nthr + threadIdx.x;
+      v[u] = load_group<int16_t>(g, min(unit, g.n_wide - 1));
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; u++) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const uint32_t unit = base + u * g.nthr + threadIdx.x;
+      if (unit < g.n_wide) commit_group16(xs, g, 8 * (g.u_begin + unit), v[u]);
+    }
+  }
+  for (uint32_t j = threadIdx.x; j < g.head_end; j += g.nthr)
+    xs[g.pad ? padded_pos(g, j) : j] = pcm_of(rel_sample<int16_t>(d, g.q_base + j, g.hist_elems, g.in_elems));
+  for (uint32_t j = g.tail_begin + threadIdx.x; j < g.total; j += g.nthr)
+    xs[g.pad ? padded_pos(g, j) : j] = pcm_of(rel_sample<int16_t>(d, g.q_base + j, g.hist_elems, g.in_elems));
+}
+
+// plain window (window_is_plain<UNR, int16_t>): the 16 bytes go from the load straight into the image
+template <int UNR>
+__device__ __forceinline__ void window_commit_plain16(int16_t *xs, const WindowGeom &g, const u32x4 (&w)[UNR]) {
+  int16_t *lane_xs = xs + threadIdx.x * 8;
+#pragma unroll
+  for (int u = 0; u < UNR; u++) {
+    const uint32_t first = u * g.nthr;
+    if (first >= g.n_wide || threadIdx.x >= g.n_wide - first) continue;
+    *reinterpret_cast<u32x4 *>(lane_xs + first * 8) = w[u];
+  }
+}
+
 // Two floats -> packed s16 pair {lo, hi} with the reference's rounding: floor(x + .5), then
 // saturation to [-32768, 32767] (equivalent to arch.h:208-209: the < -32767.5 / > 32766.5
 // branches are the clamp of floor(x + .5)).  v_cvt_rpi_i32_f32 IS floor(x + .5) ("round to plus

@@ -218,6 +218,7 @@ DeviceTables::~DeviceTables() {
   pool::device_put(device, table);
   pool::device_put(device, period_rows);
   pool::device_put(device, fine_rows);
+  pool::device_put(device, w16_rows);
   pool::device_put(device, slide_rows);
 }
 
@@ -284,6 +285,13 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
       rc = upload(&t->fine_rows, rows.data(), rows.size());
       if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     }
+  }
+  t->w16 = plan_period_w16(f, channels, kLdsBudget, t->period);
+  if (t->w16.usable) {
+    std::vector<float> rows;
+    build_period_rows(f, t->w16, &rows);
+    rc = upload(&t->w16_rows, rows.data(), rows.size());
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
   t->slide = plan_slide(f, channels);
   if (t->slide.usable && !t->period.usable) {
@@ -408,6 +416,7 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   d_table_ = tables->table;
   d_period_rows_ = tables->period_rows;
   d_period_fine_rows_ = tables->fine_rows;
+  d_period_w16_rows_ = tables->w16_rows;
   d_slide_rows_ = tables->slide_rows;
   const std::vector<float> no_table;
   filter_ = f;
@@ -419,6 +428,7 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   exact_geo_ch_ = tables->geo_ch;
   period_ = tables->period;
   period_fine_ = tables->fine;
+  period_w16_ = tables->w16;
   slide_ = tables->slide;
   return SPEEXHIP_ERR_SUCCESS;
 }
@@ -703,6 +713,7 @@ int Batch::process_device(const void *d_in, uint64_t in_stride, uint32_t *in_len
 int Batch::run_channel(uint32_t c, const void *d_in, uint32_t in_stride, uint32_t in_frames, void *d_out,
                        uint32_t out_stride, const CallPlan &plan, bool float_io, hipStream_t stream) {
   const uint32_t walked = plan.magic_used + plan.consumed;
+  if (float_io) float_seen_ = true;
   if (plan.produced == 0 && walked == 0) return SPEEXHIP_ERR_SUCCESS;
   if (have_last_stream_ && stream != last_stream_) {
     if (order_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &order_ev_));
@@ -811,6 +822,7 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
     any_work = any_work || plan.produced != 0 || d.consumed != 0;
   }
 
+  if (float_io) float_seen_ = true;  // (from here on the histories may hold non-integer samples)
   if (any_work) {
     // Calls on one batch are ordered (each reads the history the previous one left and the
     // ping-pong buffers alternate): a call enqueued on another stream than the previous one
@@ -836,7 +848,11 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       geo.outs_per_block = 256;
       e = launch_exact(filter_, geo, d_table_, channels_, d_descs, packed ? &pack : nullptr, n_streams_, max_out,
                        float_io, stream, nullptr, true);
-    } else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)
+    } else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable && !float_io && !float_seen_ && period_w16_.usable)
+      // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values)
+      e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, d_descs,
+                        packed ? &pack : nullptr, n_streams_, false, stream);
+    else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)
       e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs,
                         d_descs, packed ? &pack : nullptr, n_streams_, float_io, stream);
     else if (mode_ == SPEEXHIP_MODE_FAST && slide_.usable)

@@ -32,9 +32,10 @@ struct DeviceTables {
   float *table = nullptr;        // reference layout (exact kernel)
   float *period_rows = nullptr;  // kernels_period.hip, R = 10
   float *fine_rows = nullptr;    // ... R = 5 (launches of one generation)
+  float *w16_rows = nullptr;     // ... with an int16 LDS window (wide windows; int16 calls)
   float *slide_rows = nullptr;   // kernels_slide.hip
   ExactGeometry geo, geo_ch;     // exact kernel, all channels / one channel per launch
-  PeriodPlan period, fine;
+  PeriodPlan period, fine, w16;
   SlidePlan slide;
   size_t bytes = 0;
   DeviceTables() = default;
@@ -163,6 +164,9 @@ class Batch {
   float *d_period_rows_ = nullptr;
   PeriodPlan period_fine_;  // the same filter with 5 phases per wave: single-generation launches
   float *d_period_fine_rows_ = nullptr;
+  PeriodPlan period_w16_;   // the same filter over an int16 LDS window (usable only where it pays)
+  float *d_period_w16_rows_ = nullptr;
+  bool float_seen_ = false;  // a float call has put samples into the histories that an int16 window cannot hold
   SlidePlan slide_;        // small-ratio fast path (kernels_slide.hip); neither usable -> exact
   float *d_slide_rows_ = nullptr;
 

@@ -65,11 +65,16 @@ struct PeriodPlan {         // per filter, fixed at init
   bool usable = false;
   uint32_t r = 10, ct = 1, cgroups = 0, groups = 0;
   uint32_t row_len = 0, l4 = 0, tail_frames = 0, lane_periods = 0;
-  uint32_t pad = 0;          // LDS bank padding (floats after every period), 0 = none needed
+  uint32_t pad = 0;          // LDS bank padding (elements after every period), 0 = none needed
+  bool w16 = false;          // the LDS window holds int16 samples (2-byte elements) instead of floats: int16
+                             // calls only; twice the periods per tile where the float window limits them
   size_t rows_floats = 0, window_bytes = 0;
 };
-PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget);
-PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r);
+PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16 = false);
+PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16 = false);
+// The int16-window plan of a filter whose float plan is `t`, .usable only where it pays: at least 5/4 of the
+// periods per tile (the loop converts every sample it reads: ~20 % more vector instructions per tile).
+PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_budget, const PeriodPlan &t);
 void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<float> *rows);
 // `fine`: the same filter planned with r = 5 (or null); single-generation launches take it
 hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, const PeriodPlan *fine,

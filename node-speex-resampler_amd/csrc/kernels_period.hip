@@ -71,15 +71,18 @@ __device__ __forceinline__ void fma_tap(f32x2 &acc, const f32x2 &tap_pair, const
 
 #include "fir_loop_asm.inc"
 
-// Wave priority of the FIR loop (and of whatever follows it).  The two workgroups that share a CU are
-// dispatched together, do the same work and therefore finish together: left alone they stay in lockstep
-// for the whole launch -- both staging, then both in their FIR loops, then both storing -- so the CU's
-// vector ALUs idle through every staging / store / turnover phase (tools/probe_slots.hip shows the pairs
-// starting within 0.2 us of each other generation after generation; and a workgroup that falls behind
-// catches up, because it runs alone once its partner has left: lockstep is the stable state).  With
-// different priorities the pair cannot stay together: the workgroup in the CU's second slot (HW_ID.TG_ID,
-// the slot the dispatcher gave it) issues ahead of the first one, finishes early, and from then on one
-// of the two is in its FIR loop while the other stages or stores.
+// Wave priority of the FIR loop (and of whatever follows it): 0.  Bit 2 of p.prio (diagnostics, SPEEXHIP_PRIO=7)
+// gives the workgroup in the CU's second slot (HW_ID.TG_ID) priority 1 instead: an experiment of round 3.
+// Two workgroups that share a CU are dispatched together and do the same work; in a kernel of nothing but
+// equal phases they stay in lockstep generation after generation (tools/probe_slots.hip: the pairs start
+// within 0.2 us of each other every time), and a model of that -- both staging, both computing, both
+// storing -- predicted exactly the launch time measured here.  The stamps say otherwise for THIS kernel
+// (tools/stamps.py, profiles/r03_stamps_cfg2_s32.txt): the pairs run 11.5 us apart (median) of a 26 us
+// cycle, a CU has two workgroups in their FIR loops 60 % of the time, one 37.5 %, none 2.2 %; what the lone
+// one loses is issue efficiency (4 waves per SIMD: 5.1 cycles per v_pk_fma_f32 against 4.5 at 8), not time
+// behind a partner.  Unequal priorities made every launch SLOWER: cfg2 32 streams 200 -> 215 us, mono
+// 128 -> 145, 8 channels 569 -> 602 (the low-priority workgroup starves and its slot turns over late:
+// median turnover 1.4 -> 2.2 us, p90 2.2 -> 11.8).  Not the default.
 __device__ __forceinline__ void set_fir_priority(const PeriodParams &p) {
   if (p.prio & 4u) {
     const uint32_t tg_id = (__builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11)));  // HW_REG_HW_ID bits [19:16]
@@ -130,13 +133,31 @@ __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshi
 
 // acc[i] += group g's taps times the lane's samples, over the iterations the host tabulated for g.
 // CF: floats per frame when that is a compile-time constant (mono, stereo, 4 / 6 / 8 channels), else 0.
-template <int R, int CT, bool PADDED, int CF = 0>
+// W16: the LDS window holds int16 samples (device_helpers.h); ISA loop only.
+template <int R, int CT, bool PADDED, int CF = 0, bool W16 = false>
 __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
                                           const LaneCtx &c, uint32_t g, bool skip_all, f32x2 (&acc)[R]) {
   const uint32_t C = c.C;
   const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
   // (delta_g < num: no padding boundary before the group's first sample)
   const float *xp = xs + c.xlane + delta_g * C;
+  if constexpr (W16) {
+    using Isa = FirLoopAsm<R, CT, CF, PADDED, true>;
+    static_assert(CF != 0 && Isa::available, "an int16 window needs the ISA loop of its layout");
+    constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
+    const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];
+    const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u;
+    const float *rows_g = rows + static_cast<size_t>(g) * p.l4 * (2 * bank_taps(R));
+    const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) + (c.xlane + delta_g * C) * 2u;
+    auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+    const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
+    const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
+                                                          static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
+    Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 2u : 0u, sgpr(head), sgpr((trips >> 8) - head - tail),
+             sgpr(tail), sgpr(PADDED ? p.delta[p.groups + g] : 0u), sgpr(p.wrap_step),
+             sgpr((kStepsPerTrip * CF + p.pad) * 2u));
+    return;
+  }
 #ifndef SPEEXHIP_CXX_FIR_LOOP
   // The loop in ISA (csrc/gen_fir_loop.py) for the layouts it is generated for; the C++ loop below is
   // its reference -- same taps, same samples, same order per accumulator -- and runs the other layouts
@@ -395,7 +416,7 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
 
 // FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
 // followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
 __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__restrict__ rows,
                                          const StreamDesc &d, const float *xs, uint32_t xshift,
                                          uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
@@ -409,7 +430,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 #ifdef SPEEXHIP_STAMPS
     const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime(), fir_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    fir_group<R, CT, PADDED, ONE_GROUP ? CT : 2 * CGF>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+    fir_group<R, CT, PADDED, ONE_GROUP ? CT : 2 * CGF, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
 #ifdef SPEEXHIP_STAMPS
     {
       asm volatile("" ::"v"(acc[0]));
@@ -447,7 +468,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 //  pieces per lane there, image [period][frame][pair], 16-byte row stores: 4 ch 44.1k->48k 431 -> 421 us,
 //  but 8 ch 48k->44.1k 621 -> 644 us and 6 ch 670 -> 735 us at 32 streams: the two barriers and the
 //  serial copy-out cost more than the per-lane stores they replace; removed.)
-template <int R, bool PADDED>
+template <int R, bool PADDED, bool W16 = false>
 __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const float *__restrict__ rows,
                                                    const StreamDesc &d, float *xs, uint32_t xshift, uint32_t m_lo,
                                                    uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit) {
@@ -458,7 +479,7 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
   f32x2 acc[R];
 #pragma unroll
   for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
-  if (valid) fir_group<R, 1, PADDED, 1>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+  if (valid) fir_group<R, 1, PADDED, 1, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
   __syncthreads();  // every wave is done with the window
   if (p.skip & 8u) return;
 
@@ -529,7 +550,7 @@ __device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const 
 //
 // Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
 // shares of its phase groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T, int CGF = 0>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T, int CGF = 0, bool W16 = false>
 __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -571,9 +592,23 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
     // (float samples: 4 -- five float groups in flight spill at the 64 VGPRs of 8 waves per SIMD)
     constexpr int UNR = PADDED ? 3 : (sizeof(T) == 4 ? (ONE_GROUP ? 4 : 3) : 5);
     u32x4 w[UNR];
-    window_fetch<UNR, T>(wg, w);
-    STAMP(2);
-    window_commit<UNR, T>(xs, d, wg, w);
+    bool plain = false;
+    if constexpr (!PADDED) plain = window_is_plain<UNR, T>(wg);  // (wave-uniform)
+    if (plain) {
+      window_fetch_plain<UNR, T>(wg, w);
+      STAMP(2);
+      if constexpr (W16)
+        window_commit_plain16<UNR>(reinterpret_cast<int16_t *>(xs), wg, w);
+      else
+        window_commit_plain<UNR, T>(xs, wg, w);
+    } else {
+      window_fetch<UNR, T>(wg, w);
+      STAMP(2);
+      if constexpr (W16)
+        window_commit16<UNR>(reinterpret_cast<int16_t *>(xs), d, wg, w);
+      else
+        window_commit<UNR, T>(xs, d, wg, w);
+    }
   }
   STAMP(3);
   __syncthreads();
@@ -584,30 +619,30 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
   if constexpr (ONE_GROUP && CT == 1 && sizeof(T) == 2) {
     if (p.image_stride != 0) {
-      fir_tile_rows_mono<R, PADDED>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
+      fir_tile_rows_mono<R, PADDED, W16>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
       return;
     }
   }
-  fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
-                                        blockIdx.z, gridDim.z);
+  fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF, W16>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
+                                             blockIdx.z, gridDim.z);
 }
 
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
   if (pack != nullptr)
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF>, seen_packed);
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16>, seen_packed);
   else
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF>, seen_ring);
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16>, seen_ring);
   if (pack != nullptr)
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF>), grid, dim3(threads), lds_bytes, stream, p,
-                       p.rows, nullptr, *pack);
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16>), grid, dim3(threads), lds_bytes, stream,
+                       p, p.rows, nullptr, *pack);
   else
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF>), grid, dim3(threads), lds_bytes, stream, p,
-                       p.rows, d_descs, empty);
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16>), grid, dim3(threads), lds_bytes, stream,
+                       p, p.rows, d_descs, empty);
   return hipGetLastError();
 }
 
@@ -631,15 +666,35 @@ uint32_t default_r(const FilterSpec &f) {
 
 }  // namespace
 
-PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget) {
-  PeriodPlan t = plan_period_r(f, channels, lds_budget, default_r(f));
-  if (!t.usable && t.r != 10) t = plan_period_r(f, channels, lds_budget, 10);
+PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16) {
+  PeriodPlan t = plan_period_r(f, channels, lds_budget, default_r(f), w16);
+  if (!t.usable && t.r != 10) t = plan_period_r(f, channels, lds_budget, 10, w16);
   return t;
 }
 
-PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r) {
+PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_budget, const PeriodPlan &t) {
+  PeriodPlan w;
+  static const bool off = std::getenv("SPEEXHIP_NO_W16") != nullptr;  // diagnostics: A/B
+  if (!t.usable || off) return w;
+  w = plan_period_r(f, channels, lds_budget, t.r, true);
+  static const bool force = std::getenv("SPEEXHIP_FORCE_W16") != nullptr;  // diagnostics: every layout that has one
+  // What the int16 window costs is two conversions per sample read: +20 % vector instructions where a read
+  // feeds 10 packed FMAs (R = 10, channel pairs), +40 % at R = 5, and single-channel lanes convert two
+  // 2-byte reads per step.  Measured at 32 streams x 2^20 frames (profiles/r03_w16_ab.txt): stereo 48k->11.025k
+  // 28 -> 58 periods per tile 530 -> 338 us, 4 channels 14 -> 28: 1032 -> 687, stereo 44.1k->16k 42 -> 64: 363 -> 277,
+  // mono 48k->11.025k 58 -> 116: 289 -> 197; but stereo 44.1k->8k (R = 5) 41 -> 64 only 304 -> 272 and mono
+  // 44.1k->16k 86 -> 128 nothing (196 -> 198).  So: 5/4 of the periods for R = 10 on channel pairs, 7/4 otherwise.
+  const bool cheap = t.r == 10 && t.ct == 2;
+  if (w.usable && !force && 4 * w.lane_periods < (cheap ? 5 : 7) * t.lane_periods) w.usable = false;
+  return w;
+}
+
+// w16: plan for an int16 LDS window (2-byte elements; pad, half_offset ... count elements either way)
+PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16) {
   PeriodPlan t;
   t.r = r;
+  t.w16 = w16;
+  const size_t eb = w16 ? 2 : 4;  // bytes per LDS element
   const uint32_t it_steps = 2 * bank_taps(t.r) / t.r;  // steps per loop iteration (two banks)
   t.ct = (channels % 2 == 0) ? 2 : 1;
   t.cgroups = channels / t.ct;
@@ -662,12 +717,15 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // stereo 48k->44.1k, 32 streams: no pad 622 us, pad 4 -- two lanes per bank pair -- 188 us, pad 2
   // -- conflict-free, but 8-byte staging writes -- 199 us, pad 8: 288, pad 16: 411.)
   auto worst_bank_load = [&](uint32_t pad) {
-    const uint32_t unit = t.ct;  // floats per lane access
+    // float image: a lane reads `ct` floats (ds_read_b32 / _b64); int16 image: the dword its one or two
+    // samples sit in (ds_read_i16 / _b32, 32 banks)
+    const uint32_t unit = w16 ? 2u : t.ct;
+    const uint32_t slots = w16 ? 32u : 64 / unit;
     const uint32_t stride = f.num * channels + pad;
     uint32_t count[64] = {0}, worst = 0;
     for (uint32_t lane = 0; lane < 32; lane++) {
       const uint32_t cg = lane % t.cgroups, pl = lane / t.cgroups;
-      const uint32_t slot = ((pl * stride + cg * t.ct) / unit) % (64 / unit);
+      const uint32_t slot = ((pl * stride + cg * t.ct) / unit) % slots;
       worst = std::max(worst, ++count[slot]);
     }
     return worst;
@@ -675,7 +733,8 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   t.pad = 0;
   {
     uint32_t best = worst_bank_load(0);
-    for (uint32_t pad = 4; pad <= 64 && best > 1; pad += 4) {
+    const uint32_t pad_step = w16 ? 8 : 4;  // 16 bytes: the staging writes stay 16-byte aligned
+    for (uint32_t pad = pad_step; pad <= 16 * pad_step && best > 1; pad += pad_step) {
       const uint32_t w = worst_bank_load(pad);
       if (w < best) {
         best = w;
@@ -685,7 +744,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   }
   static const bool no_pad = std::getenv("SPEEXHIP_NO_PAD") != nullptr;
   if (no_pad) t.pad = 0;
-  if (std::getenv("SPEEXHIP_PAD")) t.pad = static_cast<uint32_t>(std::atoi(std::getenv("SPEEXHIP_PAD"))) & ~3u;  // diagnostics
+  if (std::getenv("SPEEXHIP_PAD")) t.pad = static_cast<uint32_t>(std::atoi(std::getenv("SPEEXHIP_PAD"))) & (w16 ? ~7u : ~3u);  // diagnostics
   if (t.pad != 0 && t.r != 10) return t;  // (the padded walk below is written for 4-step iterations)
   if (t.pad != 0) {
     // A padded window is only walked cheaply if every period boundary a group's window crosses
@@ -716,9 +775,9 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
     //  reads -- and discards -- one period past its last, so size the image for an even count)
     if (t.ct == 1) lane_periods = (lane_periods + 1) / 2 * 2;
     const size_t pad_floats = static_cast<size_t>(t.pad) * (lane_periods + t.tail_frames / f.num + 2);
-    size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + it_steps) * channels + pad_floats) * 4 +
-                   kSlack * 4;
-    return bytes;
+    size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + it_steps) * channels + pad_floats) * eb +
+                   kSlack * eb;
+    return (bytes + 15) / 16 * 16;
   };
   // Periods per tile: all the lanes of a wave if that leaves room for TWO workgroups per CU (one
   // workgroup's staging and stores only overlap FMAs if another one is resident; same box,
@@ -744,6 +803,8 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // needs enough phases to fill the R-wide register tile and a window that fits one CU's LDS
   // ... and at least a quarter of each wave at work (below that the exact kernel's mapping wins)
   t.usable = f.den >= 7 && t.cgroups <= 64 && 4 * t.lane_periods >= full && t.window_bytes <= lds_budget;
+  // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py)
+  if (w16 && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1))) t.usable = false;
   return t;
 }
 
@@ -922,8 +983,9 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   //  streams and slower beyond (8: 219 vs 213 us; 4 shares always slower), 64 streams 404 -> 407: a share
   //  stages the whole window again and leaves its CU with half the FIR waves; removed.)
   p.threads = 0;  // set below
-  // bit 0: prologue + staging raised, bit 1: stores raised, bit 2: the two workgroups of a CU at different FIR priorities
-  static const int env_prio = std::getenv("SPEEXHIP_PRIO") ? std::atoi(std::getenv("SPEEXHIP_PRIO")) : 7;
+  // bit 0: prologue + staging raised, bit 1: stores raised, bit 2 (measured slower, see set_fir_priority): the two
+  // workgroups of a CU at different FIR priorities
+  static const int env_prio = std::getenv("SPEEXHIP_PRIO") ? std::atoi(std::getenv("SPEEXHIP_PRIO")) : 3;
   p.prio = static_cast<uint32_t>(env_prio);
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
@@ -940,12 +1002,16 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   uint32_t grid_x = (max_periods == 0 ? 0 : tiles) + 1;
   if (splits > 1 && n_streams == 1) grid_x = (grid_x + 7) / 8 * 8;
   const dim3 grid(grid_x, n_streams, splits);
-#define SPEEXHIP_PERIOD_CASE_R(RV, CTV, ONE, PADV)                                                            \
-  return float_io ? launch_rc<RV, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, stream)   \
-                  : launch_rc<RV, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
+  // (an int16 window -- t.w16 -- exists for int16 calls on the layouts the ISA loop is generated for: ONE or CGV)
+  if (t.w16 && float_io) return hipErrorInvalidValue;
+#define SPEEXHIP_PERIOD_CASE_R(RV, CTV, ONE, PADV)                                                                                      \
+  return float_io ? launch_rc<RV, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, stream)                       \
+         : (ONE && t.w16) ? launch_rc<RV, CTV, ONE, PADV, int16_t, 0, ONE>(p, d_descs, pack, grid, threads, t.window_bytes, stream)     \
+                          : launch_rc<RV, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
   // 4 / 6 / 8 channels: channel pairs per frame as a compile-time constant (lane_ctx)
-#define SPEEXHIP_PERIOD_CASE_CG(RV, PADV, CGV)                                                                        \
-  return float_io ? launch_rc<RV, 2, false, PADV, float, CGV>(p, d_descs, pack, grid, threads, t.window_bytes, stream)   \
+#define SPEEXHIP_PERIOD_CASE_CG(RV, PADV, CGV)                                                                                          \
+  return float_io ? launch_rc<RV, 2, false, PADV, float, CGV>(p, d_descs, pack, grid, threads, t.window_bytes, stream)                  \
+         : t.w16  ? launch_rc<RV, 2, false, PADV, int16_t, CGV, true>(p, d_descs, pack, grid, threads, t.window_bytes, stream)          \
                   : launch_rc<RV, 2, false, PADV, int16_t, CGV>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
   const bool padded = t.pad != 0;
   if (t.ct == 2 && t.cgroups >= 2 && t.cgroups <= 4) {

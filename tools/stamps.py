@@ -23,8 +23,9 @@ ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--config", default="cfg2")
 ap.add_argument("--frames", type=int, default=1 << 20)
 ap.add_argument("--launches", type=int, default=3)
+ap.add_argument("--custom", default=None, help="channels,in_rate,out_rate,quality (overrides --config)")
 a = ap.parse_args()
-ch, fi, fo, q = bench.CONFIGS[a.config]
+ch, fi, fo, q = bench.CONFIGS[a.config] if not a.custom else tuple(int(v) for v in a.custom.split(","))
 S, F = a.streams, a.frames
 cap = bench.wrapper_capacity(F * ch * 2, fi, fo, ch)
 b = speexhip.Batch(S, ch, fi, fo, q)
