@@ -350,7 +350,7 @@ def main():
 
     # R repetitions of exactly K steps; each is bracketed by barrier + synchronize on both sides
     reps = max(1, args.reps)
-    wall, gpu = [], []
+    wall, gpu, issue = [], [], []
     consumed = produced = 0
     it = args.warmup + 1
     for r in range(reps):
@@ -365,9 +365,11 @@ def main():
             if r == 0:
                 consumed += sum(u)
                 produced += sum(m)
+        t_issued = time.perf_counter() - t0  # the K calls have returned; the device may still be running
         ev1.record(stream)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        issue.append(t_issued)
         dist_util.barrier(ctl)
         wall.append(dist_util.reduce_scalar(elapsed, "max", ctl))
         gpu.append(ev0.elapsed_time(ev1))
@@ -397,6 +399,10 @@ def main():
                 traffic = None
         ms_per_step = elapsed_med / args.steps * 1e3
         assert launch_ms <= ms_per_step * 1.001, (launch_ms, ms_per_step)  # the launches fit in the wall time
+        # what the host spends per step planning the call and putting the launch into the stream (rank 0;
+        # Python + ctypes + the library's planner + hipLaunchKernel): a step cannot be shorter than this, so
+        # once it reaches the kernel's own time the line measures the host, not the GPU
+        host_issue_us = statistics.median(issue) / args.steps * 1e6
         line = {
             "metric": "input Msamples/s int16 %d->%d q=%d %dch (whole job)" % (fi, fo, q, ch),
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -417,7 +423,9 @@ def main():
                            "f64 sums of f32 products" if info["kernel"] in (1, 3) else "f32") if args.mode == "fast"
                        else "as the reference",
                        "parallelism": "independent streams sharded over %d rank(s), no data-path collective" % world},
-            "timing": {"reps": reps, "ms_per_step_median": round(ms_per_step, 5),
+            "timing": {"reps": reps, "host_issue_us_per_step": round(host_issue_us, 3),
+                       "host_bound": bool(host_issue_us >= 0.95 * launch_ms * 1e3),
+                       "ms_per_step_median": round(ms_per_step, 5),
                        "ms_per_step_min": round(min(wall) / args.steps * 1e3, 5),
                        "ms_per_step_max": round(max(wall) / args.steps * 1e3, 5),
                        "region": "each repetition = exactly `steps` steps between barrier+synchronize pairs, "

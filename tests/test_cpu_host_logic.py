@@ -393,6 +393,10 @@ def test_planner_invariants_over_rates_qualities_and_channel_counts():
                         assert t["r_or_p"] in (5, 10) and t["lane_periods"] >= 1, (i, o, q, ch, t)
                         assert t["lds_bytes"] <= 150 * 1024, (i, o, q, ch, t)
                         assert t["pad"] % 4 == 0 and not (t["r_or_p"] == 5 and t["pad"]), (i, o, q, ch, t)
+                        # an int16 window is planned only where it holds clearly more periods, never more than
+                        # the lanes can take (64 per wave; single-channel lanes carry two periods each)
+                        w = t["w16_lane_periods"]
+                        assert w == 0 or (4 * w >= 5 * t["lane_periods"] and w <= (128 if ch % 2 else 64 // (ch // 2))), (i, o, q, ch, t)
                     elif t["fast_path"] == 3:
                         assert t["lds_bytes"] <= 160 * 1024, (i, o, q, ch, t)
                         assert t["row_len"] % (2 * t["steps_per_iteration"]) == 0, (i, o, q, ch, t)
@@ -411,6 +415,11 @@ def test_planner_choices_for_the_named_configurations():
     # few phases (den <= 80): groups of 5 in every launch
     for i, o in ((44100, 8000), (88200, 48000), (88200, 16000), (176400, 8000)):
         assert plan(i, o, 7, 2)["r_or_p"] == 5, (i, o)
+    # wide windows (round 3): int16 calls run over an int16 LDS window with twice the periods per tile; not where
+    # the float window already fills the waves, not for the layouts without an ISA loop (odd channel counts >= 3)
+    assert plan(48000, 11025, 7, 2)["w16_lane_periods"] >= 2 * plan(48000, 11025, 7, 2)["lane_periods"]
+    assert plan(44100, 16000, 7, 2)["w16_lane_periods"] == 64 and plan(48000, 11025, 7, 4)["w16_lane_periods"] == 28
+    assert cfg2["w16_lane_periods"] == 0 and cfg4["w16_lane_periods"] == 0 and plan(48000, 11025, 7, 3)["w16_lane_periods"] == 0
     # n:1 shapes: one period per lane from 16:1 on; 11:1 and 7:6 have no fast kernel
     assert plan(192000, 8000, 7, 2)["r_or_p"] == 1 and plan(96000, 8000, 7, 2)["r_or_p"] == 2
     assert plan(48000, 8000, 7, 2)["r_or_p"] == 4 and plan(48000, 24000, 7, 2)["r_or_p"] == 8

@@ -664,7 +664,10 @@ def test_window_layout_variants_of_the_period_kernel():
     cases = [(2, 48000, 44100, 5), (2, 48000, 44100, 10), (1, 48000, 44100, 7), (4, 48000, 44100, 5),
              (6, 44100, 48000, 7), (2, 96000, 44100, 7), (2, 32000, 44100, 7), (2, 44100, 32000, 7),
              (3, 48000, 44100, 4), (2, 11025, 48000, 6), (2, 48000, 11025, 3), (2, 44100, 8000, 5),
-             (7, 22050, 16000, 8), (2, 88200, 96000, 9)]
+             (7, 22050, 16000, 8), (2, 88200, 96000, 9),
+             # round 3: int16 calls of these run over an int16 LDS window (twice the periods per tile)
+             (2, 48000, 11025, 7), (4, 48000, 11025, 7), (2, 44100, 16000, 7), (1, 48000, 11025, 7), (2, 44100, 8000, 10),
+             (8, 48000, 11025, 5), (6, 44100, 16000, 6)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -1056,6 +1059,19 @@ def test_bench_n_rank_path_end_to_end_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    # BASELINE configs[4] in its full shape -- 8 ranks, 256 streams, 32 per rank, each rank's launch fed through
+    # its descriptor ring -- on this one GPU (short chunks): what an 8-GPU node will run (tools/scale.sh)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-streams", "256", "--steps", "3",
+                        "--warmup", "1", "--reps", "2", "--frames", "65536", "--preheat-ms", "10"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["streams_per_gpu"] == 32 and d["config"]["streams_total"] == 256
+    assert abs(d["value"] - 256 * 65536 * 2 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    assert d["parity"]["counters_equal"] and d["parity"]["max_abs_diff_lsb"] <= 1
 
 
 def test_states_recycle_device_resources_through_the_pool():
@@ -1197,3 +1213,29 @@ def test_control_calls_and_destruction_do_not_wait_for_other_states():
     assert_close(got, want, "after")
     small.close()
     big.close()
+
+
+def test_int16_window_plan_serves_int16_calls_until_a_float_call():
+    """Round 3: ratios whose float LDS window cannot hold a full tile (48k->11.025k ...) run int16 calls over an
+    int16 window.  That is only right while the histories hold PCM values: after a float call (non-integer
+    samples in the history) the stream goes back to the float window for good.  Int16 / float / int16 calls on
+    one state against the oracle doing the same, FAST mode within +-1 LSB (float: relative), counters equal;
+    and the window kind shows in nothing but speed: SPEEXHIP_NO_W16-style A/B is tools/gpu_ab.sh's job."""
+    for (ch, i, o, q) in [(2, 48000, 11025, 7), (4, 48000, 11025, 5), (2, 44100, 16000, 7)]:
+        assert speexhip.debug_plan(i, o, q, ch)["w16_lane_periods"] > 0
+        r = speexhip.Resampler(ch, i, o, q)
+        ref = orc.Oracle(ch, i, o, q)
+        for step, frames in enumerate([50000, 777, 40000, 3000, 60000]):
+            if step in (2, 3):      # float calls: samples with fractions
+                xf = (orc.lcg_pcm(frames * ch, 10 + step).astype(np.float32) * np.float32(0.37)).reshape(-1, ch)
+                got, used = r.process_float(xf, 1 << 20)
+                want, wu = ref.process_float(xf, 1 << 20)
+                assert used == wu and r.position() == ref.position(), (ch, i, o, q, step)
+                assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), (ch, i, o, q, step)
+            else:
+                x = orc.lcg_pcm(frames * ch, 20 + step).reshape(-1, ch)
+                got, used = r.process(x, 1 << 20)
+                want, wu = ref.process(x, 1 << 20)
+                assert used == wu and r.position() == ref.position(), (ch, i, o, q, step)
+                assert_close(got, want, "w16 %s step %d" % ((ch, i, o, q), step))
+        r.close()
