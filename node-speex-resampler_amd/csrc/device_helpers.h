@@ -138,6 +138,40 @@ __device__ __forceinline__ WindowGeom window_geom(const StreamDesc &d, uint32_t 
   return w;
 }
 
+// The same for a window that lies wholly inside the call's input, 16-byte aligned -- every tile of a call but
+// its first and its last few: false (and *w untouched) when the window is not of that kind.
+template <typename T>
+__device__ __forceinline__ bool window_geom_plain(const StreamDesc &d, uint32_t channels, uint32_t num,
+                                                  uint32_t tail_frames, uint32_t m_lo, uint32_t m_cnt, uint32_t nthr,
+                                                  uint32_t pad, uint32_t period_magic, WindowGeom *w) {
+  constexpr int GS = PerLoad<T>::value;
+  const int64_t hist_elems = static_cast<int64_t>(d.hist_frames) * channels;
+  const int64_t q_lo = (static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * num) * channels - hist_elems;
+  const uint32_t xshift = static_cast<uint32_t>(q_lo) & (GS - 1);
+  const uint32_t span = (m_cnt - 1) * num + tail_frames;
+  const uint32_t total = (xshift + span * channels + GS - 1) & ~static_cast<uint32_t>(GS - 1);
+  const int64_t in_elems = static_cast<int64_t>(d.in_frames) * channels;
+  const int64_t q_base = q_lo - xshift;
+  if (d.in == nullptr || (reinterpret_cast<uintptr_t>(d.in) & 15u) != 0 || q_lo < 0 ||
+      q_base + total > (in_elems & ~static_cast<int64_t>(GS - 1)))
+    return false;
+  w->nthr = nthr;
+  w->pad = pad;
+  w->period_elems = num * channels;
+  w->period_magic = period_magic;
+  w->hist_elems = hist_elems;
+  w->in_elems = in_elems;
+  w->q_base = q_base;
+  w->xshift = xshift;
+  w->total = total;
+  w->head_end = 0;
+  w->tail_begin = total;
+  w->u_begin = 0;
+  w->n_wide = total / GS;
+  w->src = static_cast<const T *>(d.in) + q_base;
+  return true;
+}
+
 template <typename T>
 __device__ __forceinline__ u32x4 load_group(const WindowGeom &g, uint32_t unit) {
   return *(g_cuint4 *)(static_cast<const T *>(g.src) + PerLoad<T>::value * static_cast<size_t>(unit));
@@ -280,6 +314,40 @@ __device__ __forceinline__ void window_commit_plain(float *xs, const WindowGeom 
     float *dst = lane_xs + first * GS;
 #pragma unroll
     for (int k = 0; k < GS; k += 4) *reinterpret_cast<float4 *>(dst + k) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
+  }
+}
+
+// ---- ... and for a PADDED window whose 16-byte quarters never straddle a padding boundary: frames of 4, 8, 12 ...
+// channels (the window starts on a multiple of the channel count, so on a multiple of 4 elements, and a
+// period is a multiple of 4 elements too).  The general path tests every group for a boundary inside it
+// and falls back to eight scalar writes with a division each; here a quarter's position is its index plus
+// (period it lies in) x pad, the period by one multiply-high: BASELINE configs[3] (8 channels 48k->44.1k)
+// staged alone took 140 us of a 584 us launch, more than its stores.
+template <int UNR, typename T>
+__device__ __forceinline__ bool window_is_plain_padded(const WindowGeom &g) {
+  constexpr uint32_t GS = PerLoad<T>::value;
+  return g.pad != 0 && g.period_magic != 0 && g.head_end == 0 && g.tail_begin == g.total && g.n_wide * GS == g.total &&
+         g.n_wide <= static_cast<uint32_t>(UNR) * g.nthr && (g.xshift & 3u) == 0 && (g.period_elems & 3u) == 0 &&
+         (g.pad & 3u) == 0;
+}
+
+template <int UNR, typename T>
+__device__ __forceinline__ void window_commit_plain_padded(float *xs, const WindowGeom &g, const u32x4 (&w)[UNR]) {
+  constexpr int GS = PerLoad<T>::value;
+#pragma unroll
+  for (int u = 0; u < UNR; u++) {
+    const uint32_t first = u * g.nthr;
+    if (first >= g.n_wide || threadIdx.x >= g.n_wide - first) continue;
+    float f[GS];
+    unpack_group(w[u], f, T());
+    const uint32_t j = (first + threadIdx.x) * GS;
+#pragma unroll
+    for (int k = 0; k < GS; k += 4) {
+      // (j + k >= xshift or the quarter lies before the first frame: period 0 either way)
+      const uint32_t n = j + k >= g.xshift ? j + k - g.xshift : 0u;
+      const uint32_t a = j + k + __umulhi(n, g.period_magic) * g.pad;
+      *reinterpret_cast<float4 *>(xs + a) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
+    }
   }
 }
 

@@ -26,9 +26,16 @@ struct StreamDesc {
                         // change left buffered (reference resample.c:727-782) -- they are input
                         // that is already in the line, so V simply starts with a longer history
   uint32_t hist_keep;   // frames this call leaves in hist_next: taps-1 + pending frames remaining
+  uint32_t m_total;     // periods this call touches: ceil((k_shift + n_out) / den) (period kernel; a division
+                        // every workgroup used to make in its prologue)
 };
 
-static const int kMaxPackedStreams = 8;
+// Batches of up to 32 streams (BASELINE configs[4]'s share of one GPU) carry their descriptors in the
+// kernel-argument segment: 2.3 KB of the 4 KB a launch may pass.  (8 until round 3: a 32-stream launch then
+// went through the pinned -> device ring, i.e. a copy of 2.3 KB -- a blit kernel in front of every launch --
+// and every workgroup fetched its descriptor with a load that could only be issued once the ring's pointer
+// had arrived from the kernel arguments: two memory round trips before the first staging load instead of one.)
+static const int kMaxPackedStreams = 32;
 struct DescPack {  // small batches travel in the kernel-argument segment (no H2D copy)
   StreamDesc d[kMaxPackedStreams];
 };

@@ -818,6 +818,7 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
     d.base_shift = plan.begin.last -
                    static_cast<int32_t>((static_cast<uint64_t>(d.k_shift) * filter_.num) / filter_.den);
     d.tile_begin = 0;
+    d.m_total = static_cast<uint32_t>((static_cast<uint64_t>(d.k_shift) + d.n_out + filter_.den - 1) / filter_.den);
     max_out = std::max(max_out, plan.produced);
     any_work = any_work || plan.produced != 0 || d.consumed != 0;
   }

@@ -396,6 +396,10 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
       if constexpr (R % 2 != 0) od[R - 1] = v[R - 1];
       return;
     }
+    // (8 channels: a lane's 4-byte pieces, 16 bytes apart, could leave as whole 16-byte frames after a 4 x 4
+    //  transpose inside each quad of lanes -- rows cg, 4 + cg, 8 + cg per lane, 3 stores instead of 10.  With the
+    //  transpose left out (wrong data, right addresses) BASELINE configs[3] at 32 streams went 588 -> 569 us, and
+    //  the 48 vector instructions of three butterfly transposes cost about that much again: not built.)
 #pragma unroll
     for (int i = 0; i < R; i++, o += C) {
       if (i < i_lo || i >= i_hi) continue;
@@ -558,7 +562,10 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
   // issue slot: its few hundred prologue and staging instructions -- the ones that put its window
   // loads in flight -- took 4-5 us there (0.5 us on an idle CU).  They run at raised priority; the
   // FIR loop and everything after it at the default.
-  if (p.prio & 1u) __builtin_amdgcn_s_setprio(3);
+  // (unconditionally: behind a test of p.prio the compiler holds back the descriptor's loads -- whose address
+  //  needs nothing but blockIdx.y -- until p.prio has arrived, a second memory round trip of ~0.4 us in every
+  //  workgroup's prologue; the diagnostics knob lowers the priority again as soon as it is known)
+  __builtin_amdgcn_s_setprio(3);
   STAMP(0);
 #ifdef SPEEXHIP_STAMPS
   {
@@ -573,12 +580,18 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
   // the descriptor then arrive through one batch of scalar loads and a single wait instead of one
   // round trip per early exit (four dependent waits, ~1.0 us from start to the first staging load).
   const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
-  const uint32_t K_end = d.k_shift + d.n_out;            // exclusive canonical output index
-  const uint32_t m_total = (K_end + p.den - 1) / p.den;  // periods touched by this call
+  if (!(p.prio & 1u)) __builtin_amdgcn_s_setprio(0);  // diagnostics: A/B of the raised prologue priority
+  const uint32_t m_total = d.m_total;  // periods touched by this call: ceil((k_shift + n_out) / den), from the host
   const uint32_t m_lo = blockIdx.x * p.lane_periods;
   const uint32_t m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 1u;
-  const WindowGeom wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, p.threads,
-                                       PADDED ? p.pad : 0u, PADDED ? p.period_magic : 0u);
+  // (most tiles lie wholly inside the call's input: a dozen scalar instructions give their geometry; the
+  //  general form -- history in front, silence behind, unaligned buffers -- costs ~150 and was a third of
+  //  the 1.2-1.4 us a workgroup took from its first instruction to its first staging load)
+  WindowGeom wg;
+  if (!window_geom_plain<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, p.threads, PADDED ? p.pad : 0u,
+                            PADDED ? p.period_magic : 0u, &wg))
+    wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, p.threads, PADDED ? p.pad : 0u,
+                        PADDED ? p.period_magic : 0u);
   if (p.skip & 64u) return;  // diagnostics: bare dispatch cost
   if (blockIdx.x == p.history_block) {
     if (blockIdx.z == 0) roll_history<T>(p.channels, d, p.threads);
@@ -592,9 +605,14 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
     // (float samples: 4 -- five float groups in flight spill at the 64 VGPRs of 8 waves per SIMD)
     constexpr int UNR = PADDED ? 3 : (sizeof(T) == 4 ? (ONE_GROUP ? 4 : 3) : 5);
     u32x4 w[UNR];
-    bool plain = false;
+    bool plain = false, plain_padded = false;
     if constexpr (!PADDED) plain = window_is_plain<UNR, T>(wg);  // (wave-uniform)
-    if (plain) {
+    if constexpr (PADDED && !W16) plain_padded = window_is_plain_padded<UNR, T>(wg);
+    if (plain_padded) {
+      window_fetch_plain<UNR, T>(wg, w);
+      STAMP(2);
+      window_commit_plain_padded<UNR, T>(xs, wg, w);
+    } else if (plain) {
       window_fetch_plain<UNR, T>(wg, w);
       STAMP(2);
       if constexpr (W16)

@@ -191,7 +191,7 @@ def test_python_mirror_of_processChunk_applies_the_capacity_rule(golden):
 def test_batched_streams_device_pointers_ragged():
     import torch
     ch, i, o, q = 2, 44100, 48000, 7
-    for S in (3, 12):  # 12 > kMaxPackedStreams exercises the descriptor ring
+    for S in (3, 12, 36):  # 36 > kMaxPackedStreams (32) exercises the descriptor ring
         frames = 30000
         lens = [frames - 137 * s for s in range(S)]
         xs = np.stack([orc.lcg_pcm(frames * ch, 500 + s).reshape(frames, ch) for s in range(S)])

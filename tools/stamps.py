@@ -111,7 +111,7 @@ for launch in range(a.launches):
             if len(mates):
                 offs.append(np.abs(mates[:, 0] - row[0]).min())
     in_fir /= in_fir.sum()
-    o = np.array(offs)
+    o = np.array(offs if offs else [0.0])
     print("  per CU, share of the launch with 0 / 1 / 2 workgroups inside their FIR loops: %.3f / %.3f / %.3f" % tuple(in_fir))
     print("  start offset between a workgroup and the nearest one resident beside it: median %.2f p10 %.2f p90 %.2f us" % (
         np.median(o), np.percentile(o, 10), np.percentile(o, 90)))
