@@ -418,16 +418,69 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
   }
 }
 
+// The kernel's parameters and the workgroup's descriptor as they lie in memory (the kernel-argument segment; the
+// descriptor ring for large batches), in the constant address space: what is read through these comes by scalar
+// loads.  The ISA loop names 40 tap SGPRs; with the parameters and the descriptor held in registers across it
+// hipcc spilled ~26 SGPRs into VGPR lanes around every group (v_writelane / v_readlane: ~60 vector instructions
+// per wave, as many as the conversions of the staging).  fir_tile therefore reads both AGAIN on either side of
+// the loop, through pointers made opaque so that the compiler cannot keep the first copies alive instead:
+// a handful of scalar loads that hit the scalar cache.
+typedef const __attribute__((address_space(4))) PeriodParams *KParams;
+typedef const __attribute__((address_space(4))) StreamDesc *KDesc;
+template <typename P>
+__device__ __forceinline__ P opaque(P ptr) {
+  asm volatile("" : "+s"(ptr));
+  return ptr;
+}
+template <typename X>
+__device__ __forceinline__ X load_k(const __attribute__((address_space(4))) X *ptr) {
+  // (dword by dword: a struct cannot be copy-constructed from another address space; unused fields' loads vanish)
+  static_assert(sizeof(X) % 4 == 0, "dword-sized structs");
+  union {
+    X v;
+    uint32_t w[sizeof(X) / 4];
+  } u;
+  const __attribute__((address_space(4))) uint32_t *q = (const __attribute__((address_space(4))) uint32_t *)opaque(ptr);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(X) / 4; i++) u.w[i] = q[i];
+  return u.v;
+}
+struct KernArgs {  // layout of resample_period's kernel arguments
+  PeriodParams p;
+  const float *rows;
+  const StreamDesc *streams;
+  DescPack pack;
+};
+
 // FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
 // followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
 template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
-__device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__restrict__ rows,
-                                         const StreamDesc &d, const float *xs, uint32_t xshift,
-                                         uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
-                                         uint32_t zsplit, uint32_t nsplit) {
-  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p, xshift, m_lo, m_cnt, lane);
-  const uint32_t g_step = p.wave_groups * nsplit;
-  for (uint32_t g = zsplit * p.wave_groups + wave; g < p.groups; g += g_step) {
+__device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDesc &d0, KParams pp,
+                                         const float *__restrict__ rows, KDesc dp, const float *xs, uint32_t xshift,
+                                         uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit,
+                                         uint32_t nsplit) {
+  // (layouts that run the C++ loop keep the copies the kernel already holds: re-reading them there only added
+  //  register pressure -- scratch in every such instance)
+#ifndef SPEEXHIP_CXX_FIR_LOOP
+  constexpr bool kReload = FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available;
+#else
+  constexpr bool kReload = false;
+#endif
+  auto params = [&]() -> PeriodParams {
+    if constexpr (kReload) return load_k(pp);
+    return p0;
+  };
+  LaneCtx c;
+  uint32_t g_step, g;
+  {
+    const PeriodParams p = params();
+    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p, xshift, m_lo, m_cnt, lane);
+    g_step = p.wave_groups * nsplit;
+    g = zsplit * p.wave_groups + wave;
+    if (g >= p.groups) return;
+  }
+  for (;;) {
+    const PeriodParams p = params();  // (this side of the loop)
     f32x2 acc[R];  // .x = first channel of the pair, .y = second (unused when CT == 1)
 #pragma unroll
     for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
@@ -448,11 +501,20 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
     }
 #endif
     STAMP(5);
-    if ((p.skip & 8u) || !c.live) continue;
-    if (p.prio & 2u) __builtin_amdgcn_s_setprio(2);
-    store_group<R, CT, ONE_GROUP, T>(p, d, c, g, acc);
-    if (p.prio & 2u) set_fir_priority(p);
-    STAMP(6);
+    const PeriodParams q = params();  // (... and the far side)
+    if (!(q.skip & 8u) && c.live) {
+      StreamDesc d;
+      if constexpr (kReload)
+        d = load_k(dp);
+      else
+        d = d0;
+      if (q.prio & 2u) __builtin_amdgcn_s_setprio(2);
+      store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
+      if (q.prio & 2u) set_fir_priority(q);
+      STAMP(6);
+    }
+    g += g_step;
+    if (g >= q.groups) return;
   }
 }
 
@@ -473,18 +535,27 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p, const float *__r
 //  but 8 ch 48k->44.1k 621 -> 644 us and 6 ch 670 -> 735 us at 32 streams: the two barriers and the
 //  serial copy-out cost more than the per-lane stores they replace; removed.)
 template <int R, bool PADDED, bool W16 = false>
-__device__ __forceinline__ void fir_tile_rows_mono(const PeriodParams &p, const float *__restrict__ rows,
-                                                   const StreamDesc &d, float *xs, uint32_t xshift, uint32_t m_lo,
-                                                   uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit) {
-  const LaneCtx c = lane_ctx<1, true, PADDED>(p, xshift, m_lo, m_cnt, lane);
-  const uint32_t g0 = zsplit * p.wave_groups;
-  const uint32_t g = g0 + wave;
-  const bool valid = g < p.groups;
+__device__ __forceinline__ void fir_tile_rows_mono(KParams pp, const float *__restrict__ rows, KDesc dp, float *xs,
+                                                   uint32_t xshift, uint32_t m_lo, uint32_t m_cnt, uint32_t wave,
+                                                   uint32_t lane, uint32_t zsplit) {
+  // (parameters and descriptor are read again on either side of the ISA loop: see KParams)
+  LaneCtx c;
+  uint32_t g0, g;
+  bool valid;
   f32x2 acc[R];
 #pragma unroll
   for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
-  if (valid) fir_group<R, 1, PADDED, 1, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+  {
+    const PeriodParams p = load_k(pp);
+    c = lane_ctx<1, true, PADDED>(p, xshift, m_lo, m_cnt, lane);
+    g0 = zsplit * p.wave_groups;
+    g = g0 + wave;
+    valid = g < p.groups;
+    if (valid) fir_group<R, 1, PADDED, 1, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+  }
   __syncthreads();  // every wave is done with the window
+  const PeriodParams p = load_k(pp);
+  const StreamDesc d = load_k(dp);
   if (p.skip & 8u) return;
 
   // samples of a row held by this workgroup (a share past the last group holds none)
@@ -637,12 +708,18 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
   if constexpr (ONE_GROUP && CT == 1 && sizeof(T) == 2) {
     if (p.image_stride != 0) {
-      fir_tile_rows_mono<R, PADDED, W16>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
+      const __attribute__((address_space(4))) KernArgs *ka =
+          (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+      const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
+      fir_tile_rows_mono<R, PADDED, W16>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
       return;
     }
   }
-  fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF, W16>(p, rows, d, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u,
-                                             blockIdx.z, gridDim.z);
+  const __attribute__((address_space(4))) KernArgs *ka =
+      (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+  const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
+  fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF, W16>(p, d, &ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
+                                             threadIdx.x & 63u, blockIdx.z, gridDim.z);
 }
 
 template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
