@@ -674,7 +674,7 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
     // 5 x 16 bytes per lane in flight: a 76 KB window staged by 1024 lanes in one round of loads
     // (the padded commit needs more registers per group: 3 there keeps the kernel at 8 waves per SIMD)
     // (float samples: 4 -- five float groups in flight spill at the 64 VGPRs of 8 waves per SIMD)
-    constexpr int UNR = PADDED ? 3 : (sizeof(T) == 4 ? (ONE_GROUP ? 4 : 3) : 5);
+    constexpr int UNR = PADDED ? 3 : (sizeof(T) == 4 ? (ONE_GROUP ? 5 : 3) : 5);
     u32x4 w[UNR];
     bool plain = false, plain_padded = false;
     if constexpr (!PADDED) plain = window_is_plain<UNR, T>(wg);  // (wave-uniform)

@@ -427,3 +427,34 @@ def test_planner_choices_for_the_named_configurations():
     # a filter too long for even a two-wave workgroup falls back to the exact kernel
     assert plan(192000, 8000, 10, 8)["fast_path"] in (0, 3)
     assert plan(192000, 1000, 10, 1)["fast_path"] == 0
+
+
+def test_generated_fir_loop_is_in_step_with_its_generator():
+    """csrc/fir_loop_asm.inc (the period kernel's FIR loop as gfx950 ISA) is committed generator output: it must be
+    what csrc/gen_fir_loop.py writes today, and every variant must hold exactly the instructions its shape
+    implies -- R x steps packed FMAs per bank, one sample read (two for single-channel lanes) per step, one
+    lgkmcnt(0) in front of each bank."""
+    import importlib.util
+    import re
+    path = os.path.join(ROOT, "node-speex-resampler_amd", "csrc", "gen_fir_loop.py")
+    spec = importlib.util.spec_from_file_location("gen_fir_loop", path)
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(os.path.dirname(path), "fir_loop_asm.inc")).read()
+    assert committed == gen.HEAD + "\n".join(v.function() for v in gen.variants()), "run python csrc/gen_fir_loop.py"
+    for v in gen.variants():
+        lines = v.lines()
+        loops = 3 if v.R == 10 else 1
+        fma = sum(1 for l in lines if l.startswith("v_pk_fma_f32"))
+        rows = (5 + 10 + 5) if v.R == 10 else v.R            # rows touched by the head / main / tail copies
+        assert fma == 2 * v.S * rows, (v.name, fma)
+        reads = sum(1 for l in lines if l.startswith("ds_read"))
+        assert reads == (loops * 2 + 1) * v.S * (2 if v.CT == 1 else 1), (v.name, reads)
+        assert sum(1 for l in lines if l == "s_waitcnt lgkmcnt(0)") == 2 * loops + 1, v.name
+        cvts = sum(1 for l in lines if l.startswith("v_cvt"))
+        assert cvts == (loops * 2 * v.S * 2 if v.w16 else 0), (v.name, cvts)
+        # taps live in s4..s73 minus the reserved s32, samples in VGPRs the launch bounds leave room for
+        used = set(gen.bank_regs(v.banks["A"]) + gen.bank_regs(v.banks["B"]))
+        named = set(int(r) for l in lines for pair in re.findall(r"s\[(\d+):(\d+)\]", l) for r in range(int(pair[0]), int(pair[1]) + 1))
+        assert named <= used and len(used) == 4 * v.S * v.R // 2 * 1 and 32 not in used and 4 <= min(used) and max(used) <= 73, v.name
+        assert max(v.vgprs()) < (64 if v.R == 10 else 128), v.name
