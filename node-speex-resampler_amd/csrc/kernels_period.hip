@@ -1036,6 +1036,13 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   //  profiles/r01_phases_cfg2_s1.txt: bare dispatch 1.7, descriptor + geometry 1.0, window staging 1.9,
   //  FIR loop 6.6, stores 3.0 -- 14.8 us if serial against 13.2 us measured: a launch that is a
   //  single generation of workgroups overlaps very little.)
+  // (Round 3 tried to give a one-generation launch twice the waves by sharing every R = 5 group between TWO waves,
+  //  half of the group's tap range each, partial sums meeting in LDS behind two barriers: 8 groups per workgroup,
+  //  4 workgroups per tile, two resident per CU = 8 waves per SIMD instead of 4, with the R = 5 instances brought
+  //  under 64 VGPRs on 20-tap banks for it.  Results equal within +-1 LSB, and slower: cfg2 one stream 12.05 ->
+  //  12.73 us, float 13.9 -> 14.8, mono 13.6 -> 14.0.  The dispatcher starts the 448 workgroups of 16 waves over
+  //  3.25 us (224: 0.65 us) -- ~2 200 waves per us --, every workgroup stages the whole 76 KB window again, and the
+  //  20-tap banks alone cost R = 5 0.2 us (44.1k->8k at 32 streams 304 -> 320 us).  Removed; profiles/r03_ab_ksplit.txt.)
   const uint32_t splits = split_count(t, tiles, n_streams, resident);
   static const uint32_t max_waves = std::getenv("SPEEXHIP_WAVES") ? std::atoi(std::getenv("SPEEXHIP_WAVES")) : 16;
   const uint32_t wave_groups = std::min<uint32_t>((t.groups + splits - 1) / splits, max_waves);
