@@ -4,11 +4,11 @@
 #   * rocprofv3 --kernel-trace --stats of the bench command          -> r0N_kernel_stats_<cfg>_s<S>.csv
 #   * HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (MI355X_MICROARCH.md; never
 #     combined with trace domains)                                      -> pmc_traffic.json, r0N_pmc_summary.json
-#   * SQ counters for cfg2 at both sizes
+#   * SQ counters for every config at both sizes; kernel stats for the EXACT-mode and float-I/O lines too
 # and, AFTER the PMC passes (bench.py reads profiles/pmc_traffic.json), the bench lines of every
 # workload (parity block in each; cpu_baseline in the 1-stream ones)   -> r0N_bench_lines.jsonl
 # Results land in gpurun_out/prof_r0N/; copy the summaries into profiles/ by hand.
-N=${1:-02}
+N=${1:-03}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_r$N; rm -rf $O; mkdir -p $O; cd $R
 cd /tmp && export TMPDIR=/tmp
 for CFG in cfg2 cfg3 cfg4 f3; do
@@ -20,10 +20,20 @@ for CFG in cfg2 cfg3 cfg4 f3; do
     done
   done
 done
-for S in 1 32; do
-  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS --output-format csv -d $O/pmc_sq_cfg2_s$S -- python3 $R/bench.py --streams $S --steps 12 --warmup 3 --reps 1 --preheat-ms 0 --no-cpu-baseline --no-parity > $O/pmc_sq_cfg2_s$S.log 2>&1
-  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq2_cfg2_s$S -- python3 $R/bench.py --streams $S --steps 12 --warmup 3 --reps 1 --preheat-ms 0 --no-cpu-baseline --no-parity > $O/pmc_sq2_cfg2_s$S.log 2>&1
+# SQ counters for every config at both sizes (round 3: cfg3 / cfg4 / F3 too), two passes of <= 8 counters
+for CFG in cfg2 cfg3 cfg4 f3; do
+  for S in 1 32; do
+    rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS --output-format csv -d $O/pmc_sq_${CFG}_s$S -- python3 $R/bench.py --config $CFG --streams $S --steps 12 --warmup 3 --reps 1 --preheat-ms 0 --no-cpu-baseline --no-parity > $O/pmc_sq_${CFG}_s$S.log 2>&1
+    rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq2_${CFG}_s$S -- python3 $R/bench.py --config $CFG --streams $S --steps 12 --warmup 3 --reps 1 --preheat-ms 0 --no-cpu-baseline --no-parity > $O/pmc_sq2_${CFG}_s$S.log 2>&1
+  done
 done
+# kernel stats of the lines that had none in round 2: EXACT mode (cfg2, cfg3) and float I/O
+for S in 1 32; do
+  ST=100; [ $S = 32 ] && ST=20
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg3exact_s$S -- python3 $R/bench.py --config cfg3 --mode exact --streams $S --steps $ST --warmup 5 --reps 3 --no-cpu-baseline --no-parity > $O/trace_cfg3exact_s$S.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg2float_s$S -- python3 $R/bench.py --io float --streams $S --steps $ST --warmup 5 --reps 3 --no-cpu-baseline --no-parity > $O/trace_cfg2float_s$S.log 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg2exact_s1 -- python3 $R/bench.py --mode exact --steps 100 --warmup 5 --reps 3 --no-cpu-baseline --no-parity > $O/trace_cfg2exact_s1.log 2>&1
 cd $R
 python3 - "$N" <<'PY'
 import csv, glob, json, collections, os, sys, shutil
@@ -73,6 +83,8 @@ for CFG in cfg3 cfg4 f3; do
   python bench.py --config $CFG --streams 32 --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 done
 python bench.py --mode exact --steps 200 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+python bench.py --config cfg3 --mode exact --steps 100 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+python bench.py --config cfg3 --mode exact --streams 32 --steps 20 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --io float --steps 300 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --io float --streams 32 --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_form.json 2>/dev/null
