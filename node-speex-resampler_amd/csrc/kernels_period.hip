@@ -1042,7 +1042,11 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   //  under 64 VGPRs on 20-tap banks for it.  Results equal within +-1 LSB, and slower: cfg2 one stream 12.05 ->
   //  12.73 us, float 13.9 -> 14.8, mono 13.6 -> 14.0.  The dispatcher starts the 448 workgroups of 16 waves over
   //  3.25 us (224: 0.65 us) -- ~2 200 waves per us --, every workgroup stages the whole 76 KB window again, and the
-  //  20-tap banks alone cost R = 5 0.2 us (44.1k->8k at 32 streams 304 -> 320 us).  Removed; profiles/r03_ab_ksplit.txt.)
+  //  20-tap banks alone cost R = 5 0.2 us (44.1k->8k at 32 streams 304 -> 320 us).  A second form kept the workgroup
+  //  count and let the eight HELPER waves of a workgroup that owns <= 8 groups compute the second half of each
+  //  group's trips instead of leaving: mono one stream 13.22 -> 13.94 us, a 441 000-frame stereo call 8.52 -> 9.02,
+  //  float 9.37 -> 10.10; only launches of a few tiles gained (16 384 frames 7.14 -> 6.36 us): the two barriers and
+  //  the pass through LDS cost more than the halved loop saves.  Removed; profiles/r03_ab_ksplit.txt.)
   const uint32_t splits = split_count(t, tiles, n_streams, resident);
   static const uint32_t max_waves = std::getenv("SPEEXHIP_WAVES") ? std::atoi(std::getenv("SPEEXHIP_WAVES")) : 16;
   const uint32_t wave_groups = std::min<uint32_t>((t.groups + splits - 1) / splits, max_waves);
