@@ -470,17 +470,16 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
     if constexpr (kReload) return load_k(pp);
     return p0;
   };
-  LaneCtx c;
-  uint32_t g_step, g;
-  {
-    const PeriodParams p = params();
-    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p, xshift, m_lo, m_cnt, lane);
-    g_step = p.wave_groups * nsplit;
-    g = zsplit * p.wave_groups + wave;
-    if (g >= p.groups) return;
-  }
+  // (the first group runs on the copy the prologue holds -- it dies at the loop, nothing later reads it --, every
+  //  further group on the copy read behind the previous one's loop: a read in FRONT of the first loop as well put
+  //  a scalar-load round trip between the staging barrier and the FIR of every workgroup, ~0.2 us that a
+  //  one-generation launch cannot hide)
+  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p0, xshift, m_lo, m_cnt, lane);
+  const uint32_t g_step = p0.wave_groups * nsplit;
+  uint32_t g = zsplit * p0.wave_groups + wave;
+  if (g >= p0.groups) return;
+  PeriodParams p = p0;
   for (;;) {
-    const PeriodParams p = params();  // (this side of the loop)
     f32x2 acc[R];  // .x = first channel of the pair, .y = second (unused when CT == 1)
 #pragma unroll
     for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
@@ -515,6 +514,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
     }
     g += g_step;
     if (g >= q.groups) return;
+    p = q;
   }
 }
 
