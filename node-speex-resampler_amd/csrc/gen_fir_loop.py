@@ -92,6 +92,18 @@ class Variant:
 
     def sample_reads(self, which, first_step):
         out = []
+        if self.CT == 2 and not self.w16 and self.S % 2 == 0 and os.environ.get("SPEEXHIP_GEN_READ2"):
+            # Experiment (SPEEXHIP_GEN_READ2=1 python csrc/gen_fir_loop.py): two steps per instruction -- the pairs of
+            # consecutive steps are consecutive registers.  Half the LDS instructions (8.2 M -> 4.1 M in the cfg2
+            # 32-stream launch), same time: cfg2 one stream 11.7-11.9 vs 11.7-12.2 us, 32 streams 191.5-193.7 vs
+            # 193.0-194.4, cfg4 550 vs 551, float 263 vs 262; 4 channels 415.8 -> 405.4.  Not the default.
+            for u in range(0, self.S, 2):
+                k = u if which == "A" else self.S + u
+                o0 = (first_step + u) * self.CF * 4 // 8
+                o1 = (first_step + u + 1) * self.CF * 4 // 8
+                p = self.pair(k)
+                out.append("ds_read2_b64 v[%d:%d], %%[addr] offset0:%d offset1:%d" % (p, p + 3, o0, o1))
+            return out
         for u in range(self.S):
             k = u if which == "A" else self.S + u
             o = (first_step + u) * self.CF * self.eb

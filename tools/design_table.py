@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Regenerates the rows of DESIGN.md section 5's table from profiles/r02_bench_lines.jsonl and
-profiles/r02_kernel_stats_*.csv (so that every figure there can be recomputed from a file in profiles/)."""
-import csv, json, os
+"""Regenerates the rows of DESIGN.md section 5's table from profiles/r03_bench_lines.jsonl and
+profiles/r03_kernel_stats_*.csv (so that every figure there can be recomputed from a file in profiles/).
+usage: python tools/design_table.py [ROUND, default 03]"""
+import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rows = [json.loads(l) for l in open(os.path.join(ROOT, 'profiles/r02_bench_lines.jsonl'))]
+N = sys.argv[1] if len(sys.argv) > 1 else '03'
+rows = [json.loads(l) for l in open(os.path.join(ROOT, 'profiles/r%s_bench_lines.jsonl' % N))]
 
 def avg(cfg, s):
-    for r in csv.DictReader(open(os.path.join(ROOT, 'profiles/r02_kernel_stats_%s_s%d.csv' % (cfg, s)))):
+    for r in csv.DictReader(open(os.path.join(ROOT, 'profiles/r%s_kernel_stats_%s_s%d.csv' % (N, cfg, s)))):
         if 'resample_' in r['Name']:
             return float(r['AverageNs']) / 1e3
 
@@ -37,11 +39,15 @@ two('cfg3 24k→48k mono q10 (slide kernel; fp32 FMA chain where the reference s
 two('cfg4 48k→44.1k 8 ch q5 (period kernel, padded window), 1 / 32 streams', 'configs[3]', 'cfg4')
 two('F3 24k→48k mono q5 (slide kernel), 1 / 32 streams', 'SURVEY F3', 'f3')
 fa, fb = c('configs[1]', 1, 'fast', 'float'), c('configs[1]', 32, 'fast', 'float')
-out.append('| cfg2, float I/O (`--io float`), 1 / 32 streams | %.1f / %.1f µs | — | %s / %s | %s / %s %% | %s / %s %% | %s / %s %% | — |' %
-           (L(fa), L(fb), num(fa['value']), num(fb['value']), pct(fa['roofline']['frac']), pct(fb['roofline']['frac']),
+out.append('| cfg2, float I/O (`--io float`), 1 / 32 streams | %.1f / %.1f µs | %.1f / %.1f | %s / %s | %s / %s %% | %s / %s %% | %s / %s %% | — |' %
+           (L(fa), L(fb), avg('cfg2float', 1), avg('cfg2float', 32), num(fa['value']), num(fb['value']), pct(fa['roofline']['frac']), pct(fb['roofline']['frac']),
             pct(fa['roofline']['read_only_frac']), pct(fb['roofline']['read_only_frac']), pct(fa['valu']['frac']), pct(fb['valu']['frac'])))
 e = c('configs[1]', 1, 'exact')
-out.append('| cfg2 EXACT mode, 1 stream | %.1f µs | — | %s | %s %% | %s %% | — | — |' % (L(e), num(e['value']), pct(e['roofline']['frac']), pct(e['roofline']['read_only_frac'])))
+out.append('| cfg2 EXACT mode (bit-identical to the reference), 1 stream | %.1f µs | %.1f µs | %s | %s %% | %s %% | — | — |' % (L(e), avg('cfg2exact', 1), num(e['value']), pct(e['roofline']['frac']), pct(e['roofline']['read_only_frac'])))
+ea, eb = c('configs[2]', 1, 'exact'), c('configs[2]', 32, 'exact')
+out.append('| cfg3 EXACT mode: configs[2] at the reference\'s precision (fp64 sums of fp32 products, `resample.c:409-417`), 1 / 32 streams | %.1f / %.1f µs | %.1f / %.1f | %s / %s | %s / %s %% | %s / %s %% | — | — |' %
+           (L(ea), L(eb), avg('cfg3exact', 1), avg('cfg3exact', 32), num(ea['value']), num(eb['value']), pct(ea['roofline']['frac']), pct(eb['roofline']['frac']),
+            pct(ea['roofline']['read_only_frac']), pct(eb['roofline']['read_only_frac'])))
 cp = [c(w, 1)['cpu_baseline']['value'] for w in ('configs[1]', 'configs[2]', 'configs[3]', 'SURVEY F3')]
 out.append("| CPU baseline: the reference's own C natively compiled (`oracle/_ref`, not the WASM build), 1 host core, cfg2 / cfg3 / cfg4 / F3 | — | — | %.1f / %.1f / %.1f / %.1f | — | — | — | — |" % tuple(cp))
 ee = [c(w, 1)['end_to_end'] for w in ('configs[1]', 'configs[2]', 'configs[3]', 'SURVEY F3')]
