@@ -164,7 +164,11 @@ SPEEXHIP_API const char *speexhip_resampler_strerror(int err);
  * `hip_stream` (a hipStream_t passed as void*; NULL = the default stream) and the call
  * returns without waiting for the GPU.  The stream position advances on the host at once
  * (it is integer arithmetic, independent of the audio), so *in_len / *out_len are final on
- * return.  d_in must stay valid until the stream has executed the call. */
+ * return.  d_in must stay valid until the stream has executed the call.  `hip_stream` itself must
+ * stay valid until the state's NEXT call of any kind (processing, control, destroy): calls on one
+ * state are ordered, so the next call -- on whatever stream -- first waits for this one on the
+ * device, and control calls and destroy wait for it on the host (for this state's last call only,
+ * never for the device: other states' launches keep running). */
 SPEEXHIP_API int speexhip_resampler_process_interleaved_int_device(SpeexHipResamplerState *st,
                                                                    const int16_t *d_in,
                                                                    uint32_t *in_len, int16_t *d_out,

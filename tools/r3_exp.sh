@@ -1,15 +1,8 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r3; mkdir -p $O; cd $R
-E1=$O/exp_$(date +%H%M%S).txt
-A=$R/node-speex-resampler_amd/libspeexhip.so; B=$R/node-speex-resampler_amd/ab/libspeexhip_b64.so
-{
-for rep in 1 2 3; do
-bash tools/gpu_ab.sh SPEEXHIP_LIB_PATH "$B $A" --steps 300
-bash tools/gpu_ab.sh SPEEXHIP_LIB_PATH "$B $A" --streams 32 --steps 100
-done
-bash tools/gpu_ab.sh SPEEXHIP_LIB_PATH "$B $A" --config cfg4 --streams 32 --steps 60
-bash tools/gpu_ab.sh SPEEXHIP_LIB_PATH "$B $A" --custom 4,44100,48000,7 --streams 32 --steps 60
-bash tools/gpu_ab.sh SPEEXHIP_LIB_PATH "$B $A" --io float --streams 32 --steps 60
-bash tools/gpu_ab.sh SPEEXHIP_LIB_PATH "$B $A" --custom 2,48000,44100,7 --streams 32 --steps 100
-} > $E1 2>&1
-cat $E1
+python tools/stamps.py --streams 1 --launches 2 > $O/stamps_cfg2_s1.txt 2>&1
+python tools/stamps.py --streams 32 --launches 2 > $O/stamps_cfg2_s32.txt 2>&1
+python tools/stamps.py --streams 32 --launches 1 --config cfg4 > $O/stamps_cfg4_s32.txt 2>&1
+python tools/stamps.py --streams 2 --launches 1 > $O/stamps_cfg2_s2.txt 2>&1
+bash tools/perf_sweep.sh > $O/perf_sweep.txt 2>&1
+tail -5 $O/perf_sweep.txt
