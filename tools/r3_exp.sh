@@ -1,8 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r3; mkdir -p $O; cd $R
-python tools/stamps.py --streams 1 --launches 2 > $O/stamps_cfg2_s1.txt 2>&1
-python tools/stamps.py --streams 32 --launches 2 > $O/stamps_cfg2_s32.txt 2>&1
-python tools/stamps.py --streams 32 --launches 1 --config cfg4 > $O/stamps_cfg4_s32.txt 2>&1
-python tools/stamps.py --streams 2 --launches 1 > $O/stamps_cfg2_s2.txt 2>&1
-bash tools/perf_sweep.sh > $O/perf_sweep.txt 2>&1
-tail -5 $O/perf_sweep.txt
+E1=$O/fuzz2_$(date +%H%M%S).txt
+{
+python tools/fuzz_gpu.py --seconds 300 --seed 3101 --batch 2>&1 | tail -6
+SPEEXHIP_FORCE_W16=1 python tools/fuzz_gpu.py --seconds 150 --seed 3102 2>&1 | tail -6
+python tools/fuzz_gpu.py --seconds 150 --seed 3103 --max-frames 1200000 --batch 2>&1 | tail -6
+} > $E1 2>&1
+cat $E1
