@@ -143,7 +143,8 @@ __device__ __forceinline__ WindowGeom window_geom(const StreamDesc &d, uint32_t 
 template <typename T>
 __device__ __forceinline__ bool window_geom_plain(const StreamDesc &d, uint32_t channels, uint32_t num,
                                                   uint32_t tail_frames, uint32_t m_lo, uint32_t m_cnt, uint32_t nthr,
-                                                  uint32_t pad, uint32_t period_magic, WindowGeom *w) {
+                                                  uint32_t pad, uint32_t period_magic, WindowGeom *w,
+                                                  uint32_t pad_every = 0) {
   constexpr int GS = PerLoad<T>::value;
   const int64_t hist_elems = static_cast<int64_t>(d.hist_frames) * channels;
   const int64_t q_lo = (static_cast<int64_t>(d.base_shift) + static_cast<int64_t>(m_lo) * num) * channels - hist_elems;
@@ -157,7 +158,7 @@ __device__ __forceinline__ bool window_geom_plain(const StreamDesc &d, uint32_t 
     return false;
   w->nthr = nthr;
   w->pad = pad;
-  w->period_elems = num * channels;
+  w->period_elems = pad_every ? pad_every : num * channels;
   w->period_magic = period_magic;
   w->hist_elems = hist_elems;
   w->in_elems = in_elems;

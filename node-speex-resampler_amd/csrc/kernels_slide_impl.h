@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   constexpr int CW = PAIR_CH ? 2 : 1;          // floats a lane reads per frame
   const uint32_t C = DENSE ? static_cast<uint32_t>(CW) : p.channels;
   const uint32_t K_end = d.k_shift + d.n_out;
-  const uint32_t m_total = (K_end + p.den - 1) / p.den;
+  const uint32_t m_total = d.m_total;  // ceil(K_end / den), from the host (round 3)
   const uint32_t tile_periods = p.blocks_per_tile * P;  // lane blocks x P
   const uint32_t m_lo = blockIdx.x * tile_periods;
   if (m_lo >= m_total) return;
@@ -94,8 +94,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   // ---- stage: frames [f0, f0 + m_cnt*num + row_len + one row) of V as float, in rows of P*NUM
   //      frames `row_stride` floats apart: the shared loader's padded image with the row as its
   //      padding period (16-byte loads, all in flight at once; device_helpers.h) ----
-  const WindowGeom wg = window_geom<T>(d, C, NUM, NUM + p.row_len + P * NUM, m_lo, m_cnt, p.threads,
-                                       p.row_stride - P * NUM * C, p.row_magic, P * NUM * C);
+  // (tiles inside the call's input -- all but the first and last few -- get their geometry from a dozen scalar
+  //  instructions: device_helpers.h, window_geom_plain)
+  WindowGeom wg;
+  if (!window_geom_plain<T>(d, C, NUM, NUM + p.row_len + P * NUM, m_lo, m_cnt, p.threads, p.row_stride - P * NUM * C,
+                            p.row_magic, &wg, P * NUM * C))
+    wg = window_geom<T>(d, C, NUM, NUM + p.row_len + P * NUM, m_lo, m_cnt, p.threads, p.row_stride - P * NUM * C,
+                        p.row_magic, P * NUM * C);
   if (!(p.skip & 2u)) {
     u32x4 w[4];
     window_fetch<4, T>(wg, w);
