@@ -24,6 +24,7 @@ ap.add_argument("--config", default="cfg2")
 ap.add_argument("--frames", type=int, default=1 << 20)
 ap.add_argument("--launches", type=int, default=3)
 ap.add_argument("--custom", default=None, help="channels,in_rate,out_rate,quality (overrides --config)")
+ap.add_argument("--io", default="int16", choices=["int16", "float"])
 a = ap.parse_args()
 ch, fi, fo, q = bench.CONFIGS[a.config] if not a.custom else tuple(int(v) for v in a.custom.split(","))
 S, F = a.streams, a.frames
@@ -32,6 +33,9 @@ b = speexhip.Batch(S, ch, fi, fo, q)
 x = torch.from_numpy(np.stack([bench.lcg_pcm(F * ch, 12345 + s).reshape(F, ch) for s in range(S)])).cuda()
 xs = [x, torch.roll(x, 17, 1).contiguous(), torch.roll(x, 34, 1).contiguous()]
 y = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+if a.io == "float":
+    xs = [v.to(torch.float32) for v in xs]
+    y = y.to(torch.float32)
 sp = torch.cuda.current_stream().cuda_stream
 lib = speexhip.lib()
 lib.speexhip_debug_stamps.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
@@ -44,10 +48,10 @@ for launch in range(a.launches):
     i = 0
     while time.perf_counter() - t0 < 0.3:
         for _ in range(32):
-            b.process_device(xs[i % 3].data_ptr(), F * ch, F, y.data_ptr(), cap * ch, cap, sp); i += 1
+            b.process_device(xs[i % 3].data_ptr(), F * ch, F, y.data_ptr(), cap * ch, cap, sp, a.io == 'float'); i += 1
         torch.cuda.synchronize()
     assert lib.speexhip_debug_stamps(None, 0, 1) == 0
-    b.process_device(xs[launch % 3].data_ptr(), F * ch, F, y.data_ptr(), cap * ch, cap, sp)
+    b.process_device(xs[launch % 3].data_ptr(), F * ch, F, y.data_ptr(), cap * ch, cap, sp, a.io == 'float')
     buf = np.zeros(N * W, np.uint64)
     assert lib.speexhip_debug_stamps(buf.ctypes.data, buf.size, 0) == 0
     st = buf.reshape(N, W).astype(np.int64)
