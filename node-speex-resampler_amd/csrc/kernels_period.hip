@@ -1029,7 +1029,18 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // and measured 224 vs 205 us at 32 streams, 703 vs 604 us on 8 channels: a tile's FIR time varies by
   // +-20 % (profiles/r02_stamps_cfg2_s32.txt), so a static share of 7 tiles per workgroup ends with
   // the slowest of 512, where the dispatcher hands the next tile to whichever CU is free; and what a
-  // fresh workgroup costs between two FIR loops is hidden behind the other workgroup's FIR anyway.)
+  // fresh workgroup costs between two FIR loops is hidden behind the other workgroup's FIR anyway.
+  // Round 3 took the static share out of the argument: 512 workgroups drawing their next tile from a
+  // device counter (the atomic issued at the top of a tile, in flight behind its staging loads; the
+  // number handed round through LDS behind two bare barriers; no wait for the tile's stores).  Results
+  // equal; 32 streams 195 -> 204-206 us, 64 streams 395 -> 408, mono 123 -> 143, FIR only 162 -> 169
+  // (profiles/r03_walk_ab.txt).  The reason is phase: the two workgroups the dispatcher keeps on a CU
+  // start half a tile apart and stay there (stamps: neighbour offset 10-12 us of a 25 us cycle), so one
+  // stages and stores while the other is in its FIR loop -- and a workgroup alone on its CU runs its loop
+  // 1.65x faster than each of two (12.4 vs 20.5 us); walkers start together and stay in step: both in
+  // their FIR loops, then both in their memory phases with nothing issuing FMAs.  What a walk could save
+  // once staggered (slot turnover 1.5 us + half the prologue per tile) is ~3 % of a launch; the one-stream
+  // launch lost 0.4 us to the loop around the kernel body.  Removed.)
   // When one workgroup per tile leaves CUs idle (one short stream), the phase groups of a tile are
   // split over several workgroups.
   // (Phase costs of the single-stream launch, R = 10, rocprofv3 with parts skipped,

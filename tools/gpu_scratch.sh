@@ -1,7 +1,13 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/r3; mkdir -p $O
-for sk in 0 256; do
-  echo "== float cfg2 s32 SPEEXHIP_SKIP=$sk"; SPEEXHIP_SKIP=$sk python tools/stamps.py --streams 32 --io float --launches 1 2>&1 | head -22
-done > $O/stamps_float.txt 2>&1
-echo "== int16 cfg2 s32" >> $O/stamps_float.txt; python tools/stamps.py --streams 32 --launches 1 2>&1 | head -22 >> $O/stamps_float.txt
-cat $O/stamps_float.txt
+{
+SPEEXHIP_WALK=1 SPEEXHIP_WALK_VERBOSE=1 timeout 120 python bench.py --no-cpu-baseline --reps 1 --streams 32 --config cfg4 2>&1 | tail -12 | cut -c1-400
+for sk in 8 2 10; do
+for w in 0 1; do
+ echo "SKIP=$sk WALK=$w"; SPEEXHIP_SKIP=$sk SPEEXHIP_WALK=$w timeout 120 python bench.py --no-cpu-baseline --no-parity --reps 3 --streams 32 2>/dev/null | python3 -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print(d['roofline']['launch_us'])"
+done; done
+} > $O/walk_ab3.txt 2>&1
+cat $O/walk_ab3.txt
