@@ -84,7 +84,6 @@ struct PeriodParams {
   uint32_t wave_groups;   // waves per workgroup; wave w of split z takes groups z*wave_groups+w, ...
   uint32_t tail_frames;   // input frames a period needs beyond its start
   uint32_t history_block; // one-shot form: blockIdx.x of the workgroup that rolls the history
-  uint32_t image_stride;  // != 0: outputs leave through an LDS image, rows this many dwords apart
   uint32_t pad;           // LDS bank padding: floats inserted after every period of the window
   uint32_t wrap_step;     // iterations between two period boundaries of a group's window (num/4)
   uint32_t period_magic;  // ceil(2^32 / (num*channels)): division-free period index in the padded image

@@ -57,6 +57,7 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef __attribute__((address_space(1))) u32x4_a4 g_u32x4_a4;
 typedef __attribute__((address_space(1))) u32x2_a4 g_u32x2_a4;
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 // acc += tap * x on both halves, the tap being element HI of a wave-uniform pair held in SGPRs.
 // Written as one instruction so that the odd element is selected in place with op_sel: left to
@@ -321,19 +322,55 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
       const int64_t hi64 = min(static_cast<int64_t>(R), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * R,
                                                            static_cast<int64_t>(d.n_out) - k0));
       G<T> *o = out_ptr<T>(d) + k0 * static_cast<int64_t>(C) + cg;
-      if constexpr (ONE_GROUP && sizeof(T) == 2 && R % 2 == 0) {
-        // mono int16: the lane's R samples are R/2 consecutive dwords when they start on one
-        if (lo64 == 0 && hi64 == R && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
-          uint32_t w[R / 2];
+      if constexpr (ONE_GROUP && sizeof(T) == 2) {
+        // mono int16: the lane's R samples leave as whole dwords -- 16 + 4 bytes (R = 10) or 8 (R = 5) -- around at
+        // most two odd samples: the first when the run starts on the upper half of a dword (k_shift odd, or every
+        // second period of an odd den), the last when what remains is odd.  (Until round 3 a run that started on
+        // an upper half went out as R stores of 2 bytes, and so did every run of R = 5: a store instruction costs
+        // one line request per lane whatever its width.)
+        if (lo64 == 0 && hi64 == R && (reinterpret_cast<uintptr_t>(d.out) & 1u) == 0) {
+          float v[R];
 #pragma unroll
-          for (int j = 0; j < R / 2; j++)
-            w[j] = half == 0 ? round_pack_pcm(acc[2 * j].x, acc[2 * j + 1].x) : round_pack_pcm(acc[2 * j].y, acc[2 * j + 1].y);
-          g_u32 *od = (g_u32 *)o;
+          for (int i = 0; i < R; i++) v[i] = half == 0 ? acc[i].x : acc[i].y;
+          auto dwords = [&](g_i16 *at, auto first_c, auto count_c) {  // samples [first, first + 2*count) as dwords
+            constexpr int F = decltype(first_c)::value, N = decltype(count_c)::value;
+            uint32_t w[N > 0 ? N : 1];
 #pragma unroll
-          for (int j = 0; j + 4 <= R / 2; j += 4) *(g_u32x4_a4 *)(od + j) = u32x4_a4{w[j], w[j + 1], w[j + 2], w[j + 3]};
-          if constexpr ((R / 2) % 4 >= 2)
-            *(g_u32x2_a4 *)(od + R / 2 / 4 * 4) = u32x2_a4{w[R / 2 / 4 * 4], w[R / 2 / 4 * 4 + 1]};
-          if constexpr ((R / 2) % 2 != 0) od[R / 2 - 1] = w[R / 2 - 1];
+            for (int j = 0; j < N; j++) w[j] = round_pack_pcm(v[F + 2 * j], v[F + 2 * j + 1]);
+            g_u32 *od = (g_u32 *)at;
+#pragma unroll
+            for (int j = 0; j + 4 <= N; j += 4) *(g_u32x4_a4 *)(od + j) = u32x4_a4{w[j], w[j + 1], w[j + 2], w[j + 3]};
+            if constexpr (N % 4 >= 2) *(g_u32x2_a4 *)(od + N / 4 * 4) = u32x2_a4{w[N / 4 * 4], w[N / 4 * 4 + 1]};
+            if constexpr (N % 2 != 0) od[N - 1] = w[N - 1];
+          };
+          auto single = [&](int i) { o[i] = static_cast<int16_t>(round_pack_pcm(v[i], 0.f) & 0xffffu); };
+          if ((reinterpret_cast<uintptr_t>(o) & 2u) == 0) {
+            dwords(o, std::integral_constant<int, 0>(), std::integral_constant<int, R / 2>());
+            if constexpr (R % 2 != 0) single(R - 1);
+          } else {
+            single(0);
+            dwords(o + 1, std::integral_constant<int, 1>(), std::integral_constant<int, (R - 1) / 2>());
+            if constexpr (R % 2 == 0) single(R - 1);
+          }
+          continue;
+        }
+      }
+      if constexpr (ONE_GROUP && sizeof(T) == 4) {
+        // mono float: the lane's R samples are R consecutive floats -- 16 + 16 + 8 bytes instead of R stores of 4
+        // (a store instruction costs one line request per lane whatever its width: 20 of them per lane made a
+        //  tile's store phase 4.5 us and 32 float mono streams of 44.1k -> 48k 228 us against 123 for int16)
+        if (lo64 == 0 && hi64 == R) {
+          float v[R];
+#pragma unroll
+          for (int i = 0; i < R; i++) v[i] = half == 0 ? acc[i].x : acc[i].y;
+          // (opaque copies, as for the stereo float stores below)
+#pragma unroll
+          for (int i = 0; i < R; i++) asm volatile("" : "+v"(v[i]));
+          G<float> *of = (G<float> *)o;
+#pragma unroll
+          for (int i = 0; i + 4 <= R; i += 4) *(G<f32x4_a4> *)(of + i) = f32x4_a4{v[i], v[i + 1], v[i + 2], v[i + 3]};
+          if constexpr (R % 4 >= 2) *(G<f32x2_a4> *)(of + R / 4 * 4) = f32x2_a4{v[R / 4 * 4], v[R / 4 * 4 + 1]};
+          if constexpr (R % 2 != 0) of[R - 1] = v[R - 1];
           continue;
         }
       }
@@ -368,17 +405,16 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
         *(G<f32x4_a4> *)(o + 2 * i) = f32x4_a4{a0, a1, a2, a3};
       }
-      if constexpr (R % 2 != 0) {
-        o[2 * (R - 1)] = acc[R - 1].x;
-        o[2 * (R - 1) + 1] = acc[R - 1].y;
-      }
+      if constexpr (R % 2 != 0) *(G<f32x2_a4> *)(o + 2 * (R - 1)) = f32x2_a4{acc[R - 1].x, acc[R - 1].y};
       return;
     }
 #pragma unroll
     for (int i = 0; i < R; i++, o += C) {
       if (i < i_lo || i >= i_hi) continue;
-      o[0] = acc[i].x;
-      if (CT == 2) o[1] = acc[i].y;
+      if constexpr (CT == 2)
+        *(G<f32x2_a4> *)o = f32x2_a4{acc[i].x, acc[i].y};  // one 8-byte store (the buffer is only known 4-byte aligned)
+      else
+        o[0] = acc[i].x;
     }
   } else {
     g_i16 *o = out_ptr<int16_t>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
@@ -518,103 +554,13 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
   }
 }
 
-// Mono int16, one pass over the groups: the tile's outputs -- samples K = m*den + r of 128
-// consecutive periods -- are one contiguous run in HBM, but a lane holds only R consecutive
-// samples of each of its two periods (20 bytes at a 2*den-byte stride), and a store instruction
-// costs one L2 request per lane whatever its width: per-lane stores alone take longer than the FIR
-// (121 vs 108 us for 32 streams of 44.1k->48k).  Here the workgroup lays its results out as an
-// image in LDS (the window is dead by then), one row per period, and writes whole rows: 16 bytes
-// per lane, consecutive lanes, full cache lines.  Lanes deposit their samples with 2-byte LDS
-// writes, shifted by one sample when the row starts on an odd sample of the output buffer, so that
-// image dwords and output dwords coincide.  Row stride odd (in dwords): the lanes of a half-wave,
-// one row apart, deposit into distinct banks.
-// (The stereo counterpart -- 40-byte pieces per lane -- was built too: stores alone 74 -> 48 us, but
-//  the launch as a whole within noise at every size, 210.8-213.5 vs 212.4-213.5 us at 32 streams and
-//  slower below; removed.  Round 2 built it for frames of several channel pairs as well -- 4-byte
-//  pieces per lane there, image [period][frame][pair], 16-byte row stores: 4 ch 44.1k->48k 431 -> 421 us,
-//  but 8 ch 48k->44.1k 621 -> 644 us and 6 ch 670 -> 735 us at 32 streams: the two barriers and the
-//  serial copy-out cost more than the per-lane stores they replace; removed.)
-template <int R, bool PADDED, bool W16 = false>
-__device__ __forceinline__ void fir_tile_rows_mono(KParams pp, const float *__restrict__ rows, KDesc dp, float *xs,
-                                                   uint32_t xshift, uint32_t m_lo, uint32_t m_cnt, uint32_t wave,
-                                                   uint32_t lane, uint32_t zsplit) {
-  // (parameters and descriptor are read again on either side of the ISA loop: see KParams)
-  LaneCtx c;
-  uint32_t g0, g;
-  bool valid;
-  f32x2 acc[R];
-#pragma unroll
-  for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
-  {
-    const PeriodParams p = load_k(pp);
-    c = lane_ctx<1, true, PADDED>(p, xshift, m_lo, m_cnt, lane);
-    g0 = zsplit * p.wave_groups;
-    g = g0 + wave;
-    valid = g < p.groups;
-    if (valid) fir_group<R, 1, PADDED, 1, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
-  }
-  __syncthreads();  // every wave is done with the window
-  const PeriodParams p = load_k(pp);
-  const StreamDesc d = load_k(dp);
-  if (p.skip & 8u) return;
-
-  // samples of a row held by this workgroup (a share past the last group holds none)
-  const uint32_t cols = g0 * R < p.den ? min(p.wave_groups * R, p.den - g0 * R) : 0u;
-  const uint32_t stride = p.image_stride;                          // dwords, odd
-  // parity of the output buffer's sample index at which row r starts (alternates when den is odd)
-  const int64_t k_tile = static_cast<int64_t>(m_lo) * p.den + g0 * R - d.k_shift;
-  const uint32_t sh0 = static_cast<uint32_t>((static_cast<int64_t>(reinterpret_cast<uintptr_t>(d.out) >> 1) + k_tile) & 1);
-  auto shift_of = [&](uint32_t r) { return (sh0 + (r & p.den)) & 1u; };  // (sh0 + r*den) & 1
-  int16_t *img16 = reinterpret_cast<int16_t *>(xs);
-  if (valid) {
-    const uint32_t real = min(static_cast<uint32_t>(R), p.den - g * R);
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      if (half == 0 ? !c.live : !c.live_b) continue;
-      const uint32_t r = lane + half * p.half_periods;
-      int16_t *row = img16 + static_cast<size_t>(r) * stride * 2 + wave * R + shift_of(r);
-#pragma unroll
-      for (int i = 0; i < R; i++)
-        if (i < static_cast<int>(real))
-          row[i] = static_cast<int16_t>(round_pack_pcm(half == 0 ? acc[i].x : acc[i].y, 0.f) & 0xffffu);
-    }
-  }
-  __syncthreads();
-
-  // copy-out: wave w takes rows w, w + nw, ...; lane l the dwords [4l, 4l+4) of the row; image
-  // dword j holds the row's samples 2j - sh and 2j + 1 - sh
-  const uint32_t nw = p.threads >> 6;
-  const uint32_t *img = reinterpret_cast<const uint32_t *>(xs);
-  for (uint32_t m = wave; m < m_cnt; m += nw) {
-    const uint32_t sh = shift_of(m);
-    const uint32_t n_dw = (cols + sh + 1) / 2;
-    const int64_t k0 = k_tile + static_cast<int64_t>(m) * p.den;  // output index of the row's sample 0
-    const int64_t lo = k0 < 0 ? -k0 : 0;
-    const int64_t hi = min<int64_t>(cols, static_cast<int64_t>(d.n_out) - k0);
-    const uint32_t *row = img + static_cast<size_t>(m) * stride;
-    g_i16 *o16 = out_ptr<int16_t>(d) + (k0 - sh);  // dword-aligned by the choice of sh
-    for (uint32_t j = 4 * lane; j < n_dw; j += 256) {
-      const uint32_t v[4] = {row[j], row[j + 1], row[j + 2], row[j + 3]};  // (rows carry 4 dwords of slack)
-      const int64_t s0 = 2 * static_cast<int64_t>(j) - sh;                  // row sample of v[0]'s low half
-      if (s0 >= lo && s0 + 8 <= hi) {
-        *(g_u32x4_a4 *)(o16 + 2 * j) = u32x4_a4{v[0], v[1], v[2], v[3]};
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int64_t a = s0 + 2 * e;
-          const bool lo_ok = a >= lo && a < hi, hi_ok = a + 1 >= lo && a + 1 < hi;
-          if (lo_ok && hi_ok)
-            *(g_u32 *)(o16 + 2 * (j + e)) = v[e];
-          else if (lo_ok)
-            o16[2 * (j + e)] = static_cast<int16_t>(v[e] & 0xffffu);
-          else if (hi_ok)
-            o16[2 * (j + e) + 1] = static_cast<int16_t>(v[e] >> 16);
-        }
-      }
-    }
-  }
-}
-
+// (Mono int16 left through an LDS image -- one row per period, whole rows written 16 bytes per lane -- from
+//  round 1 to round 3 for launches that fill the chip: 160 -> 138 us for 32 streams of 44.1k -> 48k when a lane's
+//  20-byte runs cost five stores.  With the runs packed into dwords at either alignment (store_group) the
+//  per-lane stores are faster at every size: 32 streams 122 -> 112 us, 16 streams 72.5 -> 62.7, 8 streams
+//  42.4 -> 33.5, 64 streams 229 -> 210, 44.1k -> 8k 176 -> 165, q10 199 -> 192; the image path is gone
+//  (profiles/r03_mono_stores_ab.txt).  Its stereo and multi-pair counterparts never paid: 40-byte pieces per
+//  lane, stores alone 74 -> 48 us but the launch within noise; 4 ch 431 -> 421 us, 8 ch 621 -> 644, 6 ch 670 -> 735.)
 // <= 80 SGPRs: the hardware admits 8 waves per SIMD (two 16-wave workgroups per CU) only then
 // (MI355X_MICROARCH.md, residency; measured again with caps of 88, 90 and 96: 206 -> 260 us);
 // the compiler alone settles at ~106.  (A second, uncapped build of the kernel for launches of at
@@ -706,15 +652,6 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
   if (p.skip & 128u) return;  // diagnostics: prologue + staging only
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
-  if constexpr (ONE_GROUP && CT == 1 && sizeof(T) == 2) {
-    if (p.image_stride != 0) {
-      const __attribute__((address_space(4))) KernArgs *ka =
-          (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-      const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
-      fir_tile_rows_mono<R, PADDED, W16>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
-      return;
-    }
-  }
   const __attribute__((address_space(4))) KernArgs *ka =
       (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
@@ -1080,18 +1017,6 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   p.wrap_step = f.num % 4 == 0 ? f.num / 4 : 0x40000000u;
   p.period_magic = period_magic_of(f.num * channels);
   p.history_block = max_periods == 0 ? 0 : tiles;
-  static const int env_rows = std::getenv("SPEEXHIP_ROWS") ? std::atoi(std::getenv("SPEEXHIP_ROWS")) : -1;
-  p.image_stride = 0;
-  // mono int16 (fir_tile_rows_mono): per-lane stores of 20-byte pieces cost more than the FIR, so the
-  // image pays as soon as the launch fills the chip (44.1k->48k: 8 streams 52.7 -> 46.8 us, 32 streams
-  // 159.6 -> 137.6 us; but one stream 16.6 -> 27.4 us: its few waves copy 16 rows each, in series)
-  // (odd den -- rows alternate between even and odd starts -- works too, but measured no gain:
-  //  48k->44.1k q5 mono 146 -> 153 us; it stays reachable with SPEEXHIP_ROWS=1 for the tests)
-  if ((env_rows > 0 || (env_rows < 0 && static_cast<uint64_t>(tiles) * n_streams * 2 >= resident && f.den % 2 == 0)) &&
-      !float_io && t.ct == 1 && t.cgroups == 1 && wave_groups * splits >= t.groups) {
-    const uint32_t stride = ((wave_groups * t.r + 1) / 2 + 5) | 1u;  // samples/2 + the shift + 4 dwords of slack, odd
-    if (static_cast<size_t>(stride) * t.lane_periods * 4 + 16 <= t.window_bytes) p.image_stride = stride;
-  }
   // (The tail: a launch of several generations ends ragged -- profiles/r02_stamps_cfg2_s32.txt: the last
   //  tenth of the workgroups finish over 22 of 204 us; 64 streams take 404 us against 209 for 32, so ~14 us
   //  of a launch are start + tail.  Tried: the tiles of the last 1-12 streams -- the last ones dispatched --
@@ -1109,7 +1034,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // A workgroup that owns only a share of the groups still stages the whole window: lend it the
   // waves it has no groups for, they leave after the staging barrier.
   static const int env_helpers = std::getenv("SPEEXHIP_HELPERS") ? std::atoi(std::getenv("SPEEXHIP_HELPERS")) : 1;
-  const bool helpers = env_helpers != 0 && splits > 1 && p.image_stride == 0;  // (the image paths have barriers of their own)
+  const bool helpers = env_helpers != 0 && splits > 1;
   const uint32_t threads = (helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
   p.threads = threads;
   // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8

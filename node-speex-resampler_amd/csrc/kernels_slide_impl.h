@@ -283,8 +283,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
         *(G<f32x4_a4> *)(o0 + 2 * q) = f32x4_a4{a.x, a.y, b.x, b.y};
       }
       if constexpr ((P * NP) % 2 != 0) {  // (one period per lane, one pair per period: the n:1 shapes)
-        o0[2 * (P * NP - 1)] = acc[P - 1][NP - 1].x;
-        o0[2 * (P * NP - 1) + 1] = acc[P - 1][NP - 1].y;
+        typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+        *(G<f32x2_a4> *)(o0 + 2 * (P * NP - 1)) = f32x2_a4{acc[P - 1][NP - 1].x, acc[P - 1][NP - 1].y};
       }
       return;
     }
@@ -325,6 +325,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
       if constexpr ((P * NP) % 2 != 0) *(G<uint32_t> *)(o0 + 2 * (P * NP - 1)) = v[P * NP - 1];
     }
     return;
+  }
+  if constexpr (!PAIR_CH && P * NP >= 2) {
+    // mono, the run starts on the upper half of a dword (k_shift odd): one sample, the dwords that straddle
+    // the pairs (v_alignbit), one sample -- not 2*P*NP stores of 2 bytes
+    if (dense && inside && (reinterpret_cast<uintptr_t>(o0) & 3u) == 2) {
+      constexpr int N = P * NP - 1;
+      uint32_t s[N];
+#pragma unroll
+      for (int q = 0; q < N; q++) s[q] = __builtin_amdgcn_alignbit(v[q + 1], v[q], 16);
+      o0[0] = static_cast<int16_t>(v[0] & 0xffffu);
+      G<uint32_t> *od = (G<uint32_t> *)(o0 + 1);
+      typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+      typedef __attribute__((address_space(1))) u32x2_a4 g_u32x2_a4;
+#pragma unroll
+      for (int q = 0; q + 4 <= N; q += 4) *(g_u32x4_a4 *)(od + q) = u32x4_a4{s[q], s[q + 1], s[q + 2], s[q + 3]};
+      if constexpr (N % 4 >= 2) *(g_u32x2_a4 *)(od + N / 4 * 4) = u32x2_a4{s[N / 4 * 4], s[N / 4 * 4 + 1]};
+      if constexpr (N % 2 != 0) od[N - 1] = s[N - 1];
+      o0[2 * P * NP - 1] = static_cast<int16_t>(v[P * NP - 1] >> 16);
+      return;
+    }
   }
 #pragma unroll
   for (int pp = 0; pp < P; pp++) {

@@ -739,9 +739,10 @@ def test_peek_predicts_the_counters_and_leaves_the_state_alone():
 
 
 def test_mono_rows_path_with_odd_and_even_starts():
-    """Mono int16 through the LDS image (launches that fill the chip): image dwords must line up with
-    output dwords whatever the parity of the row starts (k_shift odd or even, output pointer 2- or
-    4-byte aligned), partial rows at both ends of a call."""
+    """Mono int16 in launches that fill the chip (until round 3 through an LDS image, now packed per-lane
+    stores like the small launches): whole dwords must land on output dwords whatever the parity of the
+    row starts (k_shift odd or even, output pointer 2- or 4-byte aligned), partial rows at both ends of a
+    call."""
     import torch
     ch, S, frames = 1, 20, 400000  # ~22 tiles x 20 streams: fills the chip
     xs = np.stack([orc.lcg_pcm(frames, 900 + s) for s in range(S)]).reshape(S, frames, 1)
@@ -767,17 +768,51 @@ def test_mono_rows_path_with_odd_and_even_starts():
         b.close()
 
 
-def test_forced_image_stores_on_every_layout():
-    """The mono LDS-image store path is normally chosen only for launches that fill the chip and for an
-    even den; force it (SPEEXHIP_ROWS=1, read once per process) on the small multi-call cases, where
-    tiles are split into shares, some shares own no phase group at all, and den may be odd."""
-    import subprocess
-    import sys
-    env = dict(os.environ, SPEEXHIP_ROWS="1")
-    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
-                          "window_layout_variants or every_golden_case or edge_cases or mono_rows or many_rates"],
-                         env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+def test_mono_packed_stores_for_runs_that_start_on_either_half_of_a_dword():
+    """Mono int16 WITHOUT the LDS image (few streams): a lane's run of R (period kernel: 10, or 5 in the
+    one-stream plan) or 2*P*NP (slide kernel) samples leaves as whole dwords around at most two odd samples,
+    whether it starts on the lower or the upper half of a dword -- k_shift odd after a ragged call, every
+    second period of an odd den, an output pointer 2 bytes off.  Float mono takes 16-byte stores at
+    4-byte alignment on the same runs."""
+    import torch
+    sp = torch.cuda.current_stream().cuda_stream
+    ch = 1
+    for (i, o, q) in [(44100, 48000, 7), (48000, 44100, 5), (36000, 48000, 6), (24000, 48000, 10), (8000, 44100, 4)]:
+        for S in (1, 3):
+            frames = 90001
+            xs = np.stack([orc.lcg_pcm(frames, 77 + s) for s in range(S)]).reshape(S, frames, 1)
+            for io in ("int16", "float"):
+                for shift in (0, 1):
+                    cap = int(frames * o / i) + 16
+                    dt = torch.int16 if io == "int16" else torch.float32
+                    d_in = torch.from_numpy(xs).cuda().to(dt)
+                    d_store = torch.zeros((S, cap + 8, ch), dtype=dt, device="cuda")
+                    d_out = d_store[:, shift: shift + cap]
+                    b = speexhip.Batch(S, ch, i, o, q)
+                    refs = [orc.Oracle(ch, i, o, q) for _ in range(S)]
+                    for lens in ([frames - 3 * s for s in range(S)], [4001 + 2 * s for s in range(S)], [70003] * S,
+                                 [12345] * S):
+                        d_store.zero_()
+                        used, made = b.process_device(d_in.data_ptr(), frames * ch, lens, d_out.data_ptr(),
+                                                      (cap + 8) * ch, cap, sp, io == "float")
+                        torch.cuda.synchronize()
+                        out = d_out.cpu().numpy()
+                        store = d_store.cpu().numpy()
+                        for s in range(S):
+                            x = xs[s, : lens[s]]
+                            if io == "float":
+                                want, wu = refs[s].process_float(x.astype(np.float32), cap)
+                            else:
+                                want, wu = refs[s].process(x, cap)
+                            assert (used[s], made[s]) == (wu, want.shape[0]), (i, o, S, io, shift, s)
+                            if io == "float":
+                                got = out[s, : made[s]]
+                                assert np.abs(got - want).max(initial=0.0) <= 0.25, (i, o, S, shift, s)  # PCM-range floats: 8e-6 of full scale
+                            else:
+                                assert_close(out[s, : made[s]], want, "mono %d->%d S=%d shift %d stream %d" % (i, o, S, shift, s))
+                            # nothing written outside the stream's run (the store was zeroed before the call)
+                            assert not store[s, :shift].any() and not store[s, shift + made[s]:].any(), (i, o, S, io, shift, s)
+                    b.close()
 
 
 def test_one_very_large_call():
