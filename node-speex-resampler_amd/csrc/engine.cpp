@@ -130,6 +130,7 @@ int ctl_download(void *dst, const char *base, size_t total, size_t off, size_t l
 
 const size_t kLdsBudget = 150 * 1024;  // of the CU's 160 KiB
 const size_t kDirectCopyBytes = 256 * 1024;  // host buffers at least this big skip the pinned bounce buffer
+const size_t kZeroCopyBelow = 720 * 1024;    // ... and calls whose buffers are smaller than this run on pinned memory alone
 }  // namespace
 
 const char *last_device_error() { return g_last_error.c_str(); }
@@ -938,9 +939,14 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   // (pool-owned hipHostMalloc memory, coherent; one launch and one wait instead of copy / launch / copy
   // / wait): 480-960 stereo frames 26.5 -> 22.7 us per call, 16384 frames 41.7 -> 30.1, 65536 frames
   // 70.4 -> 53.7 (tools/small_call_latency.py).  SPEEXHIP_ZERO_COPY_BELOW=0 turns it off (A/B).
+  // Where it stops paying (profiles/r03_zero_copy_sweep.txt, per call, pinned alone vs copies): 256 KB of input
+  // 49 vs 65 us (stereo), 49 vs 66 (mono), 46 vs 65 (8 channels); 512 KB 76 vs 95, 76 vs 95, 72 vs 90; 1 MB
+  // 167 vs 145, 169 vs 144, 132 vs 150: the single-threaded memcpy into and out of the bounce buffers grows at
+  // 0.18 us per KB against 0.10 for the runtime's own staged copies -- they cross near 740 KB.  (Until late in
+  // round 3 the limit was 256 KB, which sent a 65536-frame stereo chunk down the slower way.)
   static const size_t zero_copy_below = [] {
     const char *e = std::getenv("SPEEXHIP_ZERO_COPY_BELOW");
-    return e != nullptr ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kDirectCopyBytes;
+    return e != nullptr ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kZeroCopyBelow;
   }();
   if (!split && in_bytes < zero_copy_below && out_bytes < zero_copy_below) {
     rc = ensure_stage(0, 0, in_bytes, out_bytes);
