@@ -391,7 +391,7 @@ def main():
         tfl = flops / (launch_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, PMC_FILE)
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not args.custom and F == 1 << 20:  # (the file holds the named workloads only)
             try:
                 with open(pmc) as f:
                     traffic = json.load(f).get("%s_s%d_%s%s" % (args.config, S, args.mode, "_float" if fio else ""))

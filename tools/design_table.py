@@ -48,6 +48,14 @@ ea, eb = c('configs[2]', 1, 'exact'), c('configs[2]', 32, 'exact')
 out.append('| cfg3 EXACT mode: configs[2] at the reference\'s precision (fp64 sums of fp32 products, `resample.c:409-417`), 1 / 32 streams | %.1f / %.1f µs | %.1f / %.1f | %s / %s | %s / %s %% | %s / %s %% | — | — |' %
            (L(ea), L(eb), avg('cfg3exact', 1), avg('cfg3exact', 32), num(ea['value']), num(eb['value']), pct(ea['roofline']['frac']), pct(eb['roofline']['frac']),
             pct(ea['roofline']['read_only_frac']), pct(eb['roofline']['read_only_frac'])))
+for io in ('int16', 'float'):
+    try:
+        ma, mb = c('custom: 44100->48000 Hz, 1ch', 1, 'fast', io), c('custom: 44100->48000 Hz, 1ch', 32, 'fast', io)
+    except IndexError:
+        continue
+    out.append('| 44.1k→48k mono q7, %s I/O (not a BASELINE config), 1 / 32 streams | %.1f / %.1f µs | — | %s / %s | %s / %s %% | %s / %s %% | %s / %s %% | — |' %
+               (io, L(ma), L(mb), num(ma['value']), num(mb['value']), pct(ma['roofline']['frac']), pct(mb['roofline']['frac']),
+                pct(ma['roofline']['read_only_frac']), pct(mb['roofline']['read_only_frac']), pct(ma['valu']['frac']), pct(mb['valu']['frac'])))
 cp = [c(w, 1)['cpu_baseline']['value'] for w in ('configs[1]', 'configs[2]', 'configs[3]', 'SURVEY F3')]
 out.append("| CPU baseline: the reference's own C natively compiled (`oracle/_ref`, not the WASM build), 1 host core, cfg2 / cfg3 / cfg4 / F3 | — | — | %.1f / %.1f / %.1f / %.1f | — | — | — | — |" % tuple(cp))
 ee = [c(w, 1)['end_to_end'] for w in ('configs[1]', 'configs[2]', 'configs[3]', 'SURVEY F3')]

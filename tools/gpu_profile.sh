@@ -87,6 +87,11 @@ python bench.py --config cfg3 --mode exact --steps 100 --no-cpu-baseline >> $O/r
 python bench.py --config cfg3 --mode exact --streams 32 --steps 20 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --io float --steps 300 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --io float --streams 32 --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+# mono (not a BASELINE config; the store path of round 3): 44.1k->48k q7, int16 and float
+for IO in int16 float; do
+  python bench.py --custom 1,44100,48000,7 --io $IO --steps 300 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+  python bench.py --custom 1,44100,48000,7 --io $IO --streams 32 --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_form.json 2>/dev/null
 python tools/host_path_bench.py > $O/r${N}_host_path.json 2>/dev/null
 python tools/small_call_latency.py > $O/r${N}_small_call_latency.txt 2>/dev/null
