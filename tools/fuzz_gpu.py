@@ -295,7 +295,7 @@ def main():
     orc.build()
     t0 = time.time()
     trials = fails = 0
-    seed = args.seed * 1000003
+    seed = (args.seed * 1000003) % (2 ** 32 - 10 ** 7)  # (trial seeds = seed + n must stay below numpy's 2^32)
     while time.time() - t0 < args.seconds:
         s = args.only if args.only is not None else seed + trials
         if (args.batch or args.only is not None) and (s % 3 == 0) and (args.batch or args.only_batch):
