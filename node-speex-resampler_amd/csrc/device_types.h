@@ -90,6 +90,7 @@ struct PeriodParams {
   uint32_t threads;       // lanes per workgroup (see SlideParams::threads)
   uint32_t prio;          // bit 0: prologue + staging at raised wave priority; bit 1: the stores too
   uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP), 0 in normal operation
+  uint32_t ksplit;        // > 1: tap-range shares, this many waves per phase group (fir_tile_parts)
 };
 
 }  // namespace speexhip

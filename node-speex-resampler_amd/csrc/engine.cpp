@@ -136,6 +136,12 @@ const size_t kZeroCopyBelow = 720 * 1024;    // ... and calls whose buffers are 
 const char *last_device_error() { return g_last_error.c_str(); }
 void set_last_device_error(const std::string &text) { g_last_error = text; }
 size_t lds_budget() { return kLdsBudget; }
+
+// diagnostics / tests: the int16-window plan at every launch size (normally only launches that fill the chip)
+static bool w16_always() {
+  static const bool on = std::getenv("SPEEXHIP_W16_ALWAYS") != nullptr;
+  return on;
+}
 void debug_fail_device_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
 
 bool Batch::uniform(uint32_t s) const {
@@ -850,8 +856,10 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       geo.outs_per_block = 256;
       e = launch_exact(filter_, geo, d_table_, channels_, d_descs, packed ? &pack : nullptr, n_streams_, max_out,
                        float_io, stream, nullptr, true);
-    } else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable && !float_io && !float_seen_ && period_w16_.usable)
-      // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values)
+    } else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
+               (w16_always() || period_launch_fills_chip(filter_, period_, descs, n_streams_)))
+      // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- for
+      // launches of several generations; a smaller one wants more, shorter pieces (the r = 5 shares below)
       e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, d_descs,
                         packed ? &pack : nullptr, n_streams_, false, stream);
     else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)

@@ -82,6 +82,10 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
                          const StreamDesc *d_descs, const DescPack *pack, uint32_t n_streams, bool float_io,
                          hipStream_t stream);
 
+// Does this launch fill the chip with one workgroup per tile of plan `t`?  The int16-window plan (twice the
+// periods per tile, no r = 5 companion) is for launches that do; one that does not runs `t` / `fine` in shares.
+bool period_launch_fills_chip(const FilterSpec &f, const PeriodPlan &t, const StreamDesc *h_descs, uint32_t n_streams);
+
 // ---- small-ratio fast kernel (kernels_slide.hip): den <= 6, num <= 4 -------------------------
 struct SlidePlan {
   bool usable = false;

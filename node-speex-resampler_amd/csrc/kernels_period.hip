@@ -554,6 +554,106 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
   }
 }
 
+// ---- tap-range shares (round 3, second take) -------------------------------------------------------
+// A launch that cannot fill the chip runs its tiles in shares of a few phase groups each, and a share's
+// few FIR waves then sit one to a SIMD: a wave alone waits out every scalar-load round trip (14-19 cycles
+// per packed FMA instead of 4.5-5).  For long filters -- the decimators: 48k -> 22.05k 304 steps,
+// 48k -> 11.025k 604, 44.1k -> 8k 744 -- that wave's R x steps FMAs are the launch (48k -> 11.025k stereo,
+// one stream: 33 us for 48 000 frames as for 2^20).  Here the `parts` waves of a group each take a range
+// of its trips (rows pointer, window address and padding count-down advanced to the range's first trip),
+// the partial sums meet in the dead window behind a barrier, and part 0 stores.  Only where a wave's chain is
+// long: for BASELINE configs[1] the same scheme lost (two barriers and a pass through LDS against
+// 640 FMAs per wave: 13.22 -> 13.94 us, profiles/r03_ab_ksplit.txt); see launch_period_plan for the rule.
+template <int R, int CT, bool PADDED, int CF, bool W16>
+__device__ __forceinline__ void fir_group_part(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
+                                               const LaneCtx &c, uint32_t g, uint32_t part, uint32_t parts,
+                                               f32x2 (&acc)[R]) {
+  using Isa = FirLoopAsm<R, CT, CF, PADDED, W16>;
+  static_assert(CF != 0 && Isa::available, "tap-range shares run the ISA loop");
+  constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
+  constexpr uint32_t EB = W16 ? 2u : 4u;  // bytes per window element
+  auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+  const uint32_t delta_g = p.delta[g];
+  const uint32_t trips = (p.skip & 4u) ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+  const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u, total = trips >> 8;
+  const uint32_t t0 = sgpr(total * part / parts), t1 = sgpr(total * (part + 1) / parts);
+  auto overlap = [&](uint32_t lo, uint32_t hi) {  // trips of [t0, t1) inside [lo, hi)
+    const uint32_t a = max(t0, lo), b = min(t1, hi);
+    return b > a ? b - a : 0u;
+  };
+  const uint32_t main_end = total - tail;
+  // the padded walk: a boundary behind trip to_wrap0, then every wrap_step trips (0 = none)
+  uint32_t wraps = 0, to_wrap = 0;
+  if constexpr (PADDED) {
+    const uint32_t to_wrap0 = p.delta[p.groups + g];
+    to_wrap = to_wrap0;
+    if (to_wrap0 != 0 && t0 >= to_wrap0) {
+      const uint32_t past = t0 - to_wrap0;
+      wraps = 1 + past / p.wrap_step;
+      to_wrap = p.wrap_step - past % p.wrap_step;
+    } else if (to_wrap0 != 0) {
+      to_wrap = to_wrap0 - t0;
+    }
+  }
+  const float *rows_g = rows + (static_cast<size_t>(g) * p.l4 + t0) * (2 * bank_taps(R));
+  const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) +
+                        ((c.xlane + delta_g * c.C) + t0 * kStepsPerTrip * CF + wraps * p.pad) * EB;
+  const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
+  const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
+                                                        static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
+  Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * EB : 0u, sgpr(overlap(0, head)), sgpr(overlap(head, main_end)),
+           sgpr(overlap(main_end, total)), sgpr(to_wrap), sgpr(p.wrap_step), sgpr((kStepsPerTrip * CF + p.pad) * EB));
+}
+
+// One group per wave-set (the host launches tap-range shares only when a share's groups fit its waves:
+// the partial sums overwrite the window).  Wave w: group w % wave_groups of the share, part w / wave_groups.
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
+__device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restrict__ rows, KDesc dp, float *xs,
+                                               uint32_t xshift, uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
+                                               uint32_t zsplit) {
+  constexpr int CF = ONE_GROUP ? CT : 2 * CGF;
+  LaneCtx c;
+  uint32_t g, part, gw, wg, parts;
+  bool valid;
+  f32x2 acc[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
+  {
+    const PeriodParams p = load_k(pp);
+    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p, xshift, m_lo, m_cnt, lane);
+    wg = p.wave_groups;
+    parts = p.ksplit;
+    part = 0;
+    gw = wave;
+    while (gw >= wg) {  // (wave-uniform; parts <= 16)
+      gw -= wg;
+      part++;
+    }
+    g = zsplit * wg + gw;
+    valid = g < p.groups;
+    if (valid) fir_group_part<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, part, parts, acc);
+  }
+  __syncthreads();  // every wave is done with the window
+  // partial sums of part j >= 1, group-wave gw: block (j - 1) * wg + gw of R x 64 pairs, lanes side by side
+  f32x2 *sums = reinterpret_cast<f32x2 *>(xs);
+  if (valid && part != 0) {
+    f32x2 *mine = sums + (static_cast<size_t>(part - 1) * wg + gw) * (R * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < R; i++) mine[i * 64] = acc[i];
+  }
+  __syncthreads();
+  if (!valid || part != 0) return;
+  for (uint32_t j = 1; j < parts; j++) {
+    const f32x2 *theirs = sums + (static_cast<size_t>(j - 1) * wg + gw) * (R * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < R; i++) acc[i] += theirs[i * 64];
+  }
+  const PeriodParams q = load_k(pp);
+  if ((q.skip & 8u) || !c.live) return;
+  const StreamDesc d = load_k(dp);
+  store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
+}
+
 // (Mono int16 left through an LDS image -- one row per period, whole rows written 16 bytes per lane -- from
 //  round 1 to round 3 for launches that fill the chip: 160 -> 138 us for 32 streams of 44.1k -> 48k when a lane's
 //  20-byte runs cost five stores.  With the runs packed into dwords at either alignment (store_group) the
@@ -567,12 +667,13 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
 // most one workgroup per CU was tried: removing the cap from this kernel gave 13.36 -> 13.0 us on
 // one stream, but as a separate __global__ around a shared device body it measured 13.59 vs 13.53 us,
 // i.e. nothing, and the refactoring cost the capped kernel 0.17 us -- not kept.)
-// The R = 5 instances only ever run one workgroup per CU (launch_period): no 64-VGPR limit for them.
+// The R = 5 instances only ever run one workgroup per CU (launch_period): no 64-VGPR limit for them -- nor for the
+// tap-range-share instances (KS), which are launches of one generation by construction.
 //
 // Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
 // shares of its phase groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T, int CGF = 0, bool W16 = false>
-__global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T, int CGF = 0, bool W16 = false, bool KS = false>
+__global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   // A workgroup that starts beside another one's FIR loop competes with 16 older waves for every
@@ -651,31 +752,51 @@ __global__ __launch_bounds__(1024, R == 10 ? 8 : 4) __attribute__((amdgpu_num_sg
   STAMP(4);
   if (p.skip & 128u) return;  // diagnostics: prologue + staging only
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // (KS: the instances of tap-range shares are kernels of their own -- as a run-time branch of the one kernel the
+  //  second path cost the first its registers: 64 VGPRs and 28 bytes of scratch in the BASELINE configs[1] instance)
+  if constexpr (KS) {  // every wave of the workgroup works on a group (fir_tile_parts)
+    const __attribute__((address_space(4))) KernArgs *ka =
+        (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
+    fir_tile_parts<R, CT, ONE_GROUP, PADDED, T, CGF, W16>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
+                                                         threadIdx.x & 63u, blockIdx.z);
+    return;
+  } else {
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
   const __attribute__((address_space(4))) KernArgs *ka =
       (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
   fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF, W16>(p, d, &ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
                                              threadIdx.x & 63u, blockIdx.z, gridDim.z);
+  }
 }
 
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool KS = false>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
+#ifdef SPEEXHIP_CXX_FIR_LOOP
+  constexpr bool kParts = false;
+#else
+  constexpr bool kParts = KS && FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available;
+#endif
+  if constexpr (KS && !kParts) {  // (no ISA loop for this layout: the host never asks for tap-range shares of it)
+    return hipErrorInvalidValue;
+  } else {
   DescPack empty;
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
   if (pack != nullptr)
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16>, seen_packed);
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS>, seen_packed);
   else
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16>, seen_ring);
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS>, seen_ring);
   if (pack != nullptr)
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16>), grid, dim3(threads), lds_bytes, stream,
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS>), grid, dim3(threads), lds_bytes, stream,
                        p, p.rows, nullptr, *pack);
   else
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16>), grid, dim3(threads), lds_bytes, stream,
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS>), grid, dim3(threads), lds_bytes, stream,
                        p, p.rows, d_descs, empty);
   return hipGetLastError();
+  }
 }
 
 const size_t kSlack = 16;  // floats: window starts on the input's 16-byte grid, staged by 8
@@ -932,6 +1053,15 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
                               uint32_t n_streams, bool float_io, hipStream_t stream);
 }  // namespace
 
+// (44.1k->16k stereo, one stream, through the int16 window -- 64 periods per tile, R = 10 only: 48 000 frames
+//  19.8 us, 441 000 frames 20.5, 2^20 frames 22.9; through the float window in R = 5 shares 11.0 / 12.8 / 14.4 us;
+//  48k->11.025k 33.4 -> 30.9 us: profiles/r03_small_decimators.txt.)
+bool period_launch_fills_chip(const FilterSpec &f, const PeriodPlan &t, const StreamDesc *h_descs, uint32_t n_streams) {
+  const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
+  const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
+  return split_count(t, tiles, n_streams, 2 * device_compute_units()) == 1;
+}
+
 // `fine` (may be null / unusable): the same filter planned with R = 5.  A launch that is a single
 // generation of workgroups -- one that the R = 10 plan would have to split into shares whose
 // workgroups run 8 FIR waves (2 per SIMD) beside 8 staging helpers -- takes it instead: 16 FIR
@@ -1035,7 +1165,26 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // waves it has no groups for, they leave after the staging barrier.
   static const int env_helpers = std::getenv("SPEEXHIP_HELPERS") ? std::atoi(std::getenv("SPEEXHIP_HELPERS")) : 1;
   const bool helpers = env_helpers != 0 && splits > 1;
-  const uint32_t threads = (helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
+  // Tap-range shares (fir_tile_parts): a split launch whose waves each carry a long chain -- R x row_len packed
+  // FMAs, alone on their SIMD -- gives every group as many waves as the workgroup has room for.  From 1 800 FMAs
+  // per wave (44.1k -> 16k in R = 5 shares, 1 900, gains 2.3 us of 10.8; 44.1k -> 48k q10, 1 400, loses 0.2 us of
+  // 8.7; BASELINE configs[1]'s one-generation plan, R = 5 x 140 = 700, lost 0.7 us of 13.2 with the same scheme), with
+  // at least 4 trips per part, the partial sums inside the window, an ISA loop for the layout (frames of 1, 2,
+  // 4, 6, 8 channels) and one group per wave-set.  SPEEXHIP_KSPLIT=0 turns it off, =n forces n parts (A/B, tests).
+  static const int env_ksplit = std::getenv("SPEEXHIP_KSPLIT") ? std::atoi(std::getenv("SPEEXHIP_KSPLIT")) : -1;
+  p.ksplit = 1;
+  const bool isa_layout = (t.ct == 1 && t.cgroups == 1) || (t.ct == 2 && t.cgroups <= 4);
+  if (splits > 1 && env_ksplit != 0 && isa_layout && !t.w16 && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
+    uint32_t parts = env_ksplit > 0 ? static_cast<uint32_t>(env_ksplit) : max_waves / wave_groups;
+    parts = std::min<uint32_t>(parts, max_waves / wave_groups);
+    const uint32_t trips = t.l4;  // trips per group row
+    while (parts > 1 && (trips / parts < 4 ||
+                         static_cast<size_t>(parts - 1) * wave_groups * t.r * 64 * 8 > t.window_bytes))
+      parts--;
+    if (parts > 1 && (env_ksplit > 0 || static_cast<uint64_t>(t.r) * t.row_len >= 1800)) p.ksplit = parts;
+  }
+  const uint32_t threads =
+      (p.ksplit > 1 ? wave_groups * p.ksplit : helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
   p.threads = threads;
   // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8
   // when a tile is split: workgroups whose linear ids differ by a multiple of 8 share an XCD, so
@@ -1046,15 +1195,19 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   const dim3 grid(grid_x, n_streams, splits);
   // (an int16 window -- t.w16 -- exists for int16 calls on the layouts the ISA loop is generated for: ONE or CGV)
   if (t.w16 && float_io) return hipErrorInvalidValue;
+  // (LRC: the kernel of the layout, or its tap-range-shares twin)
+#define SPEEXHIP_LRC(RV, CTV, ONE, PADV, TV, CGV)                                                                                        \
+  (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, false, true>(p, d_descs, pack, grid, threads, t.window_bytes, stream)          \
+                : launch_rc<RV, CTV, ONE, PADV, TV, CGV, false, false>(p, d_descs, pack, grid, threads, t.window_bytes, stream))
 #define SPEEXHIP_PERIOD_CASE_R(RV, CTV, ONE, PADV)                                                                                      \
-  return float_io ? launch_rc<RV, CTV, ONE, PADV, float>(p, d_descs, pack, grid, threads, t.window_bytes, stream)                       \
+  return float_io ? SPEEXHIP_LRC(RV, CTV, ONE, PADV, float, 0)                                                                           \
          : (ONE && t.w16) ? launch_rc<RV, CTV, ONE, PADV, int16_t, 0, ONE>(p, d_descs, pack, grid, threads, t.window_bytes, stream)     \
-                          : launch_rc<RV, CTV, ONE, PADV, int16_t>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
+                          : SPEEXHIP_LRC(RV, CTV, ONE, PADV, int16_t, 0)
   // 4 / 6 / 8 channels: channel pairs per frame as a compile-time constant (lane_ctx)
 #define SPEEXHIP_PERIOD_CASE_CG(RV, PADV, CGV)                                                                                          \
-  return float_io ? launch_rc<RV, 2, false, PADV, float, CGV>(p, d_descs, pack, grid, threads, t.window_bytes, stream)                  \
+  return float_io ? SPEEXHIP_LRC(RV, 2, false, PADV, float, CGV)                                                                         \
          : t.w16  ? launch_rc<RV, 2, false, PADV, int16_t, CGV, true>(p, d_descs, pack, grid, threads, t.window_bytes, stream)          \
-                  : launch_rc<RV, 2, false, PADV, int16_t, CGV>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
+                  : SPEEXHIP_LRC(RV, 2, false, PADV, int16_t, CGV)
   const bool padded = t.pad != 0;
   if (t.ct == 2 && t.cgroups >= 2 && t.cgroups <= 4) {
     if (t.r == 5) {
@@ -1091,6 +1244,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   SPEEXHIP_PERIOD_CASE(1, false, true);
 #undef SPEEXHIP_PERIOD_CASE
 #undef SPEEXHIP_PERIOD_CASE_R
+#undef SPEEXHIP_LRC
 }
 }  // namespace
 

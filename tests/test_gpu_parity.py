@@ -683,6 +683,35 @@ def test_window_layout_variants_of_the_period_kernel():
         r.close()
 
 
+def test_int16_window_on_small_launches_too():
+    """The int16-window plan normally serves only launches that fill the chip (a smaller one runs the float
+    window in r = 5 shares, which is faster there).  SPEEXHIP_W16_ALWAYS=1 (read once per process) lifts that,
+    so that the small multi-call cases of the layout and mixed int16 / float tests run over it as well."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEEXHIP_W16_ALWAYS="1")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "window_layout_variants or int16_window_plan_serves or edge_cases"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_tap_range_shares_on_every_layout():
+    """Launches that cannot fill the chip run long filters in tap-range shares (several waves per phase group,
+    each a range of the group's trips, partial sums added behind a barrier): the decimators of
+    test_window_layout_variants take them by the planner's rule.  SPEEXHIP_KSPLIT=3 (read once per process)
+    forces three parts on every split launch -- short filters, mono, float, padded and unpadded windows, both
+    phase-group sizes -- over the small multi-call cases."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEEXHIP_KSPLIT="3")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "window_layout_variants or every_golden_case or edge_cases or many_rates or mono_packed "
+                          "or float_entry or mid_stream_control_scripts_fast"],
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
 def test_many_generation_launch_with_ragged_ends():
     """40 stereo streams x 400k frames: several generations of workgroups on every CU; ragged lengths
     put partial periods and partial tiles at both ends, the second call starts mid-period."""
@@ -1274,3 +1303,36 @@ def test_int16_window_plan_serves_int16_calls_until_a_float_call():
                 assert used == wu and r.position() == ref.position(), (ch, i, o, q, step)
                 assert_close(got, want, "w16 %s step %d" % ((ch, i, o, q), step))
         r.close()
+    # ... and as a launch that fills the chip, where the int16 window is the plan in force: 24 streams
+    import torch
+    sp = torch.cuda.current_stream().cuda_stream
+    for (ch, i, o, q) in [(2, 48000, 11025, 7), (2, 44100, 16000, 7)]:
+        S, frames = 24, 160000
+        plan = speexhip.debug_plan(i, o, q, ch)
+        num = i // np.gcd(i, o)
+        assert (frames // num // plan["lane_periods"]) * S > 128, "the launch must fill the chip for the int16 window"
+        xs = np.stack([orc.lcg_pcm(frames * ch, 300 + s).reshape(frames, ch) for s in range(S)])
+        xf = xs.astype(np.float32) * np.float32(0.37)
+        cap = int(frames * o / i) + 16
+        d16, df = torch.from_numpy(xs).cuda(), torch.from_numpy(xf).cuda()
+        o16 = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+        of = torch.zeros((S, cap, ch), dtype=torch.float32, device="cuda")
+        b = speexhip.Batch(S, ch, i, o, q)
+        refs = {s: orc.Oracle(ch, i, o, q) for s in (0, 7, 23)}
+        for step, io in enumerate(["int16", "int16", "float", "int16"]):
+            lens = [frames - 11 * s - 1000 * step for s in range(S)]
+            fl = io == "float"
+            used, made = b.process_device((df if fl else d16).data_ptr(), frames * ch, lens, (of if fl else o16).data_ptr(),
+                                          cap * ch, cap, sp, fl)
+            torch.cuda.synchronize()
+            out = (of if fl else o16).cpu().numpy()
+            for s, ref in refs.items():
+                if fl:
+                    want, wu = ref.process_float(xf[s, : lens[s]], cap)
+                    assert (used[s], made[s]) == (wu, want.shape[0]), (ch, i, o, step, s)
+                    assert np.abs(out[s, : made[s]] - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), (ch, i, o, step, s)
+                else:
+                    want, wu = ref.process(xs[s, : lens[s]], cap)
+                    assert (used[s], made[s]) == (wu, want.shape[0]), (ch, i, o, step, s)
+                    assert_close(out[s, : made[s]], want, "w16 batch %s step %d stream %d" % ((ch, i, o, q), step, s))
+        b.close()
