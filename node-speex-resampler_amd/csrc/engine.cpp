@@ -857,9 +857,9 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       e = launch_exact(filter_, geo, d_table_, channels_, d_descs, packed ? &pack : nullptr, n_streams_, max_out,
                        float_io, stream, nullptr, true);
     } else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
-               (w16_always() || period_launch_fills_chip(filter_, period_, descs, n_streams_)))
-      // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- for
-      // launches of several generations; a smaller one wants more, shorter pieces (the r = 5 shares below)
+               (w16_always() || period_launch_prefers_w16(filter_, period_, period_fine_.usable, descs, n_streams_)))
+      // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- unless
+      // the launch is too small for that to pay (period_launch_prefers_w16)
       e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, d_descs,
                         packed ? &pack : nullptr, n_streams_, false, stream);
     else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)

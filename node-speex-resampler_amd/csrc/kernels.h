@@ -82,9 +82,10 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
                          const StreamDesc *d_descs, const DescPack *pack, uint32_t n_streams, bool float_io,
                          hipStream_t stream);
 
-// Does this launch fill the chip with one workgroup per tile of plan `t`?  The int16-window plan (twice the
-// periods per tile, no r = 5 companion) is for launches that do; one that does not runs `t` / `fine` in shares.
-bool period_launch_fills_chip(const FilterSpec &f, const PeriodPlan &t, const StreamDesc *h_descs, uint32_t n_streams);
+// Should this int16 launch run over the int16-window plan rather than `t` (the float-window plan, `has_fine`: with
+// an r = 5 companion)?  Launches of few tiles want more and shorter pieces (kernels_period.hip).
+bool period_launch_prefers_w16(const FilterSpec &f, const PeriodPlan &t, bool has_fine, const StreamDesc *h_descs,
+                               uint32_t n_streams);
 
 // ---- small-ratio fast kernel (kernels_slide.hip): den <= 6, num <= 4 -------------------------
 struct SlidePlan {

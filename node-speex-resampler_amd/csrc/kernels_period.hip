@@ -1053,13 +1053,23 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
                               uint32_t n_streams, bool float_io, hipStream_t stream);
 }  // namespace
 
-// (44.1k->16k stereo, one stream, through the int16 window -- 64 periods per tile, R = 10 only: 48 000 frames
-//  19.8 us, 441 000 frames 20.5, 2^20 frames 22.9; through the float window in R = 5 shares 11.0 / 12.8 / 14.4 us;
-//  48k->11.025k 33.4 -> 30.9 us: profiles/r03_small_decimators.txt.)
-bool period_launch_fills_chip(const FilterSpec &f, const PeriodPlan &t, const StreamDesc *h_descs, uint32_t n_streams) {
+// Which window for an int16 launch of a ratio that has both?  The int16 window's tiles hold twice the periods
+// (all the lanes of a wave busy where the float window leaves half of them idle) at +20-40 % vector instructions
+// for the conversions; a launch of a few tiles wants MORE pieces, not fuller ones.  Measured with tap-range
+// shares on both sides (profiles/r03_small_decimators.txt; T = tiles of the float-window plan x streams):
+// one stream 48k->11.025k stereo 48 000 / 441 000 / 2^20 frames (T = 2 / 25 / 59) 14.6 / 14.9 / 21.1 us on the
+// float window against 17.5 / 17.7 / 18.3 on the int16 one; mono 2^20 frames (T = 29) 16.3 vs 20.8; 4 channels
+// 441 000 frames (T = 50) 20.9 vs 17.2; 44.1k->16k (which has r = 5 shares) 2^20 frames (T = 57) 14.5 vs 17.0;
+// 8 streams x 131 072 frames: stereo 48k->11.025k (T = 64) 36.9 vs 30.7, mono (T = 32) 28.1 vs 21.0, 44.1k->16k
+// (T = 64) 24.2 vs 17.2.  Hence: the int16 window when the float plan fills the chip anyway, from T = 48 when
+// the ratio has no r = 5 plan, and from T = 32 when the launch is a batch of at least 4 streams.
+bool period_launch_prefers_w16(const FilterSpec &f, const PeriodPlan &t, bool has_fine, const StreamDesc *h_descs,
+                               uint32_t n_streams) {
   const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
-  return split_count(t, tiles, n_streams, 2 * device_compute_units()) == 1;
+  if (split_count(t, tiles, n_streams, 2 * device_compute_units()) == 1) return true;
+  const uint64_t T = static_cast<uint64_t>(tiles) * n_streams;
+  return (T >= 48 && !has_fine) || (n_streams >= 4 && T >= 32);
 }
 
 // `fine` (may be null / unusable): the same filter planned with R = 5.  A launch that is a single
@@ -1174,7 +1184,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   static const int env_ksplit = std::getenv("SPEEXHIP_KSPLIT") ? std::atoi(std::getenv("SPEEXHIP_KSPLIT")) : -1;
   p.ksplit = 1;
   const bool isa_layout = (t.ct == 1 && t.cgroups == 1) || (t.ct == 2 && t.cgroups <= 4);
-  if (splits > 1 && env_ksplit != 0 && isa_layout && !t.w16 && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
+  if (splits > 1 && env_ksplit != 0 && isa_layout && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
     uint32_t parts = env_ksplit > 0 ? static_cast<uint32_t>(env_ksplit) : max_waves / wave_groups;
     parts = std::min<uint32_t>(parts, max_waves / wave_groups);
     const uint32_t trips = t.l4;  // trips per group row
@@ -1196,17 +1206,18 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // (an int16 window -- t.w16 -- exists for int16 calls on the layouts the ISA loop is generated for: ONE or CGV)
   if (t.w16 && float_io) return hipErrorInvalidValue;
   // (LRC: the kernel of the layout, or its tap-range-shares twin)
-#define SPEEXHIP_LRC(RV, CTV, ONE, PADV, TV, CGV)                                                                                        \
-  (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, false, true>(p, d_descs, pack, grid, threads, t.window_bytes, stream)          \
-                : launch_rc<RV, CTV, ONE, PADV, TV, CGV, false, false>(p, d_descs, pack, grid, threads, t.window_bytes, stream))
+#define SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, W)                                                                                    \
+  (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, true>(p, d_descs, pack, grid, threads, t.window_bytes, stream)              \
+                : launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, false>(p, d_descs, pack, grid, threads, t.window_bytes, stream))
+#define SPEEXHIP_LRC(RV, CTV, ONE, PADV, TV, CGV) SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, false)
 #define SPEEXHIP_PERIOD_CASE_R(RV, CTV, ONE, PADV)                                                                                      \
   return float_io ? SPEEXHIP_LRC(RV, CTV, ONE, PADV, float, 0)                                                                           \
-         : (ONE && t.w16) ? launch_rc<RV, CTV, ONE, PADV, int16_t, 0, ONE>(p, d_descs, pack, grid, threads, t.window_bytes, stream)     \
+         : (ONE && t.w16) ? SPEEXHIP_LRCW(RV, CTV, ONE, PADV, int16_t, 0, ONE)                                                         \
                           : SPEEXHIP_LRC(RV, CTV, ONE, PADV, int16_t, 0)
   // 4 / 6 / 8 channels: channel pairs per frame as a compile-time constant (lane_ctx)
 #define SPEEXHIP_PERIOD_CASE_CG(RV, PADV, CGV)                                                                                          \
   return float_io ? SPEEXHIP_LRC(RV, 2, false, PADV, float, CGV)                                                                         \
-         : t.w16  ? launch_rc<RV, 2, false, PADV, int16_t, CGV, true>(p, d_descs, pack, grid, threads, t.window_bytes, stream)          \
+         : t.w16  ? SPEEXHIP_LRCW(RV, 2, false, PADV, int16_t, CGV, true)                                                              \
                   : SPEEXHIP_LRC(RV, 2, false, PADV, int16_t, CGV)
   const bool padded = t.pad != 0;
   if (t.ct == 2 && t.cgroups >= 2 && t.cgroups <= 4) {
@@ -1245,6 +1256,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 #undef SPEEXHIP_PERIOD_CASE
 #undef SPEEXHIP_PERIOD_CASE_R
 #undef SPEEXHIP_LRC
+#undef SPEEXHIP_LRCW
 }
 }  // namespace
 
