@@ -69,6 +69,8 @@ struct SlideParams {
   uint32_t threads;         // lanes per workgroup (a kernel argument: blockDim.x would be fetched from the
                             // dispatch packet with a vector load that drains the staging loads in flight)
   uint32_t skip;            // diagnostics only
+  uint32_t base_waves;      // waves that carry lane blocks (= threads / 64 / parts)
+  uint32_t parts;           // > 1: tap-range parts, sets of base_waves waves each a range of the iterations
 };
 
 struct PeriodParams {

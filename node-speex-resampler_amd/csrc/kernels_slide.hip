@@ -147,9 +147,29 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   const uint32_t tile_periods = p.blocks_per_tile * t.p;
   const uint32_t tiles = (max_periods + tile_periods - 1) / tile_periods;
   // LDS: one row per lane block, + the rows the last lane's window runs into
-  const size_t lds = slide_lds_bytes(t, waves);
+  size_t lds = slide_lds_bytes(t, waves);
   dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
-  const uint32_t threads = waves * 64;
+  // Tap-range parts: a launch of a few workgroups of two waves runs every lane's whole filter as one chain --
+  // P x den x row_len packed FMAs per wave, alone on its SIMD (48k -> 8k stereo, one stream: 16.7 us for 48 000
+  // frames as for 441 000).  Such a launch gives each wave's lane blocks to `parts` waves, a range of the
+  // iterations each; the sums meet in LDS behind a barrier (kernels_slide_impl.h).  SPEEXHIP_SLIDE_PARTS=0 turns
+  // it off, =n forces n (A/B, tests).
+  static const int env_parts = std::getenv("SPEEXHIP_SLIDE_PARTS") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_PARTS")) : -1;
+  p.base_waves = waves;
+  p.parts = 1;
+  {
+    const uint32_t pairs = t.row_len / (t.p * f.num) / 2;  // iteration pairs per lane
+    const uint64_t chain = static_cast<uint64_t>(t.p) * t.np * t.row_len;  // packed FMAs per wave
+    uint32_t parts = 16 / waves;
+    if (env_parts > 0) parts = std::min<uint32_t>(parts, static_cast<uint32_t>(env_parts));
+    while (parts > 1 && (pairs / parts < 2 || static_cast<size_t>(parts - 1) * waves * t.p * t.np * 64 * 8 > kSlideLdsLimit)) parts--;
+    const bool small = static_cast<uint64_t>(tiles) * n_streams * waves <= 4ull * device_compute_units();  // at most one wave per SIMD
+    if (env_parts != 0 && parts > 1 && (env_parts > 0 || (small && chain >= 1500))) {
+      p.parts = parts;
+      lds = std::max(lds, static_cast<size_t>(parts - 1) * waves * t.p * t.np * 64 * 8);
+    }
+  }
+  const uint32_t threads = waves * p.parts * 64;
   p.threads = threads;
   return float_io ? launch_slide_shape<float>(t, p, d_descs, pack, grid, threads, lds, stream)
                   : launch_slide_shape<int16_t>(t, p, d_descs, pack, grid, threads, lds, stream);

@@ -108,7 +108,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   }
   __syncthreads();
 
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Tap-range parts (p.parts > 1; small launches of long filters, launch_slide): the workgroup's waves come in
+  // `parts` sets of p.base_waves; set j runs iterations [it0, it1) of every lane block and the sums meet in LDS.
+  uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t part = 0;
+  while (wave >= p.base_waves) {  // (wave-uniform)
+    wave -= p.base_waves;
+    part++;
+  }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t cg = lane % p.cgroups;        // channel pair (PAIR_CH) or channel (phase pairs)
   const uint32_t lb = wave * p.blocks_per_wave + lane / p.cgroups;  // lane block inside the tile
@@ -158,7 +165,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
       win[IDX / 2].y = *px;
   };
   const float *__restrict__ trow = rows;  // wave-uniform, __restrict__ kernel argument -> s_load
-  const uint32_t n_it = (p.skip & 4u) ? 0 : p.row_len / U;  // even
+  uint32_t n_it = (p.skip & 4u) ? 0 : p.row_len / U;  // even
+  if (p.parts > 1) {  // this set's range of iterations, on even bounds (the loop runs them in pairs)
+    const uint32_t pairs = n_it / 2;
+    const uint32_t it0 = pairs * part / p.parts * 2, it1 = pairs * (part + 1) / p.parts * 2;
+    trow += static_cast<size_t>(it0) * TAPS_IT;
+    xrow += static_cast<size_t>(it0) * p.row_stride;
+    n_it = it1 - it0;
+  }
   f32x2 tpa[TP], tpb[TAP2 ? TP : 1];
   auto load_taps = [&](f32x2 (&t)[TP], const float *tr) {
 #pragma unroll
@@ -265,6 +279,27 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
         iteration(std::integral_constant<int, 0>(), tpa, tpa);
         iteration(std::integral_constant<int, U>(), tpa, tpa);
       }
+    }
+  }
+  if (p.parts > 1) {
+    // sums of set j >= 1, wave w: block (j - 1) * base_waves + w of P x NP x 64 pairs, lanes side by side
+    __syncthreads();  // every wave is done with the window
+    f32x2 *sums = reinterpret_cast<f32x2 *>(xs);
+    if (part != 0) {
+      f32x2 *mine = sums + (static_cast<size_t>(part - 1) * p.base_waves + wave) * (P * NP * 64) + lane;
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int r = 0; r < NP; r++) mine[(pp * NP + r) * 64] = acc[pp][r];
+    }
+    __syncthreads();
+    if (part != 0) return;
+    for (uint32_t j = 1; j < p.parts; j++) {
+      const f32x2 *theirs = sums + (static_cast<size_t>(j - 1) * p.base_waves + wave) * (P * NP * 64) + lane;
+#pragma unroll
+      for (int pp = 0; pp < P; pp++)
+#pragma unroll
+        for (int r = 0; r < NP; r++) acc[pp][r] += theirs[(pp * NP + r) * 64];
     }
   }
   if (!lane_live || (p.skip & 8u)) return;

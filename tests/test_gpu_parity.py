@@ -712,6 +712,21 @@ def test_tap_range_shares_on_every_layout():
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
 
 
+def test_slide_kernel_tap_range_parts_on_every_shape():
+    """The slide kernel's counterpart of the tap-range shares: in a small launch the waves of a workgroup come in
+    sets, each set a range of the FIR iterations of the same lane blocks, sums added in LDS.  The n:1 cases of the
+    slide tests take it by the launch rule; SPEEXHIP_SLIDE_PARTS=3 (read once per process) forces three sets on
+    every launch of every shape."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEEXHIP_SLIDE_PARTS="3")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "small_ratio or n_to_one or slide_kernel_workgroups or every_golden_case or edge_cases "
+                          "or many_rates or mono_packed or float_entry"],
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
 def test_many_generation_launch_with_ragged_ends():
     """40 stereo streams x 400k frames: several generations of workgroups on every CU; ragged lengths
     put partial periods and partial tiles at both ends, the second call starts mid-period."""
