@@ -1183,7 +1183,11 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // 4, 6, 8 channels) and one group per wave-set.  SPEEXHIP_KSPLIT=0 turns it off, =n forces n parts (A/B, tests).
   static const int env_ksplit = std::getenv("SPEEXHIP_KSPLIT") ? std::atoi(std::getenv("SPEEXHIP_KSPLIT")) : -1;
   p.ksplit = 1;
+#ifdef SPEEXHIP_CXX_FIR_LOOP
+  const bool isa_layout = false;  // (the A/B library without the ISA loop has no tap-range shares either)
+#else
   const bool isa_layout = (t.ct == 1 && t.cgroups == 1) || (t.ct == 2 && t.cgroups <= 4);
+#endif
   if (splits > 1 && env_ksplit != 0 && isa_layout && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
     uint32_t parts = env_ksplit > 0 ? static_cast<uint32_t>(env_ksplit) : max_waves / wave_groups;
     parts = std::min<uint32_t>(parts, max_waves / wave_groups);
