@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -1135,8 +1137,35 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   //  group's trips instead of leaving: mono one stream 13.22 -> 13.94 us, a 441 000-frame stereo call 8.52 -> 9.02,
   //  float 9.37 -> 10.10; only launches of a few tiles gained (16 384 frames 7.14 -> 6.36 us): the two barriers and
   //  the pass through LDS cost more than the halved loop saves.  Removed; profiles/r03_ab_ksplit.txt.)
-  const uint32_t splits = split_count(t, tiles, n_streams, resident);
   static const uint32_t max_waves = std::getenv("SPEEXHIP_WAVES") ? std::atoi(std::getenv("SPEEXHIP_WAVES")) : 16;
+  uint32_t splits = split_count(t, tiles, n_streams, resident);
+  // split_count doubles the shares by workgroup count alone.  Where that leaves a share more phase groups than a
+  // workgroup has waves (8k -> 44.1k: 45 groups in 2 shares, the waves walk two groups each: 29.5 us for one
+  // stream of 441 000 frames against 20.8 in 5 shares), a few more shares are weighed with a small cost model
+  // fitted to the launches of profiles/r03_small_decimators.txt: a wave alone on its SIMD spends ~19 cycles per
+  // packed FMA, w of them together 4.75 w; a workgroup takes its window in at ~11 bytes per cycle; workgroups
+  // beyond one per CU queue.  A candidate must beat the incumbent by 10 %.
+  static const bool model_off = std::getenv("SPEEXHIP_SPLIT_MODEL") && std::atoi(std::getenv("SPEEXHIP_SPLIT_MODEL")) == 0;  // A/B
+  if (splits > 1 && !model_off && !std::getenv("SPEEXHIP_SPLITS")) {
+    const double cus = device_compute_units();
+    auto cost = [&](uint32_t s) {
+      const double wg_per_cu = std::ceil(static_cast<double>(tiles) * n_streams * s / cus);
+      const uint32_t gps = (t.groups + s - 1) / s;                 // groups per share
+      const double walks = std::ceil(static_cast<double>(gps) / max_waves);
+      double chain = static_cast<double>(t.r) * t.row_len, waves = std::min<uint32_t>(gps, max_waves);
+      if (gps * 2 <= max_waves && chain >= 1800) {                  // tap-range shares (below)
+        const double parts = std::min<double>(max_waves / gps, std::max<uint32_t>(t.l4 / 4, 1));
+        chain /= parts;
+        waves = gps * parts;
+      }
+      const double per_simd = wg_per_cu * waves / 4;
+      return walks * chain * std::max(19.0, 4.75 * per_simd) + wg_per_cu * t.window_bytes / 11.0;
+    };
+    uint32_t best = splits;
+    for (uint32_t s2 = splits + 1; s2 <= 2 * splits + 1 && s2 <= 16 && (t.groups + s2 - 1) / s2 >= 2; s2++)
+      if (cost(s2) < 0.9 * cost(best)) best = s2;
+    splits = best;
+  }
   const uint32_t wave_groups = std::min<uint32_t>((t.groups + splits - 1) / splits, max_waves);
   PeriodParams p;
   p.rows = d_rows;
@@ -1207,6 +1236,17 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   uint32_t grid_x = (max_periods == 0 ? 0 : tiles) + 1;
   if (splits > 1 && n_streams == 1) grid_x = (grid_x + 7) / 8 * 8;
   const dim3 grid(grid_x, n_streams, splits);
+  // diagnostics: one line per launch shape on stderr
+  static const bool verbose = std::getenv("SPEEXHIP_PLAN_VERBOSE") != nullptr;
+  if (verbose) {
+    static uint64_t last = 0;
+    const uint64_t key = (static_cast<uint64_t>(tiles) << 40) ^ (static_cast<uint64_t>(n_streams) << 24) ^ (splits << 16) ^ (t.r << 8) ^ p.ksplit ^ (t.w16 ? 1u << 31 : 0u);
+    if (key != last) {
+      last = key;
+      std::fprintf(stderr, "period launch: r=%u%s groups=%u lane_periods=%u tiles=%u streams=%u splits=%u wave_groups=%u parts=%u threads=%u window=%zu B\n",
+                   t.r, t.w16 ? " (int16 window)" : "", t.groups, t.lane_periods, tiles, n_streams, splits, wave_groups, p.ksplit, threads, t.window_bytes);
+    }
+  }
   // (an int16 window -- t.w16 -- exists for int16 calls on the layouts the ISA loop is generated for: ONE or CGV)
   if (t.w16 && float_io) return hipErrorInvalidValue;
   // (LRC: the kernel of the layout, or its tap-range-shares twin)
