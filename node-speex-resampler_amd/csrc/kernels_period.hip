@@ -1224,7 +1224,11 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
     while (parts > 1 && (trips / parts < 4 ||
                          static_cast<size_t>(parts - 1) * wave_groups * t.r * 64 * 8 > t.window_bytes))
       parts--;
-    if (parts > 1 && (env_ksplit > 0 || static_cast<uint64_t>(t.r) * t.row_len >= 1800)) p.ksplit = parts;
+    // (two parts on a chip already more than half full buy nothing: there the launch is throughput, not one
+    //  wave's latency -- 32 mono streams x 131 072 frames of 48k -> 22.05k in 2 shares: 44.8 us without, 48.7 with)
+    const bool crowded = static_cast<uint64_t>(tiles) * n_streams * splits * 2 > device_compute_units();
+    if (parts > 1 && (env_ksplit > 0 || (static_cast<uint64_t>(t.r) * t.row_len >= 1800 && !(crowded && parts < 3))))
+      p.ksplit = parts;
   }
   const uint32_t threads =
       (p.ksplit > 1 ? wave_groups * p.ksplit : helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
