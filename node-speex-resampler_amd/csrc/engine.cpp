@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <list>
 #include <mutex>
@@ -957,12 +958,31 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     return e != nullptr ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kZeroCopyBelow;
   }();
   if (!split && in_bytes < zero_copy_below && out_bytes < zero_copy_below) {
-    rc = ensure_stage(0, 0, in_bytes, out_bytes);
+    // (+ 64 bytes: the completion word below lives behind the samples, in the same pinned block)
+    rc = ensure_stage(0, 0, in_bytes, out_bytes + 64);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     if (in != nullptr && in_bytes != 0) std::memcpy(h_pin_in_, in, in_bytes);
+    // The wait: hipStreamSynchronize after a tiny launch costs 11-12 us on this stack; a 32-bit stream write behind
+    // the kernel (hipStreamWriteValue32: performed once everything before it on the stream has completed) into
+    // pinned memory, polled by the caller, 8.8 (tools/ubench_sync.hip).  A launch that has not signalled after
+    // 2 ms is waited for -- and its error, if that is what happened, reported -- the ordinary way.
+    static const bool poll_done = std::getenv("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
+    volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(h_pin_out_ + ((pin_out_cap_ - 64) & ~static_cast<size_t>(63)));
+    const uint32_t seq = ++done_seq_;
+    *done = seq - 1;
     rc = process_device(in != nullptr ? h_pin_in_ : nullptr, 0, in_len, h_pin_out_, 0, out_len, float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
-    HIP_TRY(hipStreamSynchronize(own_stream_));
+    bool signalled = false;
+    if (poll_done && hipStreamWriteValue32(own_stream_, const_cast<uint32_t *>(done), seq, 0) == hipSuccess) {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+      for (uint32_t spins = 0; !signalled; spins++) {
+        signalled = __atomic_load_n(const_cast<const uint32_t *>(done), __ATOMIC_ACQUIRE) == seq;
+        if (!signalled && (spins & 255u) == 255u && std::chrono::steady_clock::now() > deadline) break;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+    if (!signalled) HIP_TRY(hipStreamSynchronize(own_stream_));
     drain.armed = false;
     const size_t made = static_cast<size_t>(*out_len) * channels_ * es;
     if (made != 0) std::memcpy(out, h_pin_out_, made);

@@ -187,6 +187,7 @@ class Batch {
   hipStream_t own_stream_ = nullptr;
   char *d_stage_in_ = nullptr, *d_stage_out_ = nullptr;
   char *h_pin_in_ = nullptr, *h_pin_out_ = nullptr;
+  uint32_t done_seq_ = 0;  // completion word of the small host-buffer calls (engine.cpp, process_host)
   size_t stage_in_cap_ = 0, stage_out_cap_ = 0, pin_in_cap_ = 0, pin_out_cap_ = 0;  // bytes
 };
 
