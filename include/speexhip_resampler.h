@@ -104,7 +104,11 @@ SPEEXHIP_API SpeexHipResamplerState *speexhip_resampler_init_frac(uint32_t nb_ch
                                                                   int quality, int *err);
 /* Replace speex_resampler_set_rate / set_rate_frac / get_ratio (speex_resampler.h:223-262,
  * resample.c:1084-1151).  OVERFLOW when a phase numerator cannot be carried to the new
- * denominator (the state is then left unchanged; the reference leaves it half-updated). */
+ * denominator: as in the reference (:1119-1134) get_rate / get_ratio then report the NEW rates and
+ * a repeat of the same call returns SUCCESS without doing anything; unlike the reference, which
+ * goes on with phase numerators on two denominators, processing continues consistently with the
+ * OLD ratio and filter until a later filter change succeeds -- from then on get_rate / get_ratio
+ * report the filter in force again. */
 SPEEXHIP_API int speexhip_resampler_set_rate(SpeexHipResamplerState *st, uint32_t in_rate, uint32_t out_rate);
 SPEEXHIP_API int speexhip_resampler_set_rate_frac(SpeexHipResamplerState *st, uint32_t ratio_num,
                                                   uint32_t ratio_den, uint32_t in_rate, uint32_t out_rate);
@@ -164,11 +168,13 @@ SPEEXHIP_API const char *speexhip_resampler_strerror(int err);
  * `hip_stream` (a hipStream_t passed as void*; NULL = the default stream) and the call
  * returns without waiting for the GPU.  The stream position advances on the host at once
  * (it is integer arithmetic, independent of the audio), so *in_len / *out_len are final on
- * return.  d_in must stay valid until the stream has executed the call.  `hip_stream` itself must
- * stay valid until the state's NEXT call of any kind (processing, control, destroy): calls on one
- * state are ordered, so the next call -- on whatever stream -- first waits for this one on the
- * device, and control calls and destroy wait for it on the host (for this state's last call only,
- * never for the device: other states' launches keep running). */
+ * return.  d_in must stay valid until the stream has executed the call.  Calls on one state are
+ * ordered: the call records an event of the state's own behind its launch; the next call -- on
+ * whatever stream -- first waits for that event on the device, and control calls and destroy wait
+ * for it on the host (for this state's last call only, never for the device: other states'
+ * launches keep running).  Nothing is asked of `hip_stream` once the call has returned: the
+ * caller may destroy it as soon as its own use of it allows (round 4; before, the stream had to
+ * outlive the state's next call). */
 SPEEXHIP_API int speexhip_resampler_process_interleaved_int_device(SpeexHipResamplerState *st,
                                                                    const int16_t *d_in,
                                                                    uint32_t *in_len, int16_t *d_out,

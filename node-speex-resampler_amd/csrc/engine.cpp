@@ -403,14 +403,15 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
     // engines (see kCtlCopyMin; not hipMemsetAsync either: a fill kernel queues behind other states'
     // kernels just the same -- set_quality beside another state's 6 ms launch took 6 ms).
     PinnedImage image;
+    DrainOnExit drain(&own_stream_);  // (declared behind the buffers it protects: an early return waits for the copies first)
     HIP_TRY(image.get(hist_bytes));
     std::memset(image.p, 0, hist_bytes);
     if (!hist.empty()) std::memcpy(image.p, hist.data(), hist_elems * n_streams_ * sizeof(float));
     for (int i = 0; i < 2; i++)
       HIP_TRY(hipMemcpyAsync(n.hist[i], image.p, hist_bytes, hipMemcpyHostToDevice, own_stream_));
     HIP_TRY(hipStreamSynchronize(own_stream_));  // the new buffers are in place for a launch on any stream
+    drain.armed = false;
   }
-  hist_bytes_ = hist_bytes;
   // What the batch held goes back to the pool / the cache below, so nothing in flight may still read it:
   // wait for this batch's own last call -- not for the device: other states' launches keep running.
   if (tables_ != nullptr) {
@@ -418,6 +419,7 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
   // commit: nothing below can fail
+  hist_bytes_ = hist_bytes;
   std::swap(d_hist_[0], n.hist[0]);
   std::swap(d_hist_[1], n.hist[1]);  // (~Fresh releases the old history buffers)
   tables_ = tables;
@@ -442,12 +444,33 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
 }
 
 // Wait for what THIS batch has enqueued.  Calls on one batch are ordered (a call on another stream
-// than the previous one waits for it on the device, run_plans), so the previous call's stream ends
-// with the batch's last piece of work; the control stream's own copies are waited for where they are
-// issued.  Contract for the device-pointer calls: the stream of a state's most recent call stays
-// valid until the state's next call, control call or destruction (include/speexhip_resampler.h).
+// than the previous one waits for it on the device, chain_to), so the event behind the last device-pointer
+// call stands for all of the batch's work; the control stream's own copies are waited for where they are
+// issued.  The event is the batch's own: nothing here depends on a caller's stream still existing.
 int Batch::quiesce() {
-  if (have_last_stream_) HIP_TRY(hipStreamSynchronize(last_stream_));
+  if (done_pending_) {
+    HIP_TRY(hipEventSynchronize(done_ev_));
+    done_pending_ = false;
+  }
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int Batch::chain_to(hipStream_t stream) {
+  if (done_pending_ && stream != last_stream_) HIP_TRY(hipStreamWaitEvent(stream, done_ev_, 0));
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int Batch::mark_launched(hipStream_t stream) {
+  last_stream_ = stream;
+  if (own_stream_ != nullptr && stream == own_stream_) {
+    // a host-buffer call: it waits for this stream before it returns (or drains it on its error exits), and the
+    // stream has already waited for whatever done_ev_ stood for (chain_to)
+    done_pending_ = false;
+    return SPEEXHIP_ERR_SUCCESS;
+  }
+  if (done_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &done_ev_));
+  HIP_TRY(hipEventRecord(done_ev_, stream));
+  done_pending_ = true;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -535,6 +558,9 @@ int Batch::change_filter(const FilterSpec &next, int design_rc, const std::vecto
     return rc;
   }
   zero_mode_ = false;
+  // (a filter change that succeeded after a set_rate_frac had overflowed -- set_quality with the old ratio: what
+  //  get_rate / get_ratio show is the filter in force again, not rates that never were)
+  shown_valid_ = false;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -620,7 +646,7 @@ Batch::~Batch() {
   // this batch's calls are chained, so the tail of its last stream is all there is to wait for
   // (a device-wide wait here stalled a server's every other state behind one state's garbage collection)
   (void)quiesce();
-  pool::event_put(device_, order_ev_);
+  pool::event_put(device_, done_ev_);
   tables_.reset();  // shared (DeviceTables): the cache keeps them for the next state with this filter
   pool::device_put(device_, d_hist_[0]);
   pool::device_put(device_, d_hist_[1]);
@@ -723,13 +749,8 @@ int Batch::run_channel(uint32_t c, const void *d_in, uint32_t in_stride, uint32_
   const uint32_t walked = plan.magic_used + plan.consumed;
   if (float_io) float_seen_ = true;
   if (plan.produced == 0 && walked == 0) return SPEEXHIP_ERR_SUCCESS;
-  if (have_last_stream_ && stream != last_stream_) {
-    if (order_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &order_ev_));
-    HIP_TRY(hipEventRecord(order_ev_, last_stream_));
-    HIP_TRY(hipStreamWaitEvent(stream, order_ev_, 0));
-  }
-  last_stream_ = stream;
-  have_last_stream_ = true;
+  int chain_rc = chain_to(stream);
+  if (chain_rc != SPEEXHIP_ERR_SUCCESS) return chain_rc;
   DescPack pack;
   std::memset(&pack, 0, sizeof(pack));
   StreamDesc &d = pack.d[0];
@@ -758,7 +779,7 @@ int Batch::run_channel(uint32_t c, const void *d_in, uint32_t in_stride, uint32_
     HIP_TRY(hipMemcpy2DAsync(d_hist_[hist_cur_] + c, channels_ * sizeof(float), d_hist_[hist_cur_ ^ 1] + c,
                              channels_ * sizeof(float), sizeof(float), d.hist_keep, hipMemcpyDeviceToDevice,
                              stream));
-  return SPEEXHIP_ERR_SUCCESS;
+  return mark_launched(stream);
 }
 
 // The interleaved call on a stream whose channels stand at different positions: channel by
@@ -836,13 +857,8 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
     // Calls on one batch are ordered (each reads the history the previous one left and the
     // ping-pong buffers alternate): a call enqueued on another stream than the previous one
     // waits for it on the device.
-    if (have_last_stream_ && stream != last_stream_) {
-      if (order_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &order_ev_));
-      HIP_TRY(hipEventRecord(order_ev_, last_stream_));
-      HIP_TRY(hipStreamWaitEvent(stream, order_ev_, 0));
-    }
-    last_stream_ = stream;
-    have_last_stream_ = true;
+    const int chain_rc = chain_to(stream);
+    if (chain_rc != SPEEXHIP_ERR_SUCCESS) return chain_rc;
     const StreamDesc *d_descs = nullptr;
     if (!packed) {
       StreamDesc *dst = d_ring_ + static_cast<size_t>(slot) * n_streams_;
@@ -878,6 +894,8 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       ring_busy_[slot] = true;
     }
     hist_cur_ ^= 1;
+    const int mark_rc = mark_launched(stream);
+    if (mark_rc != SPEEXHIP_ERR_SUCCESS) return mark_rc;
   }
   for (uint32_t s = 0; s < n_streams_; s++)
     for (uint32_t c = 0; c < channels_; c++) P(s, c) = plans[s].end;
@@ -965,7 +983,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     // The wait: hipStreamSynchronize after a tiny launch costs 11-12 us on this stack; a 32-bit stream write behind
     // the kernel (hipStreamWriteValue32: performed once everything before it on the stream has completed) into
     // pinned memory, polled by the caller, 8.8 (tools/ubench_sync.hip).  A launch that has not signalled after
-    // 2 ms is waited for -- and its error, if that is what happened, reported -- the ordinary way.
+    // 300 us is waited for -- and its error, if that is what happened, reported -- the ordinary way.
     static const bool poll_done = std::getenv("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
     volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(h_pin_out_ + ((pin_out_cap_ - 64) & ~static_cast<size_t>(63)));
     const uint32_t seq = ++done_seq_;
@@ -974,10 +992,14 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
     bool signalled = false;
     if (poll_done && hipStreamWriteValue32(own_stream_, const_cast<uint32_t *>(done), seq, 0) == hipSuccess) {
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+      // (the pool's streams are shared by all states: behind another state's long launch the word will not come
+      //  soon, so the spin is short -- 300 us, `pause` between the reads -- and then the thread sleeps in the runtime)
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
       for (uint32_t spins = 0; !signalled; spins++) {
         signalled = __atomic_load_n(const_cast<const uint32_t *>(done), __ATOMIC_ACQUIRE) == seq;
-        if (!signalled && (spins & 255u) == 255u && std::chrono::steady_clock::now() > deadline) break;
+        if (signalled) break;
+        __builtin_ia32_pause();
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
       }
     } else {
       (void)hipGetLastError();

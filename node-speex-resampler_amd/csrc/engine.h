@@ -178,10 +178,17 @@ class Batch {
   bool ring_busy_[kRing] = {};
   int ring_next_ = 0;
 
-  // stream of the previous launch (calls on different streams are chained with an event)
-  hipStream_t last_stream_ = nullptr;
-  bool have_last_stream_ = false;
-  hipEvent_t order_ev_ = nullptr;
+  // Calls on one batch are chained.  A device-pointer call records the batch's OWN event behind its launch on the
+  // caller's stream; the next call on another stream waits for that event on the device, and the control calls /
+  // the destructor wait for it on the host (quiesce).  Nothing is ever asked of the caller's stream after the call
+  // that used it has returned, so the caller may destroy it whenever its own synchronisation allows (round 4; until
+  // then the batch synchronised with / recorded on the previous call's stream).  Host-buffer calls run on the
+  // pool's stream and wait before they return: nothing of theirs is pending afterwards.
+  hipStream_t last_stream_ = nullptr;  // compared only, never used
+  bool done_pending_ = false;          // done_ev_ stands for work that may still be in flight
+  hipEvent_t done_ev_ = nullptr;
+  int chain_to(hipStream_t stream);       // before a launch on `stream`
+  int mark_launched(hipStream_t stream);  // behind it
 
   // host-buffer path (single stream)
   hipStream_t own_stream_ = nullptr;

@@ -229,7 +229,9 @@ def debug_plan(ratio_num, ratio_den, quality, channels):
         raise ValueError(strerror(rc))
     v = list(out)
     return {"fast_path": v[0], "r_or_p": v[1], "lane_periods": v[2], "row_len": v[3], "lds_bytes": v[4],
-            "pad": v[5], "fine_plan": bool(v[6]), "steps_per_iteration": v[7],
+            "pad": v[5], "fine_plan": bool(v[6]),
+            # slide kernel: tap steps per loop iteration (out[7] means something else for period plans)
+            "steps_per_iteration": v[7] if v[0] != 2 else 0,
             # period kernel: periods per tile of the int16-window plan that int16 calls take (0 = none)
             "w16_lane_periods": v[7] if v[0] == 2 else 0}
 

@@ -1351,3 +1351,105 @@ def test_int16_window_plan_serves_int16_calls_until_a_float_call():
                     assert (used[s], made[s]) == (wu, want.shape[0]), (ch, i, o, step, s)
                     assert_close(out[s, : made[s]], want, "w16 batch %s step %d stream %d" % ((ch, i, o, q), step, s))
         b.close()
+
+
+def test_device_pointer_call_asks_nothing_of_the_caller_s_stream_afterwards():
+    """Round 4: a state orders its calls through an event of its OWN, recorded behind each
+    device-pointer launch -- not by synchronising with / recording on the previous call's stream.  A caller
+    that creates a stream per call and destroys it after its own synchronisation must find every later call of
+    the state working: the next call on another stream, the control calls, the history read, destruction."""
+    import ctypes
+    import torch
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    ch, i, o, q, frames, cap = 2, 44100, 48000, 7, 50000, 60000
+    r = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT)
+    ref = orc.Oracle(ch, i, o, q)
+    d_out = torch.zeros((cap, ch), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    for call in range(4):
+        x = orc.lcg_pcm(frames * ch, 40 + call).reshape(frames, ch)
+        d_in = torch.from_numpy(x).cuda()
+        torch.cuda.synchronize()
+        s = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+        used, made = r.process_device(d_in.data_ptr(), frames, d_out.data_ptr(), cap, s.value)
+        if call % 2 == 0:                      # the caller's own synchronisation, then the stream is gone
+            assert hip.hipStreamSynchronize(s) == 0
+        assert hip.hipStreamDestroy(s) == 0    # (destroying a busy stream is legal: its work still completes)
+        want, wu = ref.process(x, cap)
+        assert (used, made) == (wu, want.shape[0])
+        if call == 1:
+            assert r.set_quality(5) == 0 and ref.set_quality(5) == 0      # control call: waits on the state's event
+        if call == 2:
+            got, gu = r.process(x, cap)                                   # host-buffer call chained behind it
+            want2, wu2 = ref.process(x, cap)
+            assert gu == wu2 and np.array_equal(got, want2)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out[:made].cpu().numpy(), want), call
+    h = r.history()
+    for c in range(ch):
+        assert np.array_equal(h[:, c], ref.history(c))
+    r.close()                                  # destruction with the last stream long gone
+
+
+def test_filter_change_after_an_overflowed_set_rate_puts_visible_and_effective_state_back_in_step():
+    """after set_rate_frac returned OVERFLOW the shown rates stayed the failed call's until a later
+    set_rate_frac; a set_quality in between (which rebuilds the filter for the ratio in force) left get_rate /
+    get_ratio reporting rates that were never in force.  Any filter change that succeeds now ends that."""
+    ch, a, b = 1, 100003, 99991
+    big = (99989, 100019, 99989, 100019)
+    r = speexhip.Resampler(ch, a, b, 3, mode=speexhip.MODE_EXACT)
+    twin = orc.Oracle(ch, a, b, 3)
+    seed = 1
+    while True:
+        x = orc.lcg_pcm(777 * ch, seed).reshape(777, ch)
+        r.process(x, 5000)
+        twin.process(x, 5000)
+        seed += 1
+        if twin.position()[1] * big[1] >= 1 << 32:
+            break
+        assert seed < 50
+    assert r.set_rate_frac(*big) == speexhip.ERR_OVERFLOW
+    assert r.rate() == (big[2], big[3])
+    assert r.set_quality(5) == 0 and twin.set_quality(5) == 0
+    assert r.rate() == (a, b) and r.ratio() == twin.ratio()
+    x = orc.lcg_pcm(3000 * ch, 7).reshape(3000, ch)
+    got, used = r.process(x, 5000)
+    want, wu = twin.process(x, 5000)
+    assert used == wu and np.array_equal(got, want)
+    assert r.set_rate_frac(*big) in (0, speexhip.ERR_OVERFLOW)   # no longer the silent no-op of a repeated call
+    r.close()
+
+
+@pytest.mark.parametrize("ch,i,o,q", [(2, 44100, 48000, 7), (1, 48000, 11025, 5), (2, 48000, 8000, 8), (1, 24000, 48000, 10)])
+def test_fast_mode_is_within_tolerance_of_itself_across_chunkings(ch, i, o, q):
+    """FAST output is NOT invariant to chunking or batching: the launch shape -- phases per
+    wave, tap-range shares, int16 or float window -- is chosen per launch and shares add partial sums in another
+    order.  What holds: every chunking is within +-1 LSB of the reference, hence within 2 LSB of any other, and
+    the counters are equal."""
+    frames = 400000
+    x = orc.lcg_pcm(frames * ch, 5).reshape(frames, ch)
+    cap = int(frames * o / i) + 64
+    whole = speexhip.Resampler(ch, i, o, q)
+    a, ua = whole.process(x, cap)
+    whole.close()
+    pieces = speexhip.Resampler(ch, i, o, q)
+    out, used = [], 0
+    for n in (480, 100000, 7, 20000, 250000, frames):
+        n = min(n, frames - used)
+        if n == 0:
+            break
+        g, u = pieces.process(x[used:used + n], cap)
+        assert u == n
+        out.append(g)
+        used += n
+    pieces.close()
+    b = np.concatenate(out)
+    want, _ = orc.Oracle(ch, i, o, q).process(x, cap)
+    assert ua == frames and a.shape == b.shape == want.shape
+    assert_close(a, want, "one call")
+    assert_close(b, want, "six calls")
+    assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2 * TOL_LSB

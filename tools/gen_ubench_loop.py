@@ -53,9 +53,14 @@ def loads(bank, byte_off):
     return out
 
 
+ROW_BYTES = 520  # period-minor window (round 4): a row = one offset inside the period for 64 (+1) periods of 8 bytes
+
+
 def ds(x, off, kind):
     if kind == "same":     # every lane the same address: broadcast, no bank work (diagnostic)
         return "ds_read_b64 %%[%s], %%[zero] offset:%d" % (x, off)
+    if kind == "contig":   # period-minor window: the 64 lanes read 512 consecutive bytes, a step is a row further
+        return "ds_read_b64 %%[%s], %%[addrc] offset:%d" % (x, off // 8 * ROW_BYTES)
     return "ds_read_b64 %%[%s], %%[addr] offset:%d" % (x, off)
 
 
@@ -74,6 +79,8 @@ def variant(scheme, smem=True, lds="b64", waits=2):
     pro = loads(sc["A"], 0) + ([] if smem else loads(sc["B"], bank_bytes) + ["s_waitcnt lgkmcnt(0)"])
     fa, fb = fma_bank(sc, sc["A"], xa), fma_bank(sc, sc["B"], xb)
     adv = ["v_add_u32 %%[addr], %d, %%[addr]" % (16 * S)] if lds else []
+    if lds == "contig":
+        adv = ["v_add_u32 %%[addrc], 0x%x, %%[addrc]" % (2 * S * ROW_BYTES)]
     if waits == 2:
         pro += rd(xa, 0)
         body = ["1:"] + wait + (loads(sc["B"], bank_bytes) if smem else []) + rd(xb, S) + fa
@@ -98,6 +105,8 @@ VARIANTS = [
     ("nosmem", "r10b20", dict(smem=False), 16, "  ... without the scalar tap loads (diagnostic)"),
     ("bare", "r10b20", dict(smem=False, lds=None), 16, "  ... FMAs + count only (diagnostic)"),
     ("same", "r10b20", dict(lds="same"), 16, "  ... every lane reads the same LDS address (diagnostic)"),
+    ("contig", "r10b20", dict(lds="contig"), 16, "  ... period-minor window: a wave reads 512 consecutive bytes per step (round 4)"),
+    ("contignos", "r10b20", dict(lds="contig", smem=False), 16, "  ... the same without the scalar tap loads (diagnostic)"),
     ("nosmem1w", "r10b20", dict(smem=False, waits=1), 16, "  ... no tap loads, ONE wait per 40 FMAs, samples requested 40 FMAs ahead (diagnostic)"),
     ("b30", "r10b30", {}, 16, "R=10, banks of 30 taps (3 steps): a wait per 30 FMAs"),
     ("b30nolds", "r10b30", dict(lds=None), 16, "  ... without the LDS sample reads (diagnostic)"),
@@ -142,6 +151,7 @@ void fir(const float *__restrict__ rows, float *__restrict__ out, int reps, int 
     const char *p = reinterpret_cast<const char *>(trow) + ITERS * TRIP_BYTES - (1ll << 32);
     uint32_t off = 0u - ITERS * (uint32_t)TRIP_BYTES;
     uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xp));
+    uint32_t addrc = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) + lane * 8 + (wave & 1) * 8;  // period-minor window
     f32x2 x0, x1, x2, x3, x4, x5, y0, y1, y2, y3;
     x0 = x1 = x2 = x3 = x4 = x5 = y0 = y1 = y2 = y3 = f32x2{(float)lane, 1.f};
     const uint32_t zero = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) + wave * 144;
@@ -207,7 +217,7 @@ def main():
         if constexpr (R == %d) {
         asm volatile(
 %s
-          : %s, %s, [off] "+s"(off), [addr] "+v"(addr)
+          : %s, %s, [off] "+s"(off), [addr] "+v"(addr), [addrc] "+v"(addrc)
           : [p] "s"(p), [zero] "v"(zero)
           : %s, "scc", "memory");
         }
