@@ -52,6 +52,8 @@ CONFIG_LABEL = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "c
                 "f3": "SURVEY F3 (direct_single)"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
+VALU64_PEAK_TFLOPS = 78.6  # fp64 vector peak: v_fma_f64 issues at the rate of v_pk_fma_f32, half the FMAs each
+                           # (tools/ubench_fma64.hip, profiles/r04_ubench_fma64.txt)
 PMC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
@@ -201,7 +203,9 @@ def parse_args(argv=None):
                     help="independent streams in the WHOLE JOB, stream s on rank s %% N (strong scaling; "
                          "256 = BASELINE configs[4]); overrides --streams")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
-    ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact", "fast_f32"],
+                    help="fast: +-1 LSB, fp64 accumulator where the reference has one (q9, q10); fast_f32: one fp32 "
+                         "FMA chain for every filter (rounds 1-3); exact: the reference's arithmetic order")
     ap.add_argument("--io", default="int16", choices=["int16", "float"],
                     help="sample type of the buffers: int16 = the BASELINE metric; float = the N2 entry point")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
@@ -301,7 +305,7 @@ def main():
         sys.exit("bench.py: rank %d owns no stream (--total-streams %d over %d ranks)" % (rank, args.total_streams, world))
     streams_total = args.total_streams if strong else args.streams * world
     cap = wrapper_capacity(F * ch * 2, fi, fo, ch)
-    mode = speexhip.MODE_EXACT if args.mode == "exact" else speexhip.MODE_FAST
+    mode = {"exact": speexhip.MODE_EXACT, "fast": speexhip.MODE_FAST, "fast_f32": speexhip.MODE_FAST_F32}[args.mode]
     batch = speexhip.Batch(S, ch, fi, fo, q, mode=mode)
     info = batch.info()
 
@@ -389,6 +393,9 @@ def main():
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         flops = 2.0 * info["filt_len"] * produced * ch / args.steps  # minimal form, 2*N per output
         tfl = flops / (launch_ms * 1e-3) / 1e12
+        # the vector peak of the arithmetic the launch runs: fp64 for the v_fma_f64 kernels and for the exact kernels of
+        # the double kinds (fp32 multiplies + fp64 adds: priced against fp64 as well)
+        valu_peak = VALU64_PEAK_TFLOPS if info["accumulate_bits"] == 64 else VALU_PEAK_TFLOPS
         traffic = None
         pmc = os.path.join(ROOT, PMC_FILE)
         if os.path.exists(pmc) and not args.custom and F == 1 << 20:  # (the file holds the named workloads only)
@@ -408,7 +415,7 @@ def main():
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f64" if info["accumulate_bits"] == 64 else "f32", "data": "synthetic",
             "config": {"workload": "%s%s: %d->%d Hz, %dch %s, q=%d, %d-frame chunk per stream per step; %s" % (
                            CONFIG_LABEL[args.config],
                            " as BASELINE configs[4] (sharded streams)" if strong and args.config == "cfg2" else "",
@@ -419,9 +426,11 @@ def main():
                        "mode": args.mode, "io": args.io, "preheat_ms": args.preheat_ms,
                        "kernel": speexhip.KERNEL_NAMES[info["kernel"]], "fast_path": info["fast_path"],
                        "filt_len": info["filt_len"],
-                       "accumulate": "f32 FMA chain (reference: %s)" % (
-                           "f64 sums of f32 products" if info["kernel"] in (1, 3) else "f32") if args.mode == "fast"
-                       else "as the reference",
+                       "accumulate": ("as the reference" if args.mode == "exact" else
+                                      "f64: v_fma_f64 chain, exact products (reference: f64 sums of f32 products)"
+                                      if info["accumulate_bits"] == 64 else
+                                      "f32 FMA chain (reference: %s)" % (
+                                          "f64 sums of f32 products" if info["kernel"] in (1, 3) else "f32")),
                        "parallelism": "independent streams sharded over %d rank(s), no data-path collective" % world},
             "timing": {"reps": reps, "host_issue_us_per_step": round(host_issue_us, 3),
                        "host_bound": bool(host_issue_us >= 0.95 * launch_ms * 1e3),
@@ -440,9 +449,10 @@ def main():
                          "launch_us_max": round(max(gpu) / args.steps * 1e3, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_only_frac": round(consumed * ch * es / args.steps / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "fp32 vector-ALU bound, not HBM bound (SURVEY F4); see valu"},
-            "valu": {"achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tfl / VALU_PEAK_TFLOPS, 4), "flops_per_launch": int(flops)},
+                         "note": "vector-ALU bound, not HBM bound (SURVEY F4); see valu"},
+            "valu": {"achieved": round(tfl, 2), "peak": valu_peak, "unit": "TFLOP/s",
+                     "frac": round(tfl / valu_peak, 4), "flops_per_launch": int(flops),
+                     "arithmetic": "fp64 vector" if valu_peak == VALU64_PEAK_TFLOPS else "fp32 vector"},
             "checksum": checksum,
         }
         if share:

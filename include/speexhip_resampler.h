@@ -40,7 +40,12 @@ enum {
   SPEEXHIP_ERR_MAX_ERROR
 };
 
-enum { SPEEXHIP_MODE_FAST = 0, SPEEXHIP_MODE_EXACT = 1 };
+enum {
+  SPEEXHIP_MODE_FAST = 0,      /* +-1 LSB; the filters the reference sums in fp64 (quality 9, 10) in fp64 */
+  SPEEXHIP_MODE_EXACT = 1,     /* bit-identical arithmetic order */
+  SPEEXHIP_MODE_FAST_F32 = 2   /* FAST with one fp32 FMA chain for every filter (the fast path of rounds 1-3):
+                                  narrower than the reference's accumulator at quality 9 and 10, still +-1 LSB */
+};
 
 /* Which of the reference's inner kernels the (rates, quality) pair selects
  * (deps/speex/resample.c:647-648,682-698). */
@@ -169,17 +174,23 @@ SPEEXHIP_API const char *speexhip_resampler_strerror(int err);
  * returns without waiting for the GPU.  The stream position advances on the host at once
  * (it is integer arithmetic, independent of the audio), so *in_len / *out_len are final on
  * return.  d_in must stay valid until the stream has executed the call.  Calls on one state are
- * ordered: the call records an event of the state's own behind its launch; the next call -- on
- * whatever stream -- first waits for that event on the device, and control calls and destroy wait
- * for it on the host (for this state's last call only, never for the device: other states'
- * launches keep running).  Nothing is asked of `hip_stream` once the call has returned: the
- * caller may destroy it as soon as its own use of it allows (round 4; before, the stream had to
- * outlive the state's next call). */
+ * ordered: the next call -- on whatever stream -- first waits for this one on the device (an event
+ * recorded on `hip_stream` at that moment), and control calls and destroy wait for `hip_stream` on
+ * the host (for this state's last call only, never for the device: other states' launches keep
+ * running).  `hip_stream` must therefore stay valid until the state's NEXT call of any kind --
+ * or be handed back with speexhip_resampler_release_stream() before the caller destroys it (a
+ * destroyed stream's handle cannot be recognised afterwards: this runtime dereferences it). */
 SPEEXHIP_API int speexhip_resampler_process_interleaved_int_device(SpeexHipResamplerState *st,
                                                                    const int16_t *d_in,
                                                                    uint32_t *in_len, int16_t *d_out,
                                                                    uint32_t *out_len,
                                                                    void *hip_stream);
+
+/* The caller is about to destroy the stream of this state's last device-pointer call (one stream per
+ * request, say): what that call still has in flight is ordered behind an event of the state's own and
+ * the stream is forgotten -- later calls, control calls and destroy wait for the event instead.  Costs one
+ * hipEventRecord (about 3 us of stream time on this stack, which is why it is not done after every call). */
+SPEEXHIP_API int speexhip_resampler_release_stream(SpeexHipResamplerState *st);
 
 SPEEXHIP_API int speexhip_resampler_process_interleaved_float_device(SpeexHipResamplerState *st,
                                                                      const float *d_in,
@@ -212,8 +223,9 @@ SPEEXHIP_API int speexhip_resampler_process_chunks_float(SpeexHipResamplerState 
 SPEEXHIP_API int speexhip_resampler_peek(SpeexHipResamplerState *st, uint32_t in_len, uint32_t out_capacity,
                                          int float_entry, uint32_t *consumed, uint32_t *produced);
 
-/* SPEEXHIP_MODE_FAST (default; +-1 LSB) or SPEEXHIP_MODE_EXACT (bit-identical arithmetic
- * order, slower).  The environment variable SPEEXHIP_MODE=exact|fast sets the initial mode. */
+/* SPEEXHIP_MODE_FAST (default; +-1 LSB), SPEEXHIP_MODE_EXACT (bit-identical arithmetic order,
+ * slower) or SPEEXHIP_MODE_FAST_F32.  The environment variable SPEEXHIP_MODE=exact|fast|fast_f32
+ * sets the initial mode. */
 SPEEXHIP_API int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode);
 
 typedef struct SpeexHipInfo {
@@ -226,14 +238,18 @@ typedef struct SpeexHipInfo {
   uint32_t sinc_table_length;    /* floats, resample.c:652,657 */
   int32_t kernel;                /* SPEEXHIP_KERNEL_* */
   int32_t mode;                  /* SPEEXHIP_MODE_* */
-  int32_t fast_path;             /* what FAST mode runs for this configuration: 2 = period-lane
-                                    kernel, 3 = small-ratio sliding-window kernel, 0 = falls back
-                                    to the exact kernel (exotic ratios) */
+  int32_t fast_path;             /* what the fast modes run for this configuration: 2 = period-lane
+                                    kernel, 3 = small-ratio sliding-window kernel, 4 / 5 = their
+                                    fp64-accumulate twins (FAST mode, quality 9 and 10), 0 = falls
+                                    back to the exact kernel (exotic ratios) */
   int32_t last_sample;           /* stream position, resample.c:135 */
   uint32_t samp_frac_num;        /* stream phase, resample.c:136 */
   int32_t device;                /* HIP device ordinal the state lives on */
   uint32_t magic_samples;        /* pending frames buffered after the history, resample.c:137 */
   uint32_t block_in;             /* frames per block: mem_alloc_size-(filt_len-1), resample.c:935 */
+  int32_t accumulate_bits;       /* accumulator of what the current mode runs for this filter: 32 (fp32 FMA chain;
+                                    exact kernels of the single kinds) or 64 (v_fma_f64 fast kernels, fast_path 4 / 5;
+                                    exact kernels of the double kinds: fp64 sums of fp32 products) */
 } SpeexHipInfo;
 
 SPEEXHIP_API int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info);
@@ -254,6 +270,7 @@ SPEEXHIP_API SpeexHipBatch *speexhip_batch_init(uint32_t n_streams, uint32_t nb_
 SPEEXHIP_API void speexhip_batch_destroy(SpeexHipBatch *b);
 SPEEXHIP_API int speexhip_batch_set_mode(SpeexHipBatch *b, int mode);
 SPEEXHIP_API int speexhip_batch_get_info(SpeexHipBatch *b, uint32_t stream, SpeexHipInfo *info);
+SPEEXHIP_API int speexhip_batch_release_stream(SpeexHipBatch *b);  /* see speexhip_resampler_release_stream */
 SPEEXHIP_API int speexhip_batch_process_interleaved_int_device(
     SpeexHipBatch *b, const int16_t *d_in, uint64_t in_stream_stride, uint32_t *in_len,
     int16_t *d_out, uint64_t out_stream_stride, uint32_t *out_len, void *hip_stream);

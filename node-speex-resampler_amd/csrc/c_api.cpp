@@ -283,6 +283,10 @@ int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode) {
   return guarded([&] { return st ? st->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG; });
 }
 
+int speexhip_resampler_release_stream(SpeexHipResamplerState *st) {
+  return guarded([&] { return st ? st->batch->release_stream() : SPEEXHIP_ERR_INVALID_ARG; });
+}
+
 int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info) {
   if (st == nullptr || info == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
   st->batch->info(0, info);
@@ -320,6 +324,10 @@ void speexhip_batch_destroy(SpeexHipBatch *b) {
 
 int speexhip_batch_set_mode(SpeexHipBatch *b, int mode) {
   return guarded([&] { return b ? b->batch->set_mode(mode) : SPEEXHIP_ERR_INVALID_ARG; });
+}
+
+int speexhip_batch_release_stream(SpeexHipBatch *b) {
+  return guarded([&] { return b ? b->batch->release_stream() : SPEEXHIP_ERR_INVALID_ARG; });
 }
 
 int speexhip_batch_get_info(SpeexHipBatch *b, uint32_t stream, SpeexHipInfo *info) {

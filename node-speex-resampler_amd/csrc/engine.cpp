@@ -206,6 +206,7 @@ int Batch::setup() {
   }
   const char *m = std::getenv("SPEEXHIP_MODE");
   if (m != nullptr && std::strcmp(m, "exact") == 0) mode_ = SPEEXHIP_MODE_EXACT;
+  if (m != nullptr && std::strcmp(m, "fast_f32") == 0) mode_ = SPEEXHIP_MODE_FAST_F32;
 
   pos_.assign(static_cast<size_t>(n_streams_) * channels_, StreamPos());
   started_.assign(n_streams_, 0);
@@ -228,6 +229,7 @@ DeviceTables::~DeviceTables() {
   pool::device_put(device, fine_rows);
   pool::device_put(device, w16_rows);
   pool::device_put(device, slide_rows);
+  pool::device_put(device, slide64_rows);
 }
 
 namespace {
@@ -262,15 +264,18 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   auto t = std::make_shared<DeviceTables>();
   t->device = device;
-  auto upload = [&](float **dst, const float *src, size_t count) -> int {
-    const int arc = dev_alloc(device, reinterpret_cast<void **>(dst), std::max(count * sizeof(float), kCtlCopyMin));
+  auto upload_bytes = [&](void **dst, const void *src, size_t bytes) -> int {
+    const int arc = dev_alloc(device, dst, std::max(bytes, kCtlCopyMin));
     if (arc != SPEEXHIP_ERR_SUCCESS) return arc;
-    if (count != 0) {
-      const int urc = ctl_upload(*dst, src, count * sizeof(float), stream);
+    if (bytes != 0) {
+      const int urc = ctl_upload(*dst, src, bytes, stream);
       if (urc != SPEEXHIP_ERR_SUCCESS) return urc;
     }
-    t->bytes += std::max(count * sizeof(float), kCtlCopyMin);
+    t->bytes += std::max(bytes, kCtlCopyMin);
     return SPEEXHIP_ERR_SUCCESS;
+  };
+  auto upload = [&](float **dst, const float *src, size_t count) -> int {
+    return upload_bytes(reinterpret_cast<void **>(dst), src, count * sizeof(float));
   };
   rc = upload(&t->table, f.table.data(), f.table_len);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
@@ -309,6 +314,16 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   } else {
     t->slide.usable = false;
+  }
+  // the reference's double kinds (quality 9, 10): fp64-accumulate twins of the fast kernels
+  if (f.kind == kDirectDouble || f.kind == kInterpolateDouble) {
+    if (t->slide.usable) t->slide64 = plan_slide64(f, channels);
+    if (t->slide64.usable) {
+      std::vector<double> rows;
+      build_slide64_rows(f, t->slide64, &rows);
+      rc = upload_bytes(reinterpret_cast<void **>(&t->slide64_rows), rows.data(), rows.size() * sizeof(double));
+      if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    }
   }
   *out = t;
   return SPEEXHIP_ERR_SUCCESS;
@@ -428,6 +443,7 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   d_period_fine_rows_ = tables->fine_rows;
   d_period_w16_rows_ = tables->w16_rows;
   d_slide_rows_ = tables->slide_rows;
+  d_slide64_rows_ = tables->slide64_rows;
   const std::vector<float> no_table;
   filter_ = f;
   filter_.table = no_table;  // the host copy of the sinc table lives only while the tables are built
@@ -440,37 +456,45 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   period_fine_ = tables->fine;
   period_w16_ = tables->w16;
   slide_ = tables->slide;
+  slide64_ = tables->slide64;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
 // Wait for what THIS batch has enqueued.  Calls on one batch are ordered (a call on another stream
-// than the previous one waits for it on the device, chain_to), so the event behind the last device-pointer
-// call stands for all of the batch's work; the control stream's own copies are waited for where they are
-// issued.  The event is the batch's own: nothing here depends on a caller's stream still existing.
+// than the previous one waits for it on the device, chain_to), so the previous call's stream ends
+// with the batch's last piece of work; the control stream's own copies are waited for where they are
+// issued.
 int Batch::quiesce() {
-  if (done_pending_) {
-    HIP_TRY(hipEventSynchronize(done_ev_));
-    done_pending_ = false;
+  if (ev_pending_) {
+    HIP_TRY(hipEventSynchronize(order_ev_));
+    ev_pending_ = false;
   }
+  if (have_last_stream_) HIP_TRY(hipStreamSynchronize(last_stream_));
   return SPEEXHIP_ERR_SUCCESS;
 }
 
 int Batch::chain_to(hipStream_t stream) {
-  if (done_pending_ && stream != last_stream_) HIP_TRY(hipStreamWaitEvent(stream, done_ev_, 0));
+  if (have_last_stream_ && stream != last_stream_) {
+    if (order_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &order_ev_));
+    HIP_TRY(hipEventRecord(order_ev_, last_stream_));
+    ev_pending_ = true;
+  }
+  if (ev_pending_) {
+    HIP_TRY(hipStreamWaitEvent(stream, order_ev_, 0));
+    ev_pending_ = false;  // (from here on the tail of `stream` stands for it)
+  }
+  last_stream_ = stream;
+  have_last_stream_ = true;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-int Batch::mark_launched(hipStream_t stream) {
-  last_stream_ = stream;
-  if (own_stream_ != nullptr && stream == own_stream_) {
-    // a host-buffer call: it waits for this stream before it returns (or drains it on its error exits), and the
-    // stream has already waited for whatever done_ev_ stood for (chain_to)
-    done_pending_ = false;
-    return SPEEXHIP_ERR_SUCCESS;
-  }
-  if (done_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &done_ev_));
-  HIP_TRY(hipEventRecord(done_ev_, stream));
-  done_pending_ = true;
+int Batch::release_stream() {
+  ON_DEVICE();
+  if (!have_last_stream_ || last_stream_ == own_stream_) return SPEEXHIP_ERR_SUCCESS;  // (the pool's streams never die)
+  if (order_ev_ == nullptr) HIP_TRY(pool::event_get(device_, &order_ev_));
+  HIP_TRY(hipEventRecord(order_ev_, last_stream_));
+  ev_pending_ = true;
+  have_last_stream_ = false;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -646,7 +670,7 @@ Batch::~Batch() {
   // this batch's calls are chained, so the tail of its last stream is all there is to wait for
   // (a device-wide wait here stalled a server's every other state behind one state's garbage collection)
   (void)quiesce();
-  pool::event_put(device_, done_ev_);
+  pool::event_put(device_, order_ev_);
   tables_.reset();  // shared (DeviceTables): the cache keeps them for the next state with this filter
   pool::device_put(device_, d_hist_[0]);
   pool::device_put(device_, d_hist_[1]);
@@ -669,7 +693,8 @@ CallPlan Batch::peek(uint32_t s, uint32_t in_len, uint32_t out_capacity, bool fl
 }
 
 int Batch::set_mode(int mode) {
-  if (mode != SPEEXHIP_MODE_FAST && mode != SPEEXHIP_MODE_EXACT) return SPEEXHIP_ERR_INVALID_ARG;
+  if (mode != SPEEXHIP_MODE_FAST && mode != SPEEXHIP_MODE_EXACT && mode != SPEEXHIP_MODE_FAST_F32)
+    return SPEEXHIP_ERR_INVALID_ARG;
   mode_ = mode;
   return SPEEXHIP_ERR_SUCCESS;
 }
@@ -688,6 +713,11 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
   o->kernel = filter_.kind;
   o->mode = mode_;
   o->fast_path = period_.usable ? 2 : (slide_.usable ? 3 : 0);
+  const bool double_kind = filter_.kind == kDirectDouble || filter_.kind == kInterpolateDouble;
+  // (what FAST would run: in EXACT mode too; FAST_F32 reports its own fp32-chain kernels)
+  if (double_kind && mode_ != SPEEXHIP_MODE_FAST_F32 && !period_.usable && slide64_.usable) o->fast_path = 4;
+  o->accumulate_bits = mode_ == SPEEXHIP_MODE_EXACT || o->fast_path == 0 ? (double_kind ? 64 : 32)
+                                                                          : (o->fast_path >= 4 ? 64 : 32);
   if (s < n_streams_) {
     o->last_sample = P(s, 0).last;
     o->samp_frac_num = P(s, 0).frac;
@@ -779,7 +809,7 @@ int Batch::run_channel(uint32_t c, const void *d_in, uint32_t in_stride, uint32_
     HIP_TRY(hipMemcpy2DAsync(d_hist_[hist_cur_] + c, channels_ * sizeof(float), d_hist_[hist_cur_ ^ 1] + c,
                              channels_ * sizeof(float), sizeof(float), d.hist_keep, hipMemcpyDeviceToDevice,
                              stream));
-  return mark_launched(stream);
+  return SPEEXHIP_ERR_SUCCESS;
 }
 
 // The interleaved call on a stream whose channels stand at different positions: channel by
@@ -866,6 +896,7 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       d_descs = dst;
     }
     hipError_t e;
+    const bool fast = mode_ != SPEEXHIP_MODE_EXACT;
     if (zero_mode_) {
       ExactGeometry geo = exact_geo_;  // (its window geometry belongs to the filter no longer in force)
       geo.staged = false;
@@ -873,16 +904,20 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       geo.outs_per_block = 256;
       e = launch_exact(filter_, geo, d_table_, channels_, d_descs, packed ? &pack : nullptr, n_streams_, max_out,
                        float_io, stream, nullptr, true);
-    } else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
+    } else if (fast && acc64() && !period_.usable && slide64_.usable) {
+      // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
+      e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, d_descs, packed ? &pack : nullptr,
+                         n_streams_, float_io, stream);
+    } else if (fast && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
                (w16_always() || period_launch_prefers_w16(filter_, period_, period_fine_.usable, descs, n_streams_)))
       // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- unless
       // the launch is too small for that to pay (period_launch_prefers_w16)
       e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, d_descs,
                         packed ? &pack : nullptr, n_streams_, false, stream);
-    else if (mode_ == SPEEXHIP_MODE_FAST && period_.usable)
+    else if (fast && period_.usable)
       e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs,
                         d_descs, packed ? &pack : nullptr, n_streams_, float_io, stream);
-    else if (mode_ == SPEEXHIP_MODE_FAST && slide_.usable)
+    else if (fast && slide_.usable)
       e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, d_descs,
                        packed ? &pack : nullptr, n_streams_, float_io, stream);
     else
@@ -894,8 +929,6 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       ring_busy_[slot] = true;
     }
     hist_cur_ ^= 1;
-    const int mark_rc = mark_launched(stream);
-    if (mark_rc != SPEEXHIP_ERR_SUCCESS) return mark_rc;
   }
   for (uint32_t s = 0; s < n_streams_; s++)
     for (uint32_t c = 0; c < channels_; c++) P(s, c) = plans[s].end;

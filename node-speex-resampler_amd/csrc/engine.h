@@ -34,9 +34,10 @@ struct DeviceTables {
   float *fine_rows = nullptr;    // ... R = 5 (launches of one generation)
   float *w16_rows = nullptr;     // ... with an int16 LDS window (wide windows; int16 calls)
   float *slide_rows = nullptr;   // kernels_slide.hip
+  double *slide64_rows = nullptr;  // kernels_slide64_impl.h: fp64 taps (filters of the reference's double kinds)
   ExactGeometry geo, geo_ch;     // exact kernel, all channels / one channel per launch
   PeriodPlan period, fine, w16;
-  SlidePlan slide;
+  SlidePlan slide, slide64;
   size_t bytes = 0;
   DeviceTables() = default;
   DeviceTables(const DeviceTables &) = delete;
@@ -99,6 +100,9 @@ class Batch {
   CallPlan peek(uint32_t s, uint32_t in_len, uint32_t out_capacity, bool float_io) const;
 
   int set_mode(int mode);
+  // The caller is about to destroy the stream of the state's last device-pointer call: order what is still in
+  // flight on it behind an event of the state's own and forget the stream.
+  int release_stream();
   void info(uint32_t stream, SpeexHipInfo *out) const;
   int history(uint32_t stream, float *dst);
   const FilterSpec &filter() const { return filter_; }
@@ -169,6 +173,11 @@ class Batch {
   bool float_seen_ = false;  // a float call has put samples into the histories that an int16 window cannot hold
   SlidePlan slide_;        // small-ratio fast path (kernels_slide.hip); neither usable -> exact
   float *d_slide_rows_ = nullptr;
+  SlidePlan slide64_;      // ... with an fp64 accumulator: what FAST runs for the double kinds (quality 9, 10)
+  double *d_slide64_rows_ = nullptr;
+  bool acc64() const {     // the fast path sums in fp64 (mode FAST on a filter the reference sums in fp64)
+    return mode_ == SPEEXHIP_MODE_FAST && (filter_.kind == kDirectDouble || filter_.kind == kInterpolateDouble);
+  }
 
   // descriptor transport for batches larger than kMaxPackedStreams
   static const int kRing = 32;
@@ -178,17 +187,20 @@ class Batch {
   bool ring_busy_[kRing] = {};
   int ring_next_ = 0;
 
-  // Calls on one batch are chained.  A device-pointer call records the batch's OWN event behind its launch on the
-  // caller's stream; the next call on another stream waits for that event on the device, and the control calls /
-  // the destructor wait for it on the host (quiesce).  Nothing is ever asked of the caller's stream after the call
-  // that used it has returned, so the caller may destroy it whenever its own synchronisation allows (round 4; until
-  // then the batch synchronised with / recorded on the previous call's stream).  Host-buffer calls run on the
-  // pool's stream and wait before they return: nothing of theirs is pending afterwards.
-  hipStream_t last_stream_ = nullptr;  // compared only, never used
-  bool done_pending_ = false;          // done_ev_ stands for work that may still be in flight
-  hipEvent_t done_ev_ = nullptr;
-  int chain_to(hipStream_t stream);       // before a launch on `stream`
-  int mark_launched(hipStream_t stream);  // behind it
+  // Calls on one batch are chained: a call on another stream than the previous one waits for it on the device
+  // (an event recorded on the previous stream at that moment), control calls and the destructor wait for the
+  // previous stream on the host.  So the stream of a device-pointer call must outlive the state's next call --
+  // unless the caller hands it back with release_stream(): the event is recorded then and the stream forgotten.
+  // (Round 4 tried an event of the batch's own recorded behind EVERY device-pointer launch, so that nothing would
+  // ever be asked of a caller's stream after its call: +3.0 us per launch on this stack -- BASELINE configs[1]
+  // 11.7 -> 14.7 us per step, profiles/r04_ab_done_event.txt.  And a stale handle cannot be recognised after the
+  // fact: this runtime dereferences it -- hipStreamSynchronize / hipEventRecord on a destroyed stream segfault,
+  // tools/probe_stream_gone.hip.)
+  hipStream_t last_stream_ = nullptr;
+  bool have_last_stream_ = false;
+  hipEvent_t order_ev_ = nullptr;
+  bool ev_pending_ = false;          // order_ev_ stands for the batch's last work (release_stream)
+  int chain_to(hipStream_t stream);  // before a launch on `stream`
 
   // host-buffer path (single stream)
   hipStream_t own_stream_ = nullptr;

@@ -100,4 +100,13 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
                         const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
                         uint32_t n_streams, bool float_io, hipStream_t stream);
 
+// ---- ... with an fp64 accumulator (kernels_slide64_impl.h, round 4): the reference's "double" kernels (quality 9
+// and 10, resample.c:389-435, :501-558) on the same ratios.  The plan reuses SlidePlan: np = den (accumulators per
+// period), cgroups = channels (one lane per channel of a lane block), pair_ch unused. ------------------------------
+SlidePlan plan_slide64(const FilterSpec &f, uint32_t channels);
+void build_slide64_rows(const FilterSpec &f, const SlidePlan &t, std::vector<double> *rows);
+hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double *d_rows, uint32_t channels,
+                          const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                          uint32_t n_streams, bool float_io, hipStream_t stream);
+
 }  // namespace speexhip

@@ -22,6 +22,16 @@ extern template hipError_t launch_slide_shape<int16_t>(const SlidePlan &, const 
 extern template hipError_t launch_slide_shape<float>(const SlidePlan &, const SlideParams &, const StreamDesc *,
                                                      const DescPack *, dim3, uint32_t, size_t, hipStream_t);
 
+template <typename T>
+hipError_t launch_slide64_shape(const SlidePlan &t, const SlideParams &p, const double *rows, const StreamDesc *d_descs,
+                                const DescPack *pack, dim3 grid, uint32_t threads, size_t lds, hipStream_t stream);
+extern template hipError_t launch_slide64_shape<int16_t>(const SlidePlan &, const SlideParams &, const double *,
+                                                         const StreamDesc *, const DescPack *, dim3, uint32_t, size_t,
+                                                         hipStream_t);
+extern template hipError_t launch_slide64_shape<float>(const SlidePlan &, const SlideParams &, const double *,
+                                                       const StreamDesc *, const DescPack *, dim3, uint32_t, size_t,
+                                                       hipStream_t);
+
 namespace {
 struct SlideShape { uint32_t num, np; bool pair_ch; uint32_t p; };
 // the instantiated (num, accumulator pairs per period, packing) -> periods per lane.  Bounds kept:
@@ -175,5 +185,118 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
                   : launch_slide_shape<int16_t>(t, p, d_descs, pack, grid, threads, lds, stream);
 }
 
+
+// ---- the fp64-accumulate twin (kernels_slide64_impl.h) ---------------------------------------------------------
+namespace {
+struct Slide64Shape { uint32_t num, den, p; };
+// (num, den) -> periods per lane.  Bounds: U*den <= 30 tap doubles per iteration (one bank of SGPR pairs; two banks
+// up to 16), a ring of 2U doubles + P*den accumulators + U raw samples within ~110 VGPRs.
+const Slide64Shape kShapes64[] = {
+    {1, 1, 8}, {1, 2, 8}, {1, 3, 8}, {1, 4, 4}, {1, 5, 4}, {1, 6, 4}, {2, 1, 8}, {2, 3, 4}, {2, 5, 2}, {3, 1, 4},
+    {3, 2, 4}, {3, 5, 2}, {4, 1, 4}, {4, 5, 1}, {5, 1, 4}, {5, 2, 2}, {5, 3, 2}, {5, 4, 1}, {5, 6, 1}, {6, 1, 2},
+    {6, 5, 1}, {7, 1, 2}, {8, 1, 2}, {8, 3, 1}, {9, 1, 2}, {10, 1, 2}, {12, 1, 1}, {16, 1, 1}, {20, 1, 1}, {24, 1, 1},
+};
+}  // namespace
+
+SlidePlan plan_slide64(const FilterSpec &f, uint32_t channels) {
+  SlidePlan t;
+  t.pair_ch = false;
+  t.np = f.den;
+  t.cgroups = channels;
+  t.num = f.num;
+  t.usable = false;
+  for (const Slide64Shape &sh : kShapes64)
+    if (sh.num == f.num && sh.den == f.den) {
+      t.p = sh.p;
+      t.usable = channels <= 64;
+    }
+  if (!t.usable) return t;
+  const uint32_t steps = t.p * f.num;
+  const uint32_t dmax = static_cast<uint32_t>((static_cast<uint64_t>(f.den - 1) * f.num) / f.den);
+  t.row_len = (f.taps + dmax + 2 * steps - 1) / (2 * steps) * (2 * steps);  // an even number of iterations
+  // row stride: the lanes of a wave read one float each, lane (block b, channel c) at b*stride + c: the pad with
+  // the fewest lanes of a wave on one bank
+  const uint32_t row_elems = steps * channels;
+  const uint32_t blocks = 64 / channels;
+  uint32_t best = 0xffffffffu;
+  t.row_stride = row_elems;
+  for (uint32_t pad = 0; pad < 32; pad++) {
+    uint32_t count[64] = {0}, worst = 0;
+    for (uint32_t b = 0; b < blocks; b++)
+      for (uint32_t c = 0; c < channels; c++) worst = std::max(worst, ++count[(b * (row_elems + pad) + c) % 64]);
+    if (worst < best) {
+      best = worst;
+      t.row_stride = row_elems + pad;
+    }
+  }
+  if (slide_lds_bytes(t, 2) > kSlideLdsLimit) t.usable = false;
+  return t;
+}
+
+void build_slide64_rows(const FilterSpec &f, const SlidePlan &t, std::vector<double> *rows) {
+  // [step][phase], rows of phase r shifted by delta_r, + one iteration of zero padding
+  rows->assign(static_cast<size_t>(t.row_len + t.p * f.num) * f.den, 0.0);
+  std::vector<double> h(f.taps);
+  for (uint32_t r = 0; r < f.den; r++) {
+    const uint32_t phase = static_cast<uint32_t>((static_cast<uint64_t>(r) * f.num) % f.den);
+    const uint32_t shift = static_cast<uint32_t>((static_cast<uint64_t>(r) * f.num) / f.den);
+    phase_taps(f, phase, h.data());
+    for (uint32_t j = 0; j < f.taps; j++) (*rows)[static_cast<size_t>(j + shift) * f.den + r] = h[j];
+  }
+}
+
+hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double *d_rows, uint32_t channels,
+                          const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                          uint32_t n_streams, bool float_io, hipStream_t stream) {
+  uint32_t max_periods = 0;
+  for (uint32_t s = 0; s < n_streams; s++) {
+    if (h_descs[s].n_out == 0) continue;
+    const uint64_t k_end = static_cast<uint64_t>(h_descs[s].k_shift) + h_descs[s].n_out;
+    max_periods = std::max<uint32_t>(max_periods, static_cast<uint32_t>((k_end + f.den - 1) / f.den));
+  }
+  const uint32_t blocks_per_wave = 64 / t.cgroups;
+  static const uint32_t max_waves = std::getenv("SPEEXHIP_SLIDE_WAVES") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_WAVES")) : 8;
+  uint32_t waves = max_waves;
+  while (waves > 2 && static_cast<uint64_t>(max_periods) * n_streams < 512ull * waves * blocks_per_wave * t.p)
+    waves /= 2;
+  while (waves > 2 && slide_lds_bytes(t, waves) > kSlideLdsLimit) waves /= 2;  // (fits with 2: plan_slide64)
+  SlideParams p;
+  p.rows = nullptr;  // (the fp64 rows travel as a kernel argument of their own)
+  p.den = f.den;
+  p.taps = f.taps;
+  p.row_len = t.row_len;
+  p.channels = channels;
+  p.cgroups = t.cgroups;
+  p.blocks_per_wave = blocks_per_wave;
+  p.blocks_per_tile = blocks_per_wave * waves;
+  p.row_stride = t.row_stride;
+  p.row_magic = period_magic_of(t.p * f.num * channels);
+  static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
+  p.skip = skip_mask;
+  const uint32_t tile_periods = p.blocks_per_tile * t.p;
+  const uint32_t tiles = (max_periods + tile_periods - 1) / tile_periods;
+  size_t lds = slide_lds_bytes(t, waves);
+  dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
+  // tap-range parts, by the slide kernel's rule (a wave's chain here: P x den x row_len fp64 FMAs)
+  static const int env_parts = std::getenv("SPEEXHIP_SLIDE_PARTS") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_PARTS")) : -1;
+  p.base_waves = waves;
+  p.parts = 1;
+  {
+    const uint32_t pairs = t.row_len / (t.p * f.num) / 2;
+    const uint64_t chain = static_cast<uint64_t>(t.p) * f.den * t.row_len;
+    uint32_t parts = 16 / waves;
+    if (env_parts > 0) parts = std::min<uint32_t>(parts, static_cast<uint32_t>(env_parts));
+    while (parts > 1 && (pairs / parts < 2 || static_cast<size_t>(parts - 1) * waves * t.p * f.den * 64 * 8 > kSlideLdsLimit)) parts--;
+    const bool small = static_cast<uint64_t>(tiles) * n_streams * waves <= 4ull * device_compute_units();
+    if (env_parts != 0 && parts > 1 && (env_parts > 0 || (small && chain >= 1500))) {
+      p.parts = parts;
+      lds = std::max(lds, static_cast<size_t>(parts - 1) * waves * t.p * f.den * 64 * 8);
+    }
+  }
+  const uint32_t threads = waves * p.parts * 64;
+  p.threads = threads;
+  return float_io ? launch_slide64_shape<float>(t, p, d_rows, d_descs, pack, grid, threads, lds, stream)
+                  : launch_slide64_shape<int16_t>(t, p, d_rows, d_descs, pack, grid, threads, lds, stream);
+}
 
 }  // namespace speexhip

@@ -1,0 +1,7 @@
+// kernels_slide64_f32.hip -- the fp64-accumulate slide kernel (kernels_slide64_impl.h) for float calls
+// (speex_resampler_process_interleaved_float, deps/speex/resample.c:1038-1059)
+#include "kernels_slide64_impl.h"
+namespace speexhip {
+template hipError_t launch_slide64_shape<float>(const SlidePlan &, const SlideParams &, const double *, const StreamDesc *,
+                                                const DescPack *, dim3, uint32_t, size_t, hipStream_t);
+}

@@ -477,7 +477,7 @@ static napi_value GetInfo(napi_env env, napi_callback_info info) {
   PUT_U32(in_rate) PUT_U32(out_rate) PUT_U32(num_rate) PUT_U32(den_rate) PUT_U32(nb_channels)
   PUT_I32(quality) PUT_U32(filt_len) PUT_U32(oversample) PUT_U32(sinc_table_length) PUT_I32(kernel)
   PUT_I32(mode) PUT_I32(fast_path) PUT_I32(last_sample) PUT_U32(samp_frac_num) PUT_I32(device)
-  PUT_U32(magic_samples) PUT_U32(block_in)
+  PUT_U32(magic_samples) PUT_U32(block_in) PUT_I32(accumulate_bits)
   return obj;
 }
 

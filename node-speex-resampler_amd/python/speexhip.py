@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (SPEEXHIP_LIB_PATH: same-box A/B of two builds of the library, tools/gpu_ab.sh; never set in tests)
 LIB_PATH = os.environ.get("SPEEXHIP_LIB_PATH") or os.path.join(PKG_DIR, "libspeexhip.so")
 
-MODE_FAST, MODE_EXACT = 0, 1
+MODE_FAST, MODE_EXACT, MODE_FAST_F32 = 0, 1, 2
 KERNEL_NAMES = ("direct_single", "direct_double", "interpolate_single", "interpolate_double")
 # reference codes (deps/speex/speex_resampler.h:104-113) + 6 = HIP failure
 ERR_SUCCESS, ERR_ALLOC_FAILED, ERR_BAD_STATE, ERR_INVALID_ARG, ERR_PTR_OVERLAP, ERR_OVERFLOW = 0, 1, 2, 3, 4, 5
@@ -47,6 +47,7 @@ EXPORTS = [
     "speexhip_resampler_set_output_stride", "speexhip_resampler_get_output_stride",
     "speexhip_resampler_get_channel_position", "speexhip_debug_fail_device_allocs",
     "speexhip_release_cached_memory", "speexhip_debug_plan",
+    "speexhip_resampler_release_stream", "speexhip_batch_release_stream",
 ]
 
 
@@ -56,7 +57,8 @@ class Info(C.Structure):
                 ("filt_len", C.c_uint32), ("oversample", C.c_uint32),
                 ("sinc_table_length", C.c_uint32), ("kernel", C.c_int32), ("mode", C.c_int32),
                 ("fast_path", C.c_int32), ("last_sample", C.c_int32), ("samp_frac_num", C.c_uint32),
-                ("device", C.c_int32), ("magic_samples", C.c_uint32), ("block_in", C.c_uint32)]
+                ("device", C.c_int32), ("magic_samples", C.c_uint32), ("block_in", C.c_uint32),
+                ("accumulate_bits", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -111,6 +113,10 @@ def lib():
         L.speexhip_batch_destroy.argtypes = [p]
         L.speexhip_batch_set_mode.restype = i32
         L.speexhip_batch_set_mode.argtypes = [p, i32]
+        L.speexhip_resampler_release_stream.restype = i32
+        L.speexhip_resampler_release_stream.argtypes = [p]
+        L.speexhip_batch_release_stream.restype = i32
+        L.speexhip_batch_release_stream.argtypes = [p]
         L.speexhip_batch_get_info.restype = i32
         L.speexhip_batch_get_info.argtypes = [p, u32, C.POINTER(Info)]
         L.speexhip_batch_process_interleaved_int_device.restype = i32
@@ -328,6 +334,12 @@ class Resampler:
         rc = lib().speexhip_resampler_set_mode(self._h, mode)
         if rc:
             raise ValueError(strerror(rc))
+
+    def release_stream(self):
+        """before the caller destroys the stream of this state's last device-pointer call"""
+        rc = lib().speexhip_resampler_release_stream(self._h)
+        if rc:
+            raise RuntimeError(strerror(rc))
 
     def info(self):
         i = Info()

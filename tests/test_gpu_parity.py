@@ -287,7 +287,8 @@ def test_small_ratio_sliding_window_kernel_variants():
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
-        assert r.info()["fast_path"] == 3, (ch, i, o, q, r.info()["fast_path"])
+        # (quality 9 and 10 -- the reference's double kernels -- take the fp64-accumulate twin, round 4)
+        assert r.info()["fast_path"] == (4 if q >= 9 else 3), (ch, i, o, q, r.info()["fast_path"])
         for call, frames in enumerate([1, 3000, 777, 20000]):
             x = orc.lcg_pcm(frames * ch, 31 * call + ch).reshape(frames, ch)
             cap = 7 * frames // 2 if call == 2 else 1 << 20  # one capacity-bound call
@@ -415,7 +416,7 @@ def test_n_to_one_decimation_takes_the_slide_kernel():
                           (4, 192000, 8000, 3)]:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
-        assert r.info()["fast_path"] == 3, (ch, i, o, q)
+        assert r.info()["fast_path"] == (4 if q >= 9 else 3), (ch, i, o, q)
         for call, frames in enumerate([60000, 5, 120001]):
             x = orc.tone_pcm(frames, ch, seed=call) if call else orc.lcg_pcm(frames * ch, 9).reshape(frames, ch)
             got, used = r.process(x, 1 << 20)
@@ -436,7 +437,7 @@ def test_slide_kernel_workgroups_shrink_to_the_lds():
     import torch
     ch, i, o, q, S, F = 8, 96000, 8000, 10, 24, 96000
     b = speexhip.Batch(S, ch, i, o, q)
-    assert b.info()["fast_path"] == 3
+    assert b.info()["fast_path"] == 4   # (q10: the fp64-accumulate slide kernel; same LDS image, same rule)
     x = np.stack([orc.lcg_pcm(F * ch, 50 + s).reshape(F, ch) for s in range(S)])
     d_in = torch.from_numpy(x).cuda()
     cap = F // 12 + 16
@@ -1353,11 +1354,12 @@ def test_int16_window_plan_serves_int16_calls_until_a_float_call():
         b.close()
 
 
-def test_device_pointer_call_asks_nothing_of_the_caller_s_stream_afterwards():
-    """Round 4: a state orders its calls through an event of its OWN, recorded behind each
-    device-pointer launch -- not by synchronising with / recording on the previous call's stream.  A caller
-    that creates a stream per call and destroys it after its own synchronisation must find every later call of
-    the state working: the next call on another stream, the control calls, the history read, destruction."""
+def test_a_caller_may_destroy_the_stream_of_a_device_pointer_call_after_release_stream():
+    """Round 4: control calls, the history read and the destructor wait for the stream of the state's
+    previous call, and the next call on another stream records an event on it -- so that stream must outlive the
+    state's next call.  A caller with one stream per request hands the stream back first
+    (speexhip_resampler_release_stream: one event of the state's own, recorded then; a stale handle cannot be
+    recognised afterwards -- this runtime dereferences it, tools/probe_stream_gone.hip) and may then destroy it."""
     import ctypes
     import torch
     hip = ctypes.CDLL("libamdhip64.so")
@@ -1376,7 +1378,8 @@ def test_device_pointer_call_asks_nothing_of_the_caller_s_stream_afterwards():
         s = ctypes.c_void_p()
         assert hip.hipStreamCreate(ctypes.byref(s)) == 0
         used, made = r.process_device(d_in.data_ptr(), frames, d_out.data_ptr(), cap, s.value)
-        if call % 2 == 0:                      # the caller's own synchronisation, then the stream is gone
+        r.release_stream()
+        if call % 2 == 0:                      # with or without the caller's own synchronisation
             assert hip.hipStreamSynchronize(s) == 0
         assert hip.hipStreamDestroy(s) == 0    # (destroying a busy stream is legal: its work still completes)
         want, wu = ref.process(x, cap)
@@ -1453,3 +1456,70 @@ def test_fast_mode_is_within_tolerance_of_itself_across_chunkings(ch, i, o, q):
     assert_close(a, want, "one call")
     assert_close(b, want, "six calls")
     assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 2 * TOL_LSB
+
+
+# every (num, den) of the fp64-accumulate slide kernel (kernels_slide.hip, kShapes64), as rates
+_SLIDE64_RATIOS = [(8000, 8000), (24000, 48000), (16000, 48000), (12000, 48000), (8000, 40000), (8000, 48000),
+                   (48000, 24000), (32000, 48000), (16000, 40000), (48000, 16000), (48000, 32000), (24000, 40000),
+                   (32000, 8000), (32000, 40000), (40000, 8000), (40000, 16000), (40000, 24000), (40000, 32000),
+                   (40000, 48000), (48000, 8000), (48000, 40000), (56000, 8000), (64000, 8000), (32000, 12000),
+                   (72000, 8000), (80000, 8000), (96000, 8000), (128000, 8000), (160000, 8000), (192000, 8000)]
+
+
+def test_fp64_accumulate_slide_kernel_on_every_shape():
+    """Round 4: FAST mode runs the reference's DOUBLE kernels (quality 9 and 10: resample.c:389-435 direct_double,
+    :501-558 interpolate_double) through v_fma_f64 kernels -- exact products, fp64 sums: wider than the reference's
+    fp64 sums of fp32-rounded products, where the fp32 FMA chain of rounds 1-3 (still there as MODE_FAST_F32) was
+    narrower.  Every (num, den) shape, mono / stereo / 3 channels, int16 and float calls mixed on one stream,
+    against the oracle: +-1 LSB, counters and history equal, and FEWER samples off by one than the fp32 chain."""
+    worst = 0.0
+    for n, (i, o) in enumerate(_SLIDE64_RATIOS):
+        for ch in (1, 2, 3):
+            q = 10 if (n + ch) % 2 else 9
+            ref = orc.Oracle(ch, i, o, q)
+            r = speexhip.Resampler(ch, i, o, q)
+            info = r.info()
+            assert info["fast_path"] == 4 and info["accumulate_bits"] == 64, (ch, i, o, q, info)
+            for call, frames in enumerate([1, 30000, 777, 50001]):
+                x = orc.lcg_pcm(frames * ch, 17 * call + ch + n).reshape(frames, ch)
+                cap = max(1, frames * o // i // 2) if call == 2 else 1 << 20  # one capacity-bound call
+                if call == 1:
+                    got, used = r.process_float(x.astype(np.float32), cap)
+                    want, wu = ref.process_float(x.astype(np.float32), cap)
+                    assert used == wu and got.shape == want.shape
+                    # float entry point: the FIR value as is (resample.c:927-963), within an LSB-sized tolerance
+                    assert np.abs(got - want).max() <= 0.05, (ch, i, o, q, np.abs(got - want).max())
+                    continue
+                got, used = r.process(x, cap)
+                want, wu = ref.process(x, cap)
+                assert used == wu and r.position() == ref.position(), (ch, i, o, q, call)
+                assert_close(got, want, "slide64 %s call %d" % ((ch, i, o, q), call), rate=2e-3)
+                if got.size >= 20000:
+                    worst = max(worst, float((got != want).mean()))
+            for c in range(ch):
+                assert np.array_equal(r.history()[:, c], ref.history(c))
+            r.close()
+    print("slide64: worst share of samples off by one: %.2e" % worst)
+
+
+def test_fp64_accumulate_is_closer_to_the_reference_than_the_fp32_chain():
+    """BASELINE configs[2] (24k -> 48k mono q10, 2^20 frames) in the three modes: EXACT bit-identical, FAST (fp64
+    accumulate) and FAST_F32 (fp32 chain) within +-1 LSB -- and FAST with at most half the mismatches of FAST_F32."""
+    ch, i, o, q, frames = 1, 24000, 48000, 10, 1 << 20
+    x = orc.lcg_pcm(frames * ch, 77).reshape(frames, ch)
+    cap = 2 * frames + 64
+    want, wu = orc.Oracle(ch, i, o, q).process(x, cap)
+    rates = {}
+    for mode in (speexhip.MODE_EXACT, speexhip.MODE_FAST, speexhip.MODE_FAST_F32):
+        r = speexhip.Resampler(ch, i, o, q, mode=mode)
+        got, used = r.process(x, cap)
+        assert used == wu and got.shape == want.shape
+        assert r.info()["accumulate_bits"] == (32 if mode == speexhip.MODE_FAST_F32 else 64)
+        assert r.info()["fast_path"] == (3 if mode == speexhip.MODE_FAST_F32 else 4)
+        diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= (0 if mode == speexhip.MODE_EXACT else TOL_LSB)
+        rates[mode] = float((diff != 0).mean())
+        r.close()
+    print("configs[2] mismatch rates: fp64 accumulate %.2e, fp32 chain %.2e" % (rates[speexhip.MODE_FAST], rates[speexhip.MODE_FAST_F32]))
+    assert rates[speexhip.MODE_FAST] <= 1.5e-3
+    assert rates[speexhip.MODE_FAST] <= 0.5 * rates[speexhip.MODE_FAST_F32] + 1e-4
