@@ -230,6 +230,8 @@ DeviceTables::~DeviceTables() {
   pool::device_put(device, w16_rows);
   pool::device_put(device, slide_rows);
   pool::device_put(device, slide64_rows);
+  pool::device_put(device, period64_rows);
+  pool::device_put(device, fine64_rows);
 }
 
 namespace {
@@ -317,6 +319,26 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
   }
   // the reference's double kinds (quality 9, 10): fp64-accumulate twins of the fast kernels
   if (f.kind == kDirectDouble || f.kind == kInterpolateDouble) {
+    if (t->period.usable) {
+      t->period64 = plan_period(f, channels, kLdsBudget, false, true);
+      if (t->period64.usable) {
+        std::vector<double> rows;
+        build_period_rows64(f, t->period64, &rows);
+        rc = upload_bytes(reinterpret_cast<void **>(&t->period64_rows), rows.data(), rows.size() * sizeof(double));
+        if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+      }
+      if (t->period64.usable && t->period64.r == 10) {
+        static const bool no_fine64 = std::getenv("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
+        t->fine64 = plan_period_r(f, channels, kLdsBudget, 5, false, true);
+        if (no_fine64 || t->fine64.lane_periods != t->period64.lane_periods) t->fine64.usable = false;
+        if (t->fine64.usable) {
+          std::vector<double> rows;
+          build_period_rows64(f, t->fine64, &rows);
+          rc = upload_bytes(reinterpret_cast<void **>(&t->fine64_rows), rows.data(), rows.size() * sizeof(double));
+          if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+        }
+      }
+    }
     if (t->slide.usable) t->slide64 = plan_slide64(f, channels);
     if (t->slide64.usable) {
       std::vector<double> rows;
@@ -444,6 +466,8 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   d_period_w16_rows_ = tables->w16_rows;
   d_slide_rows_ = tables->slide_rows;
   d_slide64_rows_ = tables->slide64_rows;
+  d_period64_rows_ = tables->period64_rows;
+  d_period64_fine_rows_ = tables->fine64_rows;
   const std::vector<float> no_table;
   filter_ = f;
   filter_.table = no_table;  // the host copy of the sinc table lives only while the tables are built
@@ -457,6 +481,8 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   period_w16_ = tables->w16;
   slide_ = tables->slide;
   slide64_ = tables->slide64;
+  period64_ = tables->period64;
+  period64_fine_ = tables->fine64;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -716,6 +742,7 @@ void Batch::info(uint32_t s, SpeexHipInfo *o) const {
   const bool double_kind = filter_.kind == kDirectDouble || filter_.kind == kInterpolateDouble;
   // (what FAST would run: in EXACT mode too; FAST_F32 reports its own fp32-chain kernels)
   if (double_kind && mode_ != SPEEXHIP_MODE_FAST_F32 && !period_.usable && slide64_.usable) o->fast_path = 4;
+  if (double_kind && mode_ != SPEEXHIP_MODE_FAST_F32 && period64_.usable) o->fast_path = 5;
   o->accumulate_bits = mode_ == SPEEXHIP_MODE_EXACT || o->fast_path == 0 ? (double_kind ? 64 : 32)
                                                                           : (o->fast_path >= 4 ? 64 : 32);
   if (s < n_streams_) {
@@ -904,6 +931,11 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       geo.outs_per_block = 256;
       e = launch_exact(filter_, geo, d_table_, channels_, d_descs, packed ? &pack : nullptr, n_streams_, max_out,
                        float_io, stream, nullptr, true);
+    } else if (fast && acc64() && period64_.usable) {
+      // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
+      e = launch_period(filter_, period64_, reinterpret_cast<const float *>(d_period64_rows_), &period64_fine_,
+                        reinterpret_cast<const float *>(d_period64_fine_rows_), channels_, descs, d_descs,
+                        packed ? &pack : nullptr, n_streams_, float_io, stream);
     } else if (fast && acc64() && !period_.usable && slide64_.usable) {
       // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
       e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, d_descs, packed ? &pack : nullptr,

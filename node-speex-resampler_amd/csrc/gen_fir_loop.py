@@ -205,6 +205,158 @@ struct FirLoopAsm<%d, %d, %d, %s, %s> {
        ", ".join(outs), ", ".join(ins), ", ".join(clob))
 
 
+class Variant64(Variant):
+    """The loop with an fp64 accumulator (round 4): what FAST mode runs for the reference's double kernels (quality
+    9 and 10, deps/speex/resample.c:389-435, :501-558).  Same structure, same SGPR homes -- a bank is half as many
+    taps, each a double in an aligned SGPR pair --, the samples widened in place behind the wait (v_cvt_f64_f32),
+    one v_fma_f64 per tap and half of the lane's pair: every product exact, the sum fp64 throughout.  v_fma_f64
+    issues at the rate of v_pk_fma_f32 (tools/ubench_fma64.hip), so this is the fp32 loop's instruction stream with
+    half the multiply-adds per instruction.  No int16 window (its conversions would come on top)."""
+
+    def __init__(self, R, S, CT, CF, padded):
+        Variant.__init__(self, R, 2 * S, CT, CF, padded, False)   # register homes of the fp32 scheme with 2S steps
+        self.S = S                                                # steps per bank here
+        self.vbase = {10: 56, 5: 64}[R]   # (R = 10: the top of the 64 VGPRs of 8 waves per SIMD, v0-v55 left in one piece)
+        self.name = "A64_R%d_S%d_CT%d_CF%d_P%d" % (R, S, CT, CF, int(padded))
+
+    # step k (0 .. 2S-1) of a trip: four VGPRs, x as a double in [q, q+1], y in [q+2, q+3]; the raw floats arrive
+    # in q (x) and q+2 (y)
+    def quad(self, k):
+        return self.vbase + 4 * k
+
+    def vgprs(self):
+        return list(range(self.vbase, self.vbase + 8 * self.S))
+
+    def tap_pair(self, which, t):
+        """first SGPR of the t-th double of the bank"""
+        r = tap_reg(self.banks[which], 2 * t)
+        assert r % 2 == 0 and tap_reg(self.banks[which], 2 * t + 1) == r + 1
+        return r
+
+    def fma_bank(self, which, lo, hi):
+        out = []
+        for u in range(self.S):
+            k = u if which == "A" else self.S + u
+            q = self.quad(k)
+            for i in range(lo, hi):
+                r = self.tap_pair(which, u * self.R + i)
+                out.append("v_fma_f64 %%[a%dx], s[%d:%d], v[%d:%d], %%[a%dx]" % (i, r, r + 1, q, q + 1, i))
+                out.append("v_fma_f64 %%[a%dy], s[%d:%d], v[%d:%d], %%[a%dy]" % (i, r, r + 1, q + 2, q + 3, i))
+        return out
+
+    def tap_loads(self, which, byte_off):
+        out, t = [], 0
+        for f, m in self.banks[which]:
+            out.append("s_load_dword%s s[%d:%d], %%[rows], %%[off] offset:0x%x"
+                       % ("x%d" % m if m > 1 else "", f, f + m - 1, byte_off + 4 * t))
+            t += m
+        return out
+
+    def sample_reads(self, which, first_step):
+        out = []
+        for u in range(self.S):
+            k = u if which == "A" else self.S + u
+            o = (first_step + u) * self.CF * 4
+            q = self.quad(k)
+            if self.CT == 2:
+                # both channels of the frame: x lands in q, y in q+1 and moves to its own pair when widened
+                out.append("ds_read_b64 v[%d:%d], %%[addr] offset:%d" % (q, q + 1, o))
+            else:
+                out += ["ds_read_b32 v%d, %%[addr] offset:%d" % (q, o), "ds_read_b32 v%d, %%[addr2] offset:%d" % (q + 2, o)]
+        return out
+
+    def converts(self, which):
+        out = []
+        for u in range(self.S):
+            k = u if which == "A" else self.S + u
+            q = self.quad(k)
+            if self.CT == 2:
+                out += ["v_cvt_f64_f32_e32 v[%d:%d], v%d" % (q + 2, q + 3, q + 1), "v_cvt_f64_f32_e32 v[%d:%d], v%d" % (q, q + 1, q)]
+            else:
+                out += ["v_cvt_f64_f32_e32 v[%d:%d], v%d" % (q, q + 1, q), "v_cvt_f64_f32_e32 v[%d:%d], v%d" % (q + 2, q + 3, q + 2)]
+        return out
+
+    def loop(self, label, cnt, lo, hi):
+        S, R = self.S, self.R
+        bank_bytes = 8 * S * R
+        adv = 2 * S * self.CF * 4
+        body = ["s_sub_u32 %%[%s], %%[%s], 1" % (cnt, cnt), "s_cbranch_scc1 %d1f" % label, "%d0:" % label]
+        body += ["s_waitcnt lgkmcnt(0)"] + self.converts("A") + self.tap_loads("B", bank_bytes) + self.sample_reads("B", S)
+        body += self.fma_bank("A", lo, hi)
+        body += ["s_waitcnt lgkmcnt(0)"] + self.converts("B")
+        if self.padded:
+            body += ["s_sub_u32 %[wrap], %[wrap], 1", "s_cmp_eq_u32 %[wrap], 0",
+                     "s_cselect_b32 %[tmp], %[advpad], " + str(adv), "s_cselect_b32 %[wrap], %[wrapstep], %[wrap]",
+                     "v_add_u32 %[addr], %[tmp], %[addr]"]
+            if self.CT == 1:
+                body += ["v_add_u32 %[addr2], %[tmp], %[addr2]"]
+        else:
+            body += ["v_add_u32 %%[addr], %d, %%[addr]" % adv]
+            if self.CT == 1:
+                body += ["v_add_u32 %%[addr2], %d, %%[addr2]" % adv]
+        body += self.tap_loads("A", 2 * bank_bytes) + self.sample_reads("A", 0)
+        body += self.fma_bank("B", lo, hi)
+        body += ["s_add_u32 %%[off], %%[off], 0x%x" % (2 * bank_bytes), "s_sub_u32 %%[%s], %%[%s], 1" % (cnt, cnt),
+                 "s_cbranch_scc0 %d0b" % label, "%d1:" % label]
+        return body
+
+    def function(self):
+        R = self.R
+        asm = "\n".join('      "%s\\n"' % l for l in self.lines())
+        outs = []
+        for i in range(R):
+            outs += ['[a%dx] "+v"(acc[%d][0])' % (i, i), '[a%dy] "+v"(acc[%d][1])' % (i, i)]
+        outs.append('[addr] "+v"(addr)')
+        if self.CT == 1:
+            outs.append('[addr2] "+v"(addr2)')
+        outs += ['[off] "+s"(off)', '[main] "+s"(main)']
+        if R == 10:
+            outs += ['[head] "+s"(head)', '[tail] "+s"(tail)']
+        ins = ['[rows] "s"(rows_g)']
+        if self.padded:
+            outs += ['[wrap] "+s"(to_wrap)', '[tmp] "=&s"(tmp)']
+            ins += ['[advpad] "s"(adv_pad)', '[wrapstep] "s"(wrap_step)']
+        clob = ['"s%d"' % r for r in bank_regs(self.banks["A"]) + bank_regs(self.banks["B"])] + ['"v%d"' % r for r in self.vgprs()]
+        return '''template <>
+struct FirLoopAsm64<%d, %d, %d, %s> {
+  static constexpr bool available = true;
+  static constexpr int steps_per_bank = %d;
+  // as FirLoopAsm::run; acc[i][0 / 1]: the two halves of row i (channel pair, or the lane's two periods) in fp64;
+  // rows_g: the group's tap rows as doubles
+  static __device__ __forceinline__ void run(double (&acc)[%d][2], const double *rows_g, uint32_t addr, uint32_t addr2,
+                                             uint32_t head, uint32_t main, uint32_t tail, uint32_t to_wrap,
+                                             uint32_t wrap_step, uint32_t adv_pad) {
+    uint32_t off = 0, tmp;
+    (void)tmp; (void)addr2; (void)head; (void)tail; (void)to_wrap; (void)wrap_step; (void)adv_pad;
+    asm volatile(
+%s
+      : %s
+      : %s
+      : %s, "scc", "memory");
+  }
+};
+''' % (R, self.CT, self.CF, "true" if self.padded else "false", self.S, R, asm,
+       ", ".join(outs), ", ".join(ins), ", ".join(clob))
+
+    def lines(self):
+        # the prologue leaves bank A in flight, like the fp32 loop; its conversions run behind the first wait
+        pro = self.tap_loads("A", 0) + self.sample_reads("A", 0)
+        if self.R == 10:
+            body = self.loop(1, "head", 0, 5) + self.loop(2, "main", 0, 10) + self.loop(3, "tail", 5, 10)
+        else:
+            body = self.loop(2, "main", 0, self.R)
+        return pro + body + ["s_waitcnt lgkmcnt(0)"]
+
+
+def variants64():
+    out = []
+    for CT, CF in ((2, 2), (2, 4), (2, 6), (2, 8), (1, 1)):
+        for padded in (False, True):
+            out.append(Variant64(10, 1, CT, CF, padded))
+        out.append(Variant64(5, R5_STEPS // 2, CT, CF, False))
+    return out
+
+
 def variants():
     out = []
     for w16 in (False, True):
@@ -230,11 +382,21 @@ struct FirLoopAsm {
 '''
 
 
+HEAD64 = '''
+// ---- fp64 accumulator (round 4; gen_fir_loop.py, Variant64) ----
+template <int R, int CT, int CF, bool PADDED>
+struct FirLoopAsm64 {
+  static constexpr bool available = false;
+};
+
+'''
+
+
 def main():
-    src = HEAD + "\n".join(v.function() for v in variants())
+    src = HEAD + "\n".join(v.function() for v in variants()) + HEAD64 + "\n".join(v.function() for v in variants64())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fir_loop_asm.inc")
     open(path, "w").write(src)
-    print("wrote %s: %d variants, %d lines" % (path, len(variants()), src.count("\n")))
+    print("wrote %s: %d + %d variants, %d lines" % (path, len(variants()), len(variants64()), src.count("\n")))
 
 
 if __name__ == "__main__":

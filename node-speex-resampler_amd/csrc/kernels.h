@@ -68,14 +68,19 @@ struct PeriodPlan {         // per filter, fixed at init
   uint32_t pad = 0;          // LDS bank padding (elements after every period), 0 = none needed
   bool w16 = false;          // the LDS window holds int16 samples (2-byte elements) instead of floats: int16
                              // calls only; twice the periods per tile where the float window limits them
+  bool a64 = false;          // fp64 accumulator (round 4): the tap rows are doubles, a loop trip is half as many steps,
+                             // rows_floats counts doubles
   size_t rows_floats = 0, window_bytes = 0;
 };
-PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16 = false);
-PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16 = false);
+PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16 = false, bool a64 = false);
+PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16 = false,
+                         bool a64 = false);
 // The int16-window plan of a filter whose float plan is `t`, .usable only where it pays: at least 5/4 of the
 // periods per tile (the loop converts every sample it reads: ~20 % more vector instructions per tile).
 PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_budget, const PeriodPlan &t);
 void build_period_rows(const FilterSpec &f, const PeriodPlan &t, std::vector<float> *rows);
+// ... of an a64 plan: t.rows_floats doubles, then the per-group tables (uint32, bit-copied into the tail)
+void build_period_rows64(const FilterSpec &f, const PeriodPlan &t, std::vector<double> *rows);
 // `fine`: the same filter planned with r = 5 (or null); single-generation launches take it
 hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, const PeriodPlan *fine,
                          const float *d_rows_fine, uint32_t channels, const StreamDesc *h_descs,

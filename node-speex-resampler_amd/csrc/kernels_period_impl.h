@@ -1,0 +1,847 @@
+#pragma once
+// kernels_period_impl.h -- the device side of the period kernel (and launch_rc, the one place that names a
+// kernel instance): included by kernels_period.hip (host side + the fp32 instances) and kernels_period64.hip (the
+// fp64-accumulate instances, round 4), so that the two sets of instances compile side by side.
+//
+// kernels_period.hip -- the primary fast gfx950 FIR kernel ("period-lane" mapping).
+//
+// With K = k_shift + k = m*den + r (stream_plan.h) every output of every stream is
+//     Out[r, m, c] = sum_s Tp[r][s] * V[base + m*num + delta_{g*R} + s][c]
+// where Tp[r] are the effective taps of phase (r*num) mod den (the reference's four
+// interpolation accumulators collapsed, deps/speex/resample.c:438-558; the direct kernels
+// :331-435 as they are), pre-shifted so that the R phases of group g = r / R read the same
+// input sample at the same step s.  fp32 FMA on the vector ALUs, no MFMA; +-1 LSB.
+//
+// Mapping (what makes it fast on CDNA4):
+//   * lane  = one output PERIOD m (x one channel pair): the 64 lanes of a wave need the SAME
+//     tap at every step, so taps never touch LDS or VGPRs -- they are wave-uniform, fetched by
+//     scalar loads (s_load_dwordx16, L2 / scalar cache) and fed to v_pk_fma_f32 as SGPR
+//     operands; one packed FMA updates both channels of a frame.
+//   * wave  = one group of R consecutive phases: R accumulator pairs per lane, R FMAs per
+//     LDS sample read; ~30 VGPRs -> 8 waves per SIMD hide the scalar-load and LDS latencies.
+//   * LDS holds only the input window (float, channel-interleaved): lanes read it at a stride
+//     of num*channels floats (conflict-free ds_read_b64 for the common ratios), and two
+//     workgroups fit per CU, so one workgroup's staging / stores overlap the other's FMAs.
+//   * outputs go straight from registers to HBM (4 bytes per lane per row); the partial lines
+//     meet in L2.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "device_helpers.h"
+#include "device_types.h"
+#include "filter_design.h"
+#include "kernels.h"
+
+namespace speexhip {
+// Diagnostics build only (-DSPEEXHIP_STAMPS, tools/stamps.py): every workgroup records when it
+// reached a few points, on the 100 MHz s_memrealtime clock all CUs share.  Not in the product.
+#ifdef SPEEXHIP_STAMPS
+static __device__ unsigned long long g_stamps[8192 * 16];
+#define STAMP(k)                                                                                         \
+  do {                                                                                                   \
+    const uint32_t lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                \
+    if ((threadIdx.x & 63u) == 0 && lin_ < 8192)                                                         \
+      atomicMax(&g_stamps[lin_ * 16 + (k)], (unsigned long long)__builtin_amdgcn_s_memrealtime());        \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// taps per bank of the FIR loop's two-bank pipeline, by phases per wave (host + device)
+__host__ __device__ constexpr int bank_taps(int r) { return r == 10 ? 20 : 30; }
+// dword-aligned wide global stores (global memory needs only dword alignment for x2/x4)
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef __attribute__((address_space(1))) u32x4_a4 g_u32x4_a4;
+typedef __attribute__((address_space(1))) u32x2_a4 g_u32x2_a4;
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// acc += tap * x on both halves, the tap being element HI of a wave-uniform pair held in SGPRs.
+// Written as one instruction so that the odd element is selected in place with op_sel: left to
+// itself hipcc copies odd taps into even SGPRs first (one s_mov each), and the scalar ALU --
+// ONE per CU, shared by all 32 resident waves -- becomes the bottleneck of the loop.
+__device__ __forceinline__ void fma_tap(f32x2 &acc, const f32x2 &tap_pair, const f32x2 &x, bool hi) {
+  if (hi)  // constant after unrolling: the branch folds away
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(tap_pair), "v"(x));
+}
+
+#include "fir_loop_asm.inc"
+
+// Wave priority of the FIR loop (and of whatever follows it): 0.  Bit 2 of p.prio (diagnostics, SPEEXHIP_PRIO=7)
+// gives the workgroup in the CU's second slot (HW_ID.TG_ID) priority 1 instead: an experiment of round 3.
+// Two workgroups that share a CU are dispatched together and do the same work; in a kernel of nothing but
+// equal phases they stay in lockstep generation after generation (tools/probe_slots.hip: the pairs start
+// within 0.2 us of each other every time), and a model of that -- both staging, both computing, both
+// storing -- predicted exactly the launch time measured here.  The stamps say otherwise for THIS kernel
+// (tools/stamps.py, profiles/r03_stamps_cfg2_s32.txt): the pairs run 11.5 us apart (median) of a 26 us
+// cycle, a CU has two workgroups in their FIR loops 60 % of the time, one 37.5 %, none 2.2 %; what the lone
+// one loses is issue efficiency (4 waves per SIMD: 5.1 cycles per v_pk_fma_f32 against 4.5 at 8), not time
+// behind a partner.  Unequal priorities made every launch SLOWER: cfg2 32 streams 200 -> 215 us, mono
+// 128 -> 145, 8 channels 569 -> 602 (the low-priority workgroup starves and its slot turns over late:
+// median turnover 1.4 -> 2.2 us, p90 2.2 -> 11.8).  Not the default.
+__device__ __forceinline__ void set_fir_priority(const PeriodParams &p) {
+  if (p.prio & 4u) {
+    const uint32_t tg_id = (__builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11)));  // HW_REG_HW_ID bits [19:16]
+    if (tg_id & 1u) {
+      __builtin_amdgcn_s_setprio(1);
+      return;
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// What a lane needs to know about its place in a tile.
+struct LaneCtx {
+  uint32_t C;       // channels per frame
+  uint32_t cg;      // channel group of this lane
+  bool live;        // the lane's period exists in this tile
+  bool live_b;      // single-channel lanes: the lane's SECOND period (half a tile further) exists
+  uint32_t xlane;   // float index of the lane's first sample of a group with delta_g = 0
+  uint64_t K_lane;  // canonical output index of the lane's period, phase 0
+};
+
+template <int CT, bool ONE_GROUP, bool PADDED, int CGF = 0>
+__device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshift, uint32_t m_lo,
+                                            uint32_t m_cnt, uint32_t lane) {
+  // ONE_GROUP: the frame is exactly one channel group (mono, stereo): the sample stride is a
+  // compile-time constant and the LDS reads of an iteration share one address register.
+  // CGF != 0: a frame of CGF channel groups (4, 6, 8 channels as 2, 3, 4 pairs) known at compile time:
+  // the same for the common multi-channel layouts -- the FIR loop of 8 channels spent 4 vector adds per
+  // 40 FMAs on LDS addresses with the stride in a register.
+  constexpr uint32_t kGroups = ONE_GROUP ? 1u : static_cast<uint32_t>(CGF);
+  const uint32_t cgroups = kGroups != 0 ? kGroups : p.cgroups;
+  LaneCtx c;
+  c.C = kGroups != 0 ? kGroups * CT : p.channels;
+  c.cg = ONE_GROUP ? 0 : lane % cgroups;
+  const uint32_t pl = ONE_GROUP ? lane : lane / cgroups;  // period of this lane inside the tile
+  // CT == 1 (odd channel counts): a packed FMA has no second channel to work on, so the lane takes
+  // a second PERIOD instead, half a tile further (p.half_periods): .x = period pl, .y = pl + half.
+  const uint32_t lane_max = CT == 1 ? p.half_periods : p.lane_periods;
+  c.live = pl < lane_max && pl < m_cnt;
+  c.live_b = CT == 1 && pl < lane_max && pl + p.half_periods < m_cnt;
+  // PADDED: the LDS image carries p.pad floats after every period (num frames) so that the
+  // lanes of a wave -- num*C floats apart, a multiple of the bank count for e.g. 8 channels at
+  // num = 160 -- hit distinct banks; the per-step offset is then wave-uniform scalar arithmetic.
+  c.xlane = xshift + min(pl, lane_max - 1) * (p.num * c.C + (PADDED ? p.pad : 0u)) + c.cg * CT;
+  c.K_lane = static_cast<uint64_t>(m_lo + pl) * p.den;
+  return c;
+}
+
+// acc[i] += group g's taps times the lane's samples, over the iterations the host tabulated for g.
+// CF: floats per frame when that is a compile-time constant (mono, stereo, 4 / 6 / 8 channels), else 0.
+// W16: the LDS window holds int16 samples (device_helpers.h); ISA loop only.
+template <int R, int CT, bool PADDED, int CF = 0, bool W16 = false>
+__device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
+                                          const LaneCtx &c, uint32_t g, bool skip_all, f32x2 (&acc)[R]) {
+  const uint32_t C = c.C;
+  const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
+  // (delta_g < num: no padding boundary before the group's first sample)
+  const float *xp = xs + c.xlane + delta_g * C;
+  if constexpr (W16) {
+    using Isa = FirLoopAsm<R, CT, CF, PADDED, true>;
+    static_assert(CF != 0 && Isa::available, "an int16 window needs the ISA loop of its layout");
+    constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
+    const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];
+    const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u;
+    const float *rows_g = rows + static_cast<size_t>(g) * p.l4 * (2 * bank_taps(R));
+    const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) + (c.xlane + delta_g * C) * 2u;
+    auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+    const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
+    const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
+                                                          static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
+    Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 2u : 0u, sgpr(head), sgpr((trips >> 8) - head - tail),
+             sgpr(tail), sgpr(PADDED ? p.delta[p.groups + g] : 0u), sgpr(p.wrap_step),
+             sgpr((kStepsPerTrip * CF + p.pad) * 2u));
+    return;
+  }
+#ifndef SPEEXHIP_CXX_FIR_LOOP
+  // The loop in ISA (csrc/gen_fir_loop.py) for the layouts it is generated for; the C++ loop below is
+  // its reference -- same taps, same samples, same order per accumulator -- and runs the other layouts
+  // (odd channel counts >= 3, more than 8 channels).  -DSPEEXHIP_CXX_FIR_LOOP builds the A/B library.
+  using Isa = FirLoopAsm<R, CT, CF, PADDED, false>;
+  if constexpr (CF != 0 && Isa::available) {
+    constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
+    static_assert(kStepsPerTrip * R == 2 * bank_taps(R), "the ISA loop and the tap rows disagree on the trip");
+    const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+    const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u;
+    const float *rows_g = rows + static_cast<size_t>(g) * p.l4 * (2 * bank_taps(R));
+    const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xp));
+    // (wave-uniform values all of them, but hipcc keeps some of them in VGPRs -- the group index is a loop
+    //  counter it moved to the vector side -- and will not copy them back by itself)
+    auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+    const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
+    const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
+                                                          static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
+    Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 4u : 0u, sgpr(head), sgpr((trips >> 8) - head - tail),
+             sgpr(tail), sgpr(PADDED ? p.delta[p.groups + g] : 0u), sgpr(p.wrap_step),
+             sgpr((kStepsPerTrip * CF + p.pad) * 4u));
+    return;
+  }
+#endif
+  // padded layout: the host shifted this group's start by <= 3 frames so that the one padding
+  // boundaries its window crosses fall between iterations (the first before iteration wrap_it)
+  // (counted DOWN to the next boundary, like the loop itself: with 80 SGPRs there is no register to
+  //  spare for loop bounds, and a bound reloaded from the kernel arguments drags an lgkmcnt(0) wait
+  //  -- i.e. the whole tap prefetch -- into every iteration)
+  uint32_t to_wrap = PADDED ? p.delta[p.groups + g] : 0u;
+  // Taps are wave-uniform: they travel HBM/L2 -> scalar cache -> SGPRs (s_load: the row pointer
+  // is a __restrict__ kernel argument, so the loads are provably invariant) and feed
+  // v_pk_fma_f32 directly.
+  // (s_setprio around the loop -- FIR waves ahead of staging / storing ones -- measured 6 % slower.)
+  // Bank A = steps 0-1 of an iteration, bank B = steps 2-3: each bank is its 2R taps (R SGPR
+  // pairs) plus its two sample reads.  Order per iteration, pinned with sched_barrier:
+  //   wait A | issue loads B | 2R FMAs A | wait B | issue loads A(next) | 2R FMAs B
+  // A wait is lgkmcnt(0) (scalar loads return out of order and share the counter with LDS),
+  // so a bank's loads must be issued right AFTER the other bank's wait; `touch_bank` is an
+  // empty asm that reads the bank and thereby makes hipcc put the wait exactly there.
+  // A bank is 20 taps = 10 SGPR pairs for R = 10 (2 steps).  The R = 5 kernel only runs launches of
+  // one generation -- one workgroup per CU, 4 waves per SIMD, so the 80-SGPR cap that buys the second
+  // resident workgroup is not needed there -- and takes banks of 30 taps (6 steps): 30 FMAs between
+  // two waits instead of 20 give the scalar loads half as much time again to land.
+  constexpr int BANK = bank_taps(R), NP = BANK / 2;  // taps / SGPR pairs per bank
+  constexpr int STEPS = BANK / R;                     // steps per bank; an iteration is two banks
+  static_assert(R == 10 || R == 5, "phases per wave");
+  const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (2 * BANK);
+  f32x2 ta[NP], tb[NP], xa[STEPS], xb[STEPS];
+  auto load_bank = [&](f32x2 (&t)[NP], f32x2 (&x)[STEPS], const float *tp, const float *sp) {
+#pragma unroll
+    for (int j = 0; j < NP; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
+#pragma unroll
+    for (int u = 0; u < STEPS; u++) {
+      if (CT == 2) {
+        x[u] = *reinterpret_cast<const f32x2 *>(sp + u * C);
+      } else {
+        // (mono: two steps of each period arrive as (a0, a1), (b0, b1) and hipcc re-pairs them with ~7 v_mov
+        //  per 4 steps; one v_pk_mov_b32 per pair instead -- 4 per 4 steps -- measured slower, 145.5 vs
+        //  142.1 us for 32 mono streams of 44.1k -> 48k, 170 vs 159 for 48k -> 44.1k)
+        x[u].x = sp[u * C];
+        x[u].y = sp[u * C + p.half_offset];  // the same step of the lane's second period
+      }
+    }
+  };
+  auto touch_bank = [&](const f32x2 (&t)[NP], const f32x2 (&x)[STEPS]) {
+    if constexpr (NP == 10) {
+      asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
+                   "s"(t[8]), "s"(t[9]), "v"(x[0]), "v"(x[1]));
+    } else {
+      static_assert(NP == 15 && STEPS == 6, "touch_bank lists 10 pairs + 2 samples or 15 pairs + 6 samples");
+      asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]),
+                   "s"(t[8]), "s"(t[9]), "s"(t[10]), "s"(t[11]), "s"(t[12]), "s"(t[13]), "s"(t[14]), "v"(x[0]),
+                   "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]));
+    }
+  };
+  // phases [LO, HI) of the group only: the head and tail iterations of a group, where the host
+  // knows half of the rows to be all zero (below)
+  auto fma_bank = [&](const f32x2 (&t)[NP], const f32x2 (&x)[STEPS], auto lo_c, auto hi_c) {
+    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#pragma unroll
+    for (int u = 0; u < STEPS; u++)
+#pragma unroll
+      for (int i = LO; i < HI; i++) fma_tap(acc[i], t[(u * R + i) >> 1], x[u], ((u * R + i) & 1) != 0);
+  };
+  load_bank(ta, xa, trow, xp);
+  // (Per trip hipcc spends two vector instructions beside the 40 FMAs: the window address and the trip
+  //  count, which it keeps in a VGPR -- v_add_co, branch on vcc -- because no SGPR is left under the cap.
+  //  Forcing the count into an SGPR, or running two iterations per trip (one address step, scalar count:
+  //  1 in 81), pushes SGPR spills past the 64 VGPRs into scratch in every instantiation: 32 streams
+  //  208 -> 219 us, 8 channels 607 -> 667, float 273 -> 337.  Re-reading the parameters and the descriptor
+  //  from memory after the loop, so that they need not live across it, takes the headline instance from
+  //  18 to 3 spilled SGPRs -- and the scalar count still spills: it is the loop's own 40 taps + pointers +
+  //  temporaries that fill the budget.)
+  auto run = [&](uint32_t count, auto lo_c, auto hi_c) {
+    for (uint32_t left = count; left != 0; left--) {
+      touch_bank(ta, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      load_bank(tb, xb, trow + BANK, xp + STEPS * C);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_bank(ta, xa, lo_c, hi_c);
+      __builtin_amdgcn_sched_barrier(0);
+      touch_bank(tb, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      trow += 2 * BANK;
+      xp += 2 * STEPS * C;
+      if (PADDED && --to_wrap == 0) {  // wave-uniform: the window pointer steps over the bank padding
+        xp += p.pad;
+        to_wrap = p.wrap_step;         // the next period boundary, num/4 iterations on (or never)
+      }
+      // next iteration's bank A: the rows carry one iteration of zero padding past the last
+      // group and the window one step group of slack, so the final prefetch stays in bounds
+      load_bank(ta, xa, trow, xp);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_bank(tb, xb, lo_c, hi_c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // The R rows of a group start up to R-1 steps apart (each phase's window begins ~num/den input
+  // frames after the previous one's), so the loop covers taps + that spread steps and every row is
+  // zero outside its own `taps` of them.  Whole iterations in which one HALF of the rows is zero are
+  // run on the other half only: `head` leading iterations where rows R/2.. have not begun, `tail`
+  // trailing ones where rows ..R/2-1 have ended (44.1k->48k q7: 1400 -> 1320 or 1340 FMAs per group).
+  // The counts come from the host per group (build_period_rows); skipped products are exact zeros.
+  if constexpr (R == 10) {
+    const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+    const uint32_t head = trips & 15u, tail = (trips >> 4) & 15u;
+    // (the accumulators are made opaque between the loops: left alone the register allocator ties
+    //  all of them into one 32-register tuple in some instantiations and spills it around each loop)
+    auto pin = [&]() {
+      asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                   "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]));
+    };
+    run(head, std::integral_constant<int, 0>(), std::integral_constant<int, R / 2>());
+    pin();
+    run((trips >> 8) - head - tail, std::integral_constant<int, 0>(), std::integral_constant<int, R>());
+    pin();
+    run(tail, std::integral_constant<int, R / 2>(), std::integral_constant<int, R>());
+  } else {
+    run(skip_all ? 0u : p.delta[2 * p.groups + g] >> 8, std::integral_constant<int, 0>(), std::integral_constant<int, R>());
+  }
+  touch_bank(ta, xa);  // retire the last prefetch
+}
+
+// The same with an fp64 accumulator (round 4; FirLoopAsm64, csrc/gen_fir_loop.py): the reference's double kernels,
+// deps/speex/resample.c:389-435 and :501-558.  rows: the group's taps as doubles [trip][step][R]; a trip is
+// 2 * steps_per_bank steps (2 for R = 10, 6 for R = 5), the host's tables count in those (build_period_rows64).
+template <int R, int CT, bool PADDED, int CF>
+__device__ __forceinline__ void fir_group64(const PeriodParams &p, const double *__restrict__ rows, const float *xs,
+                                            const LaneCtx &c, uint32_t g, bool skip_all, double (&acc)[R][2]) {
+  using Isa = FirLoopAsm64<R, CT, CF, PADDED>;
+  static_assert(CF != 0 && Isa::available, "the fp64 accumulator runs the ISA loop of its layout");
+  constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
+  const uint32_t delta_g = p.delta[g];
+  const float *xp = xs + c.xlane + delta_g * c.C;
+  const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+  const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u;
+  const double *rows_g = rows + static_cast<size_t>(g) * p.l4 * (kStepsPerTrip * R);
+  const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xp));
+  auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+  const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
+  const double *rows_s = reinterpret_cast<const double *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
+                                                          static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
+  // (padded windows: the host's boundary tables count 4-step iterations; a trip here is kStepsPerTrip steps)
+  constexpr uint32_t kPerIt = 4 / kStepsPerTrip;
+  Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 4u : 0u, sgpr(head), sgpr((trips >> 8) - head - tail), sgpr(tail),
+           sgpr(PADDED ? p.delta[p.groups + g] * kPerIt : 0u), sgpr(p.wrap_step * kPerIt), sgpr((kStepsPerTrip * CF + p.pad) * 4u));
+}
+
+// Round / interleave / store the R phases of group g for this lane's period: R consecutive
+// frames per lane, 4 bytes each per channel pair.  With two workgroups per CU the stores
+// overlap the other workgroup's FMAs (an LDS transpose for fully coalesced stores measured
+// slower).
+template <int R, int CT, bool ONE_GROUP, typename T>
+__device__ __forceinline__ void store_group(const PeriodParams &p, const StreamDesc &d, const LaneCtx &c,
+                                            uint32_t g, const f32x2 (&acc)[R]) {
+  const uint32_t C = c.C, cg = c.cg;
+  if constexpr (CT == 1) {
+    // single-channel lanes: .x belongs to the lane's period, .y to its second period half a tile on
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (half == 0 ? !c.live : !c.live_b) continue;
+      const int64_t k0 = static_cast<int64_t>(c.K_lane) + static_cast<int64_t>(half * p.half_periods) * p.den +
+                         static_cast<int64_t>(g) * R - d.k_shift;
+      const int64_t lo64 = k0 < 0 ? -k0 : 0;
+      const int64_t hi64 = min(static_cast<int64_t>(R), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * R,
+                                                           static_cast<int64_t>(d.n_out) - k0));
+      G<T> *o = out_ptr<T>(d) + k0 * static_cast<int64_t>(C) + cg;
+      if constexpr (ONE_GROUP && sizeof(T) == 2) {
+        // mono int16: the lane's R samples leave as whole dwords -- 16 + 4 bytes (R = 10) or 8 (R = 5) -- around at
+        // most two odd samples: the first when the run starts on the upper half of a dword (k_shift odd, or every
+        // second period of an odd den), the last when what remains is odd.  (Until round 3 a run that started on
+        // an upper half went out as R stores of 2 bytes, and so did every run of R = 5: a store instruction costs
+        // one line request per lane whatever its width.)
+        if (lo64 == 0 && hi64 == R && (reinterpret_cast<uintptr_t>(d.out) & 1u) == 0) {
+          float v[R];
+#pragma unroll
+          for (int i = 0; i < R; i++) v[i] = half == 0 ? acc[i].x : acc[i].y;
+          auto dwords = [&](g_i16 *at, auto first_c, auto count_c) {  // samples [first, first + 2*count) as dwords
+            constexpr int F = decltype(first_c)::value, N = decltype(count_c)::value;
+            uint32_t w[N > 0 ? N : 1];
+#pragma unroll
+            for (int j = 0; j < N; j++) w[j] = round_pack_pcm(v[F + 2 * j], v[F + 2 * j + 1]);
+            g_u32 *od = (g_u32 *)at;
+#pragma unroll
+            for (int j = 0; j + 4 <= N; j += 4) *(g_u32x4_a4 *)(od + j) = u32x4_a4{w[j], w[j + 1], w[j + 2], w[j + 3]};
+            if constexpr (N % 4 >= 2) *(g_u32x2_a4 *)(od + N / 4 * 4) = u32x2_a4{w[N / 4 * 4], w[N / 4 * 4 + 1]};
+            if constexpr (N % 2 != 0) od[N - 1] = w[N - 1];
+          };
+          auto single = [&](int i) { o[i] = static_cast<int16_t>(round_pack_pcm(v[i], 0.f) & 0xffffu); };
+          if ((reinterpret_cast<uintptr_t>(o) & 2u) == 0) {
+            dwords(o, std::integral_constant<int, 0>(), std::integral_constant<int, R / 2>());
+            if constexpr (R % 2 != 0) single(R - 1);
+          } else {
+            single(0);
+            dwords(o + 1, std::integral_constant<int, 1>(), std::integral_constant<int, (R - 1) / 2>());
+            if constexpr (R % 2 == 0) single(R - 1);
+          }
+          continue;
+        }
+      }
+      if constexpr (ONE_GROUP && sizeof(T) == 4) {
+        // mono float: the lane's R samples are R consecutive floats -- 16 + 16 + 8 bytes instead of R stores of 4
+        // (a store instruction costs one line request per lane whatever its width: 20 of them per lane made a
+        //  tile's store phase 4.5 us and 32 float mono streams of 44.1k -> 48k 228 us against 123 for int16)
+        if (lo64 == 0 && hi64 == R) {
+          float v[R];
+#pragma unroll
+          for (int i = 0; i < R; i++) v[i] = half == 0 ? acc[i].x : acc[i].y;
+          // (opaque copies, as for the stereo float stores below)
+#pragma unroll
+          for (int i = 0; i < R; i++) asm volatile("" : "+v"(v[i]));
+          G<float> *of = (G<float> *)o;
+#pragma unroll
+          for (int i = 0; i + 4 <= R; i += 4) *(G<f32x4_a4> *)(of + i) = f32x4_a4{v[i], v[i + 1], v[i + 2], v[i + 3]};
+          if constexpr (R % 4 >= 2) *(G<f32x2_a4> *)(of + R / 4 * 4) = f32x2_a4{v[R / 4 * 4], v[R / 4 * 4 + 1]};
+          if constexpr (R % 2 != 0) of[R - 1] = v[R - 1];
+          continue;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < R; i++, o += C) {
+        if (i < lo64 || i >= hi64) continue;
+        const float v = half == 0 ? acc[i].x : acc[i].y;
+        if constexpr (sizeof(T) == 4)
+          o[0] = v;
+        else
+          o[0] = static_cast<int16_t>(round_pack_pcm(v, 0.f) & 0xffffu);
+      }
+    }
+    return;
+  }
+  // rows i in [i_lo, i_hi) of this group are real phases that fall inside this call
+  const int64_t k0 = static_cast<int64_t>(c.K_lane) + static_cast<int64_t>(g) * R - d.k_shift;
+  const int64_t lo64 = k0 < 0 ? -k0 : 0;
+  const int64_t hi64 = min(static_cast<int64_t>(R), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * R,
+                                                       static_cast<int64_t>(d.n_out) - k0));
+  const int i_lo = static_cast<int>(min(lo64, static_cast<int64_t>(R)));
+  const int i_hi = static_cast<int>(max(hi64, static_cast<int64_t>(0)));
+  if constexpr (sizeof(T) == 4) {
+    // float I/O (resample.c:927-963): the FIR value as is
+    G<float> *o = out_ptr<float>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
+    if (ONE_GROUP && CT == 2 && i_lo == 0 && i_hi == R) {
+#pragma unroll
+      for (int i = 0; i + 1 < R; i += 2) {
+        // (through opaque copies: a 16-byte store straight from two accumulators makes the register
+        //  allocator tie all R of them into one tuple, which it then spills around the FIR loops)
+        float a0 = acc[i].x, a1 = acc[i].y, a2 = acc[i + 1].x, a3 = acc[i + 1].y;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        *(G<f32x4_a4> *)(o + 2 * i) = f32x4_a4{a0, a1, a2, a3};
+      }
+      if constexpr (R % 2 != 0) *(G<f32x2_a4> *)(o + 2 * (R - 1)) = f32x2_a4{acc[R - 1].x, acc[R - 1].y};
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++, o += C) {
+      if (i < i_lo || i >= i_hi) continue;
+      if constexpr (CT == 2)
+        *(G<f32x2_a4> *)o = f32x2_a4{acc[i].x, acc[i].y};  // one 8-byte store (the buffer is only known 4-byte aligned)
+      else
+        o[0] = acc[i].x;
+    }
+  } else {
+    g_i16 *o = out_ptr<int16_t>(d) + k0 * static_cast<int64_t>(C) + cg * CT;
+    const bool aligned = CT == 2 && ((reinterpret_cast<uintptr_t>(d.out) | (C * 2u)) & 3u) == 0;
+    if (ONE_GROUP && CT == 2 && aligned && i_lo == 0 && i_hi == R) {
+      // the lane's R frames are R consecutive dwords: 16 + 16 + 8 bytes instead of R narrow
+      // stores (each store instruction costs one line request per lane whatever its width)
+      uint32_t v[R];
+#pragma unroll
+      for (int i = 0; i < R; i++) v[i] = round_pack_pcm(acc[i].x, acc[i].y);
+      g_u32 *od = (g_u32 *)o;
+#pragma unroll
+      for (int i = 0; i + 4 <= R; i += 4) *(g_u32x4_a4 *)(od + i) = u32x4_a4{v[i], v[i + 1], v[i + 2], v[i + 3]};
+      if constexpr (R % 4 >= 2) *(g_u32x2_a4 *)(od + R / 4 * 4) = u32x2_a4{v[R / 4 * 4], v[R / 4 * 4 + 1]};
+      if constexpr (R % 2 != 0) od[R - 1] = v[R - 1];
+      return;
+    }
+    // (8 channels: a lane's 4-byte pieces, 16 bytes apart, could leave as whole 16-byte frames after a 4 x 4
+    //  transpose inside each quad of lanes -- rows cg, 4 + cg, 8 + cg per lane, 3 stores instead of 10.  With the
+    //  transpose left out (wrong data, right addresses) BASELINE configs[3] at 32 streams went 588 -> 569 us, and
+    //  the 48 vector instructions of three butterfly transposes cost about that much again: not built.)
+#pragma unroll
+    for (int i = 0; i < R; i++, o += C) {
+      if (i < i_lo || i >= i_hi) continue;
+      if (CT == 2) {
+        const uint32_t v = round_pack_pcm(acc[i].x, acc[i].y);
+        if (aligned) {
+          *(g_u32 *)o = v;
+        } else {
+          o[0] = static_cast<int16_t>(v & 0xffffu);
+          o[1] = static_cast<int16_t>(v >> 16);
+        }
+      } else {
+        o[0] = static_cast<int16_t>(round_pack_pcm(acc[i].x, 0.f) & 0xffffu);
+      }
+    }
+  }
+}
+
+// The kernel's parameters and the workgroup's descriptor as they lie in memory (the kernel-argument segment; the
+// descriptor ring for large batches), in the constant address space: what is read through these comes by scalar
+// loads.  The ISA loop names 40 tap SGPRs; with the parameters and the descriptor held in registers across it
+// hipcc spilled ~26 SGPRs into VGPR lanes around every group (v_writelane / v_readlane: ~60 vector instructions
+// per wave, as many as the conversions of the staging).  fir_tile therefore reads both AGAIN on either side of
+// the loop, through pointers made opaque so that the compiler cannot keep the first copies alive instead:
+// a handful of scalar loads that hit the scalar cache.
+typedef const __attribute__((address_space(4))) PeriodParams *KParams;
+typedef const __attribute__((address_space(4))) StreamDesc *KDesc;
+template <typename P>
+__device__ __forceinline__ P opaque(P ptr) {
+  asm volatile("" : "+s"(ptr));
+  return ptr;
+}
+template <typename X>
+__device__ __forceinline__ X load_k(const __attribute__((address_space(4))) X *ptr) {
+  // (dword by dword: a struct cannot be copy-constructed from another address space; unused fields' loads vanish)
+  static_assert(sizeof(X) % 4 == 0, "dword-sized structs");
+  union {
+    X v;
+    uint32_t w[sizeof(X) / 4];
+  } u;
+  const __attribute__((address_space(4))) uint32_t *q = (const __attribute__((address_space(4))) uint32_t *)opaque(ptr);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(X) / 4; i++) u.w[i] = q[i];
+  return u.v;
+}
+struct KernArgs {  // layout of resample_period's kernel arguments
+  PeriodParams p;
+  const float *rows;
+  const StreamDesc *streams;
+  DescPack pack;
+};
+
+// FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
+// followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool A64 = false>
+__device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDesc &d0, KParams pp,
+                                         const float *__restrict__ rows, KDesc dp, const float *xs, uint32_t xshift,
+                                         uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit,
+                                         uint32_t nsplit) {
+  // (layouts that run the C++ loop keep the copies the kernel already holds: re-reading them there only added
+  //  register pressure -- scratch in every such instance)
+#ifndef SPEEXHIP_CXX_FIR_LOOP
+  constexpr bool kReload = A64 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available;
+#else
+  constexpr bool kReload = A64;
+#endif
+  auto params = [&]() -> PeriodParams {
+    if constexpr (kReload) return load_k(pp);
+    return p0;
+  };
+  // (the first group runs on the copy the prologue holds -- it dies at the loop, nothing later reads it --, every
+  //  further group on the copy read behind the previous one's loop: a read in FRONT of the first loop as well put
+  //  a scalar-load round trip between the staging barrier and the FIR of every workgroup, ~0.2 us that a
+  //  one-generation launch cannot hide)
+  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p0, xshift, m_lo, m_cnt, lane);
+  const uint32_t g_step = p0.wave_groups * nsplit;
+  uint32_t g = zsplit * p0.wave_groups + wave;
+  if (g >= p0.groups) return;
+  PeriodParams p = p0;
+  for (;;) {
+    f32x2 acc[R];  // .x = first channel of the pair, .y = second (unused when CT == 1)
+#pragma unroll
+    for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
+#ifdef SPEEXHIP_STAMPS
+    const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime(), fir_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if constexpr (A64) {
+      // fp64 sums, then the reference's store of its double sum into a float (resample.c:417, :544)
+      double acc64[R][2];
+#pragma unroll
+      for (int i = 0; i < R; i++) acc64[i][0] = acc64[i][1] = 0.0;
+      fir_group64<R, CT, PADDED, ONE_GROUP ? CT : 2 * CGF>(p, reinterpret_cast<const double *>(rows), xs, c, g, (p.skip & 4u) != 0,
+                                                           acc64);
+#pragma unroll
+      for (int i = 0; i < R; i++) acc[i] = f32x2{static_cast<float>(acc64[i][0]), static_cast<float>(acc64[i][1])};
+    } else {
+      fir_group<R, CT, PADDED, ONE_GROUP ? CT : 2 * CGF, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+    }
+#ifdef SPEEXHIP_STAMPS
+    {
+      asm volatile("" ::"v"(acc[0]));
+      const unsigned long long fir_t1 = __builtin_amdgcn_s_memtime(), fir_r1 = __builtin_amdgcn_s_memrealtime();
+      const uint32_t lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      if ((threadIdx.x & 63u) == 0 && lin_ < 8192) atomicMax(&g_stamps[lin_ * 16 + 7], fir_t1 - fir_t0);
+      if (threadIdx.x == 0 && lin_ < 8192) {  // wave 0: shader cycles and 100 MHz ticks of the same interval
+        g_stamps[lin_ * 16 + 9] = fir_t1 - fir_t0;
+        g_stamps[lin_ * 16 + 10] = fir_r1 - fir_r0;
+      }
+    }
+#endif
+    STAMP(5);
+    const PeriodParams q = params();  // (... and the far side)
+    if (!(q.skip & 8u) && c.live) {
+      StreamDesc d;
+      if constexpr (kReload)
+        d = load_k(dp);
+      else
+        d = d0;
+      if (q.prio & 2u) __builtin_amdgcn_s_setprio(2);
+      store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
+      if (q.prio & 2u) set_fir_priority(q);
+      STAMP(6);
+    }
+    g += g_step;
+    if (g >= q.groups) return;
+    p = q;
+  }
+}
+
+// ---- tap-range shares (round 3, second take) -------------------------------------------------------
+// A launch that cannot fill the chip runs its tiles in shares of a few phase groups each, and a share's
+// few FIR waves then sit one to a SIMD: a wave alone waits out every scalar-load round trip (14-19 cycles
+// per packed FMA instead of 4.5-5).  For long filters -- the decimators: 48k -> 22.05k 304 steps,
+// 48k -> 11.025k 604, 44.1k -> 8k 744 -- that wave's R x steps FMAs are the launch (48k -> 11.025k stereo,
+// one stream: 33 us for 48 000 frames as for 2^20).  Here the `parts` waves of a group each take a range
+// of its trips (rows pointer, window address and padding count-down advanced to the range's first trip),
+// the partial sums meet in the dead window behind a barrier, and part 0 stores.  Only where a wave's chain is
+// long: for BASELINE configs[1] the same scheme lost (two barriers and a pass through LDS against
+// 640 FMAs per wave: 13.22 -> 13.94 us, profiles/r03_ab_ksplit.txt); see launch_period_plan for the rule.
+template <int R, int CT, bool PADDED, int CF, bool W16>
+__device__ __forceinline__ void fir_group_part(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
+                                               const LaneCtx &c, uint32_t g, uint32_t part, uint32_t parts,
+                                               f32x2 (&acc)[R]) {
+  using Isa = FirLoopAsm<R, CT, CF, PADDED, W16>;
+  static_assert(CF != 0 && Isa::available, "tap-range shares run the ISA loop");
+  constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
+  constexpr uint32_t EB = W16 ? 2u : 4u;  // bytes per window element
+  auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+  const uint32_t delta_g = p.delta[g];
+  const uint32_t trips = (p.skip & 4u) ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+  const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u, total = trips >> 8;
+  const uint32_t t0 = sgpr(total * part / parts), t1 = sgpr(total * (part + 1) / parts);
+  auto overlap = [&](uint32_t lo, uint32_t hi) {  // trips of [t0, t1) inside [lo, hi)
+    const uint32_t a = max(t0, lo), b = min(t1, hi);
+    return b > a ? b - a : 0u;
+  };
+  const uint32_t main_end = total - tail;
+  // the padded walk: a boundary behind trip to_wrap0, then every wrap_step trips (0 = none)
+  uint32_t wraps = 0, to_wrap = 0;
+  if constexpr (PADDED) {
+    const uint32_t to_wrap0 = p.delta[p.groups + g];
+    to_wrap = to_wrap0;
+    if (to_wrap0 != 0 && t0 >= to_wrap0) {
+      const uint32_t past = t0 - to_wrap0;
+      wraps = 1 + past / p.wrap_step;
+      to_wrap = p.wrap_step - past % p.wrap_step;
+    } else if (to_wrap0 != 0) {
+      to_wrap = to_wrap0 - t0;
+    }
+  }
+  const float *rows_g = rows + (static_cast<size_t>(g) * p.l4 + t0) * (2 * bank_taps(R));
+  const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) +
+                        ((c.xlane + delta_g * c.C) + t0 * kStepsPerTrip * CF + wraps * p.pad) * EB;
+  const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
+  const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
+                                                        static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
+  Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * EB : 0u, sgpr(overlap(0, head)), sgpr(overlap(head, main_end)),
+           sgpr(overlap(main_end, total)), sgpr(to_wrap), sgpr(p.wrap_step), sgpr((kStepsPerTrip * CF + p.pad) * EB));
+}
+
+// One group per wave-set (the host launches tap-range shares only when a share's groups fit its waves:
+// the partial sums overwrite the window).  Wave w: group w % wave_groups of the share, part w / wave_groups.
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
+__device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restrict__ rows, KDesc dp, float *xs,
+                                               uint32_t xshift, uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
+                                               uint32_t zsplit) {
+  constexpr int CF = ONE_GROUP ? CT : 2 * CGF;
+  LaneCtx c;
+  uint32_t g, part, gw, wg, parts;
+  bool valid;
+  f32x2 acc[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
+  {
+    const PeriodParams p = load_k(pp);
+    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p, xshift, m_lo, m_cnt, lane);
+    wg = p.wave_groups;
+    parts = p.ksplit;
+    part = 0;
+    gw = wave;
+    while (gw >= wg) {  // (wave-uniform; parts <= 16)
+      gw -= wg;
+      part++;
+    }
+    g = zsplit * wg + gw;
+    valid = g < p.groups;
+    if (valid) fir_group_part<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, part, parts, acc);
+  }
+  __syncthreads();  // every wave is done with the window
+  // partial sums of part j >= 1, group-wave gw: block (j - 1) * wg + gw of R x 64 pairs, lanes side by side
+  f32x2 *sums = reinterpret_cast<f32x2 *>(xs);
+  if (valid && part != 0) {
+    f32x2 *mine = sums + (static_cast<size_t>(part - 1) * wg + gw) * (R * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < R; i++) mine[i * 64] = acc[i];
+  }
+  __syncthreads();
+  if (!valid || part != 0) return;
+  for (uint32_t j = 1; j < parts; j++) {
+    const f32x2 *theirs = sums + (static_cast<size_t>(j - 1) * wg + gw) * (R * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < R; i++) acc[i] += theirs[i * 64];
+  }
+  const PeriodParams q = load_k(pp);
+  if ((q.skip & 8u) || !c.live) return;
+  const StreamDesc d = load_k(dp);
+  store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
+}
+
+// (Mono int16 left through an LDS image -- one row per period, whole rows written 16 bytes per lane -- from
+//  round 1 to round 3 for launches that fill the chip: 160 -> 138 us for 32 streams of 44.1k -> 48k when a lane's
+//  20-byte runs cost five stores.  With the runs packed into dwords at either alignment (store_group) the
+//  per-lane stores are faster at every size: 32 streams 122 -> 112 us, 16 streams 72.5 -> 62.7, 8 streams
+//  42.4 -> 33.5, 64 streams 229 -> 210, 44.1k -> 8k 176 -> 165, q10 199 -> 192; the image path is gone
+//  (profiles/r03_mono_stores_ab.txt).  Its stereo and multi-pair counterparts never paid: 40-byte pieces per
+//  lane, stores alone 74 -> 48 us but the launch within noise; 4 ch 431 -> 421 us, 8 ch 621 -> 644, 6 ch 670 -> 735.)
+// <= 80 SGPRs: the hardware admits 8 waves per SIMD (two 16-wave workgroups per CU) only then
+// (MI355X_MICROARCH.md, residency; measured again with caps of 88, 90 and 96: 206 -> 260 us);
+// the compiler alone settles at ~106.  (A second, uncapped build of the kernel for launches of at
+// most one workgroup per CU was tried: removing the cap from this kernel gave 13.36 -> 13.0 us on
+// one stream, but as a separate __global__ around a shared device body it measured 13.59 vs 13.53 us,
+// i.e. nothing, and the refactoring cost the capped kernel 0.17 us -- not kept.)
+// The R = 5 instances only ever run one workgroup per CU (launch_period): no 64-VGPR limit for them -- nor for the
+// tap-range-share instances (KS), which are launches of one generation by construction.
+//
+// Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
+// shares of its phase groups.
+template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T, int CGF = 0, bool W16 = false, bool KS = false,
+          bool A64 = false>
+__global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
+    PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  // A workgroup that starts beside another one's FIR loop competes with 16 older waves for every
+  // issue slot: its few hundred prologue and staging instructions -- the ones that put its window
+  // loads in flight -- took 4-5 us there (0.5 us on an idle CU).  They run at raised priority; the
+  // FIR loop and everything after it at the default.
+  // (unconditionally: behind a test of p.prio the compiler holds back the descriptor's loads -- whose address
+  //  needs nothing but blockIdx.y -- until p.prio has arrived, a second memory round trip of ~0.4 us in every
+  //  workgroup's prologue; the diagnostics knob lowers the priority again as soon as it is known)
+  __builtin_amdgcn_s_setprio(3);
+  STAMP(0);
+#ifdef SPEEXHIP_STAMPS
+  {
+    const uint32_t lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && lin_ < 8192)
+      g_stamps[lin_ * 16 + 8] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11))) << 32) |
+                                __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+  }
+#endif
+  // Everything up to the window geometry is computed BEFORE the first branch (on whatever values an
+  // exiting workgroup happens to have: pure arithmetic, no memory access): the kernel arguments and
+  // the descriptor then arrive through one batch of scalar loads and a single wait instead of one
+  // round trip per early exit (four dependent waits, ~1.0 us from start to the first staging load).
+  const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
+  if (!(p.prio & 1u)) __builtin_amdgcn_s_setprio(0);  // diagnostics: A/B of the raised prologue priority
+  const uint32_t m_total = d.m_total;  // periods touched by this call: ceil((k_shift + n_out) / den), from the host
+  const uint32_t m_lo = blockIdx.x * p.lane_periods;
+  const uint32_t m_cnt = m_lo < m_total ? min(p.lane_periods, m_total - m_lo) : 1u;
+  // (most tiles lie wholly inside the call's input: a dozen scalar instructions give their geometry; the
+  //  general form -- history in front, silence behind, unaligned buffers -- costs ~150 and was a third of
+  //  the 1.2-1.4 us a workgroup took from its first instruction to its first staging load)
+  WindowGeom wg;
+  if (!window_geom_plain<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, p.threads, PADDED ? p.pad : 0u,
+                            PADDED ? p.period_magic : 0u, &wg))
+    wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, p.threads, PADDED ? p.pad : 0u,
+                        PADDED ? p.period_magic : 0u);
+  if (p.skip & 64u) return;  // diagnostics: bare dispatch cost
+  if (blockIdx.x == p.history_block) {
+    if (blockIdx.z == 0) roll_history<T>(p.channels, d, p.threads);
+    return;
+  }
+  if (d.n_out == 0 || blockIdx.x > p.history_block || m_lo >= m_total) return;
+  STAMP(1);
+  if (!(p.skip & 2u)) {
+    // 5 x 16 bytes per lane in flight: a 76 KB window staged by 1024 lanes in one round of loads
+    // (the padded commit needs more registers per group: 3 there keeps the kernel at 8 waves per SIMD)
+    // (float samples: 4 -- five float groups in flight spill at the 64 VGPRs of 8 waves per SIMD)
+    constexpr int UNR = PADDED ? 3 : (sizeof(T) == 4 ? (ONE_GROUP ? 5 : 3) : 5);
+    u32x4 w[UNR];
+    bool plain = false, plain_padded = false;
+    if constexpr (!PADDED) plain = window_is_plain<UNR, T>(wg);  // (wave-uniform)
+    if constexpr (PADDED && !W16) plain_padded = window_is_plain_padded<UNR, T>(wg);
+    if (plain_padded) {
+      window_fetch_plain<UNR, T>(wg, w);
+      STAMP(2);
+      window_commit_plain_padded<UNR, T>(xs, wg, w);
+    } else if (plain) {
+      window_fetch_plain<UNR, T>(wg, w);
+      STAMP(2);
+      if constexpr (W16)
+        window_commit_plain16<UNR>(reinterpret_cast<int16_t *>(xs), wg, w);
+      else
+        window_commit_plain<UNR, T>(xs, wg, w);
+    } else {
+      window_fetch<UNR, T>(wg, w);
+      STAMP(2);
+      if constexpr (W16)
+        window_commit16<UNR>(reinterpret_cast<int16_t *>(xs), d, wg, w);
+      else
+        window_commit<UNR, T>(xs, d, wg, w);
+    }
+  }
+  STAMP(3);
+  __syncthreads();
+  if (p.prio & 7u) set_fir_priority(p);
+  STAMP(4);
+  if (p.skip & 128u) return;  // diagnostics: prologue + staging only
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // (KS: the instances of tap-range shares are kernels of their own -- as a run-time branch of the one kernel the
+  //  second path cost the first its registers: 64 VGPRs and 28 bytes of scratch in the BASELINE configs[1] instance)
+  if constexpr (KS) {  // every wave of the workgroup works on a group (fir_tile_parts)
+    const __attribute__((address_space(4))) KernArgs *ka =
+        (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
+    fir_tile_parts<R, CT, ONE_GROUP, PADDED, T, CGF, W16>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
+                                                         threadIdx.x & 63u, blockIdx.z);
+    return;
+  } else {
+  if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
+  const __attribute__((address_space(4))) KernArgs *ka =
+      (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+  const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
+  fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF, W16, A64>(p, d, &ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
+                                                  threadIdx.x & 63u, blockIdx.z, gridDim.z);
+  }
+}
+
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool KS = false, bool A64 = false>
+hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
+                     uint32_t threads, size_t lds_bytes, hipStream_t stream) {
+#ifdef SPEEXHIP_CXX_FIR_LOOP
+  constexpr bool kParts = false;
+#else
+  constexpr bool kParts = KS && FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available;
+#endif
+  if constexpr (KS && !kParts) {  // (no ISA loop for this layout: the host never asks for tap-range shares of it)
+    return hipErrorInvalidValue;
+  } else {
+  DescPack empty;
+  if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
+  static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
+  if (pack != nullptr)
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS, A64>, seen_packed);
+  else
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS, A64>, seen_ring);
+  if (pack != nullptr)
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS, A64>), grid, dim3(threads), lds_bytes, stream,
+                       p, p.rows, nullptr, *pack);
+  else
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS, A64>), grid, dim3(threads), lds_bytes, stream,
+                       p, p.rows, d_descs, empty);
+  return hipGetLastError();
+  }
+}
+
+}  // namespace
+}  // namespace speexhip

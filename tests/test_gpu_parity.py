@@ -672,7 +672,8 @@ def test_window_layout_variants_of_the_period_kernel():
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
-        assert r.info()["fast_path"] == 2, (ch, i, o, q)
+        # (quality 9 and 10 on the ISA loop's layouts: the fp64-accumulate instances, round 4)
+        assert r.info()["fast_path"] == (5 if q >= 9 and ch in (1, 2, 4, 6, 8) else 2), (ch, i, o, q)
         for call, frames in enumerate([30000, 3, 0, 61234]):
             x = orc.tone_pcm(frames, ch, seed=call + q) if call % 2 else orc.lcg_pcm(frames * ch, 77 + call).reshape(frames, ch)
             got, used = r.process(x, 1 << 20)
@@ -1523,3 +1524,63 @@ def test_fp64_accumulate_is_closer_to_the_reference_than_the_fp32_chain():
     print("configs[2] mismatch rates: fp64 accumulate %.2e, fp32 chain %.2e" % (rates[speexhip.MODE_FAST], rates[speexhip.MODE_FAST_F32]))
     assert rates[speexhip.MODE_FAST] <= 1.5e-3
     assert rates[speexhip.MODE_FAST] <= 0.5 * rates[speexhip.MODE_FAST_F32] + 1e-4
+
+
+def test_fp64_accumulate_period_kernel_on_every_layout():
+    """Round 4: the period kernel with an fp64 accumulator (kernels_period64.hip, FirLoopAsm64): quality 9 and 10 on
+    ratios with den >= 7 -- mono (two periods per lane), stereo, 4 / 6 / 8 channels, plain and padded windows, the
+    r = 5 plan of one-generation launches and the r = 10 plan of batches -- against the oracle over multi-call
+    streams with int16 and float calls mixed: +-1 LSB, counters, position and history equal.  Layouts without an
+    ISA loop (3 channels) keep the fp32 chain and say so."""
+    import torch
+    worst = 0.0
+    cases = [(1, 44100, 48000, 10), (2, 44100, 48000, 10), (2, 44100, 48000, 9), (2, 48000, 44100, 10),
+             (1, 48000, 44100, 9), (4, 44100, 48000, 10), (6, 48000, 44100, 9), (8, 48000, 44100, 10),
+             (8, 44100, 48000, 9), (2, 48000, 11025, 10), (1, 44100, 8000, 9), (2, 44100, 8000, 10),
+             (2, 32000, 44100, 10), (1, 22050, 16000, 9), (2, 88200, 48000, 10), (2, 16000, 44100, 9)]
+    for (ch, i, o, q) in cases:
+        ref = orc.Oracle(ch, i, o, q)
+        r = speexhip.Resampler(ch, i, o, q)
+        info = r.info()
+        assert info["fast_path"] == 5 and info["accumulate_bits"] == 64, (ch, i, o, q, info)
+        for call, frames in enumerate([3, 40000, 1111, 300000]):
+            x = orc.lcg_pcm(frames * ch, 13 * call + ch).reshape(frames, ch)
+            cap = max(1, frames * o // i // 2) if call == 2 else 1 << 20  # one capacity-bound call
+            if call == 1:
+                got, used = r.process_float(x.astype(np.float32), cap)
+                want, wu = ref.process_float(x.astype(np.float32), cap)
+                assert used == wu and got.shape == want.shape
+                assert np.abs(got - want).max() <= 0.05, (ch, i, o, q, np.abs(got - want).max())
+                continue
+            got, used = r.process(x, cap)
+            want, wu = ref.process(x, cap)
+            assert used == wu and r.position() == ref.position(), (ch, i, o, q, call)
+            assert_close(got, want, "period64 %s call %d" % ((ch, i, o, q), call), rate=2e-3)
+            if got.size >= 20000:
+                worst = max(worst, float((got != want).mean()))
+        for c in range(ch):
+            assert np.array_equal(r.history()[:, c], ref.history(c))
+        r.close()
+    print("period64: worst share of samples off by one: %.2e" % worst)
+    # a batch of several generations (r = 10 plan), stereo q10, ragged streams
+    ch, i, o, q, S, F = 2, 44100, 48000, 10, 24, 150000
+    b = speexhip.Batch(S, ch, i, o, q)
+    assert b.info()["fast_path"] == 5
+    x = np.stack([orc.lcg_pcm(F * ch, 500 + s).reshape(F, ch) for s in range(S)])
+    d_in = torch.from_numpy(x).cuda()
+    cap = int(F * o / i) + 64
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    lens = [F - 1000 * (s % 5) for s in range(S)]
+    used, made = b.process_device(d_in.data_ptr(), F * ch, lens, d_out.data_ptr(), cap * ch, cap,
+                                  torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for s in (0, 7, 23):
+        want, wu = orc.Oracle(ch, i, o, q).process(x[s, : lens[s]], cap)
+        assert used[s] == wu and made[s] == want.shape[0]
+        assert_close(out[s, : made[s]], want, "period64 batch stream %d" % s, rate=2e-3)
+    b.close()
+    # no ISA loop for 3 channels: the fp32 chain, reported as such
+    r = speexhip.Resampler(3, 44100, 48000, 10)
+    assert r.info()["fast_path"] == 2 and r.info()["accumulate_bits"] == 32
+    r.close()
