@@ -384,6 +384,7 @@ def main():
 
     rc = 0
     if rank == 0:
+        box_ghz = speexhip.device_clock()  # (after the timed region)
         elapsed_med = statistics.median(wall)
         value = total_in_samples / elapsed_med / 1e6
         # dominant kernel = the one launch per step; algorithmic bytes per launch:
@@ -454,6 +455,9 @@ def main():
                      "frac": round(tfl / valu_peak, 4), "flops_per_launch": int(flops),
                      "arithmetic": "fp64 vector" if valu_peak == VALU64_PEAK_TFLOPS else "fp32 vector"},
             "checksum": checksum,
+            # which kind of box this was: the shader clock held under an FIR-like load (the pool's boxes differ by
+            # 4-6 %: lines of different leases compare at equal clocks only)
+            "box": {"shader_ghz_under_load": round(box_ghz[0], 3), "slowest_workgroup_ghz": round(box_ghz[1], 3)},
         }
         if share:
             line["config"]["parallelism"] += "; TEST RUN: all ranks share GPU 0 (BENCH_SHARE_GPU=1, gloo) -- not a measurement"

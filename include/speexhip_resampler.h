@@ -348,6 +348,11 @@ SPEEXHIP_API int speexhip_resampler_get_channel_position(SpeexHipResamplerState 
 SPEEXHIP_API int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
                                      uint32_t out[8]);
 
+/* Which kind of box is this?  Runs ~0.3 ms of packed fp32 FMAs with LDS reads on every CU and reports the shader
+ * clock (GHz) the chip held meanwhile (median / slowest workgroup): the pool's boxes differ by 4-6 %, so bench
+ * lines and the perf gate (tests/test_gpu_perf_gate.py) quote it.  Diagnostics; blocks the calling thread. */
+SPEEXHIP_API int speexhip_debug_device_clock(double *ghz_median, double *ghz_min);
+
 /* Test hook: the n-th next device allocation made while installing a filter fails, as if the
  * device were out of memory (exercises the resampler_basic_zero fallback, and the release of what
  * an aborted install had already allocated, without exhausting HBM); 0 = off. */

@@ -47,7 +47,7 @@ EXPORTS = [
     "speexhip_resampler_set_output_stride", "speexhip_resampler_get_output_stride",
     "speexhip_resampler_get_channel_position", "speexhip_debug_fail_device_allocs",
     "speexhip_release_cached_memory", "speexhip_debug_plan",
-    "speexhip_resampler_release_stream", "speexhip_batch_release_stream",
+    "speexhip_resampler_release_stream", "speexhip_batch_release_stream", "speexhip_debug_device_clock",
 ]
 
 
@@ -113,6 +113,8 @@ def lib():
         L.speexhip_batch_destroy.argtypes = [p]
         L.speexhip_batch_set_mode.restype = i32
         L.speexhip_batch_set_mode.argtypes = [p, i32]
+        L.speexhip_debug_device_clock.restype = i32
+        L.speexhip_debug_device_clock.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.speexhip_resampler_release_stream.restype = i32
         L.speexhip_resampler_release_stream.argtypes = [p]
         L.speexhip_batch_release_stream.restype = i32
@@ -225,6 +227,15 @@ def plan_call_ex(num, den, in_len, out_cap, float_entry, block_in, last, frac, m
     if rc != 0:
         raise ValueError(strerror(rc))
     return c.value, p.value, l.value, f.value, m.value
+
+
+def device_clock():
+    """(median GHz, slowest workgroup's GHz) the chip holds under an FIR-like load: the kind of box this is"""
+    a, b = C.c_double(), C.c_double()
+    rc = lib().speexhip_debug_device_clock(C.byref(a), C.byref(b))
+    if rc:
+        raise RuntimeError(strerror(rc))
+    return a.value, b.value
 
 
 def debug_plan(ratio_num, ratio_den, quality, channels):

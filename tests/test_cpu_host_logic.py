@@ -441,7 +441,8 @@ def test_generated_fir_loop_is_in_step_with_its_generator():
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     committed = open(os.path.join(os.path.dirname(path), "fir_loop_asm.inc")).read()
-    assert committed == gen.HEAD + "\n".join(v.function() for v in gen.variants()), "run python csrc/gen_fir_loop.py"
+    assert committed == (gen.HEAD + "\n".join(v.function() for v in gen.variants()) + gen.HEAD64 +
+                         "\n".join(v.function() for v in gen.variants64())), "run python csrc/gen_fir_loop.py"
     for v in gen.variants():
         lines = v.lines()
         loops = 3 if v.R == 10 else 1
@@ -458,3 +459,23 @@ def test_generated_fir_loop_is_in_step_with_its_generator():
         named = set(int(r) for l in lines for pair in re.findall(r"s\[(\d+):(\d+)\]", l) for r in range(int(pair[0]), int(pair[1]) + 1))
         assert named <= used and len(used) == 4 * v.S * v.R // 2 * 1 and 32 not in used and 4 <= min(used) and max(used) <= 73, v.name
         assert max(v.vgprs()) < (64 if v.R == 10 else 128), v.name
+    # the fp64-accumulate variants (round 4): one v_fma_f64 per tap and half of the lane's pair, one conversion per
+    # half of every sample read, doubles in aligned SGPR pairs of the same homes, aligned VGPR pairs
+    assert len(gen.variants64()) == 15
+    for v in gen.variants64():
+        lines = v.lines()
+        loops = 3 if v.R == 10 else 1
+        rows = (5 + 10 + 5) if v.R == 10 else v.R
+        assert sum(1 for l in lines if l.startswith("v_fma_f64")) == 2 * v.S * rows * 2, v.name
+        assert not any(l.startswith("v_pk_fma_f32") for l in lines), v.name
+        assert sum(1 for l in lines if l.startswith("ds_read")) == (loops * 2 + 1) * v.S * (2 if v.CT == 1 else 1), v.name
+        assert sum(1 for l in lines if l.startswith("v_cvt_f64_f32")) == loops * 2 * v.S * 2, v.name
+        assert sum(1 for l in lines if l == "s_waitcnt lgkmcnt(0)") == 2 * loops + 1, v.name
+        used = set(gen.bank_regs(v.banks["A"]) + gen.bank_regs(v.banks["B"]))
+        assert len(used) == 2 * (2 * v.S * v.R) and 32 not in used and max(used) <= 73, v.name   # two dwords per tap
+        for l in lines:
+            if l.startswith("v_fma_f64"):
+                m = re.match(r"v_fma_f64 %\[a\d+[xy]\], s\[(\d+):(\d+)\], v\[(\d+):(\d+)\]", l)
+                assert m and int(m.group(1)) % 2 == 0 and int(m.group(3)) % 2 == 0, (v.name, l)
+                assert int(m.group(1)) in used and int(m.group(2)) in used, (v.name, l)
+        assert max(v.vgprs()) < (64 if v.R == 10 else 128) and min(v.vgprs()) % 2 == 0, v.name

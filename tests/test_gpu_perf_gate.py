@@ -1,0 +1,44 @@
+"""Perf-regression gate (round 4): every workload of profiles/perf_floor.json -- the BASELINE configs
+at 1 and 32 streams, the lowest rows of the channels x rate-pairs sweep, a few one-generation launches -- is
+re-measured (50 launches through HIP events on the launch stream, best of 3 repetitions, after a clock preheat) and
+must stay under its ceiling: 10 % above the slowest time any box has measured for it (tools/perf_floor.py --measure
+--merge, run on several leases; the pool's boxes differ by 4-6 %).  It guards the fitted planners (launch_period_plan,
+period_launch_prefers_w16, launch_slide's rules): the forced-variant parity tests keep them correct, this keeps
+them fast.  SPEEXHIP_PERF_GATE=0 skips it (a box known to be throttled)."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+from golden_util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("perf_floor", os.path.join(ROOT, "tools", "perf_floor.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.skipif(os.environ.get("SPEEXHIP_PERF_GATE") == "0", reason="SPEEXHIP_PERF_GATE=0")
+def test_no_workload_is_slower_than_its_ceiling():
+    import speexhip
+    tool = _tool()
+    floor = json.load(open(tool.FLOOR))
+    ghz, ghz_min = speexhip.device_clock()
+    known = {w[0]: w for w in tool.WORKLOADS}
+    late, report = [], []
+    for name, row in sorted(floor["workloads"].items()):
+        assert name in known and list(known[name][1]) == row["config"], "perf_floor.json and tools/perf_floor.py disagree on %s" % name
+        us, path = tool.measure(known[name])
+        if us > row["ceiling_us"]:  # once more before it counts: a neighbour's burst, a clock dip
+            us = min(us, tool.measure(known[name], reps=5)[0])
+        report.append("%-22s %9.2f us  ceiling %9.2f  (slowest seen %9.2f)  path %d" % (name, us, row["ceiling_us"], row["slowest_us"], path))
+        assert path == row["fast_path"], "%s runs fast_path %d, the floor was measured on %d" % (name, path, row["fast_path"])
+        if us > row["ceiling_us"]:
+            late.append(report[-1])
+    print("box: %.3f GHz under load (slowest workgroup %.3f)\n" % (ghz, ghz_min) + "\n".join(report))
+    assert not late, "slower than the ceiling of profiles/perf_floor.json (box at %.3f GHz):\n%s" % (ghz, "\n".join(late))
