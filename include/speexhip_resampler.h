@@ -28,7 +28,7 @@ extern "C" {
 #define SPEEXHIP_API __attribute__((visibility("default")))
 
 /* Error codes: 0..5 are the reference's enum (deps/speex/speex_resampler.h:104-113);
- * 6 is new and reports a HIP runtime/device failure. */
+ * 6 is new and reports a HIP runtime/device failure; 7 is returned by the ..._take calls only. */
 enum {
   SPEEXHIP_ERR_SUCCESS = 0,
   SPEEXHIP_ERR_ALLOC_FAILED = 1,
@@ -37,6 +37,7 @@ enum {
   SPEEXHIP_ERR_PTR_OVERLAP = 4,
   SPEEXHIP_ERR_OVERFLOW = 5,
   SPEEXHIP_ERR_DEVICE = 6,
+  SPEEXHIP_ERR_NO_BLOCK = 7,   /* ..._take: no pinned result block free right now; the state is untouched */
   SPEEXHIP_ERR_MAX_ERROR
 };
 
@@ -185,6 +186,23 @@ SPEEXHIP_API int speexhip_resampler_process_interleaved_int_device(SpeexHipResam
                                                                    uint32_t *in_len, int16_t *d_out,
                                                                    uint32_t *out_len,
                                                                    void *hip_stream);
+
+/* The host-buffer calls with the result left in a PINNED block owned by the caller afterwards (release it with
+ * speexhip_block_release).  Same counters, same samples as speexhip_resampler_process_interleaved_int / _float with
+ * *out_len as the capacity; *out_block = NULL when no frame was produced.  The kernel writes the block straight through
+ * PCIe, so the samples cross memory once on their way out, not twice (device or pinned buffer, then a copy into the
+ * caller's buffer).  Blocks are carved out of one pinned slab (SPEEXHIP_TAKE_MB, default 64 MiB, made by the first
+ * such call), never allocated per call: while the caller holds so many blocks that none fits, the call returns
+ * SPEEXHIP_ERR_NO_BLOCK WITHOUT touching the state, and the caller makes the copying call instead.  The N-API addon
+ * hands the block to JavaScript as an external Buffer: src/index.ts:111-115 returns a fresh Buffer the caller owns,
+ * and so does it. */
+SPEEXHIP_API int speexhip_resampler_process_interleaved_int_take(SpeexHipResamplerState *st, const int16_t *in,
+                                                                 uint32_t *in_len, uint32_t *out_len,
+                                                                 int16_t **out_block);
+SPEEXHIP_API int speexhip_resampler_process_interleaved_float_take(SpeexHipResamplerState *st, const float *in,
+                                                                   uint32_t *in_len, uint32_t *out_len,
+                                                                   float **out_block);
+SPEEXHIP_API void speexhip_block_release(void *block);
 
 /* The caller is about to destroy the stream of this state's last device-pointer call (one stream per
  * request, say): what that call still has in flight is ordered behind an event of the state's own and

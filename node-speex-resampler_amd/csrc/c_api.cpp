@@ -137,6 +137,22 @@ int speexhip_resampler_process_interleaved_int_device(SpeexHipResamplerState *st
                                    static_cast<hipStream_t>(hip_stream)); });
 }
 
+int speexhip_resampler_process_interleaved_int_take(SpeexHipResamplerState *st, const int16_t *in, uint32_t *in_len,
+                                                    uint32_t *out_len, int16_t **out_block) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr || out_block == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return st->batch->process_host_take(in, in_len, out_len, false, reinterpret_cast<void **>(out_block)); });
+}
+
+int speexhip_resampler_process_interleaved_float_take(SpeexHipResamplerState *st, const float *in, uint32_t *in_len,
+                                                      uint32_t *out_len, float **out_block) {
+  if (st == nullptr || in_len == nullptr || out_len == nullptr || out_block == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] { return st->batch->process_host_take(in, in_len, out_len, true, reinterpret_cast<void **>(out_block)); });
+}
+
+void speexhip_block_release(void *block) {
+  if (block != nullptr) speexhip::Batch::release_block(block);
+}
+
 int speexhip_resampler_process_interleaved_float(SpeexHipResamplerState *st, const float *in,
                                                  uint32_t *in_len, float *out, uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))
@@ -266,6 +282,7 @@ const char *speexhip_resampler_strerror(int err) {
     case SPEEXHIP_ERR_INVALID_ARG: return "Invalid argument.";
     case SPEEXHIP_ERR_PTR_OVERLAP: return "Input and output buffers overlap.";
     case SPEEXHIP_ERR_DEVICE: return speexhip::last_device_error();
+    case SPEEXHIP_ERR_NO_BLOCK: return "No pinned result block available (state untouched).";
     default: return "Unknown error. Bad error code or strange version mismatch.";
   }
 }

@@ -996,6 +996,80 @@ int Batch::ensure_stage(size_t dev_in, size_t dev_out, size_t pin_in, size_t pin
   return rc;
 }
 
+// Host buffer in, result in a pinned block the caller owns afterwards (the N-API addon wraps it in an external
+// Buffer: src/index.ts:111-115 returns a fresh, caller-owned Buffer, and so does this -- without the copy into it).
+// The kernel writes the block directly: small calls as before (they already wrote pinned memory, then the result
+// was copied out of it: 0.18 us per KB), large ones instead of a device buffer + a copy back.  States whose
+// channels stand apart and the zero fallback take the ordinary path into the block.
+int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len, bool float_io, void **block) {
+  *block = nullptr;
+  if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
+  ON_DEVICE();
+  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
+  const uint32_t frames = *in_len;
+  const bool split = !uniform(0);
+  uint32_t will_make = 0;
+  for (uint32_t c = 0; c < (split ? channels_ : 1u); c++)
+    will_make = std::max(will_make, produced_closed_form(filter_.num, filter_.den, frames, *out_len, P(0, c)));
+  const size_t in_bytes = static_cast<size_t>(frames) * channels_ * es;
+  const size_t out_bytes = static_cast<size_t>(will_make) * channels_ * es;
+  // (+ 64 bytes behind the samples: the completion word)  Nothing has touched the state yet: without a block the
+  // caller makes the copying call instead.
+  void *blk = nullptr;
+  if (!pool::block_get(&blk, out_bytes + 128)) return SPEEXHIP_ERR_NO_BLOCK;
+  struct Guard {
+    void *p;
+    ~Guard() {
+      if (p != nullptr) (void)pool::block_put(p);
+    }
+  } guard{blk};
+  int rc;
+  if (split || zero_mode_) {
+    rc = process_host(in, in_len, blk, out_len, float_io);
+    if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
+  } else {
+    DrainOnExit drain(&own_stream_);
+    const bool direct_in = in_bytes >= kZeroCopyBelow;
+    rc = ensure_stage(direct_in ? in_bytes : 0, 0, direct_in ? 0 : in_bytes, 0);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    const void *src = nullptr;
+    if (in != nullptr && in_bytes != 0) {
+      if (direct_in) {
+        HIP_TRY(hipMemcpyAsync(d_stage_in_, in, in_bytes, hipMemcpyHostToDevice, own_stream_));
+        src = d_stage_in_;
+      } else {
+        std::memcpy(h_pin_in_, in, in_bytes);
+        src = h_pin_in_;
+      }
+    }
+    volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(static_cast<char *>(blk) + ((out_bytes + 63) & ~static_cast<size_t>(63)));
+    *done = 0;
+    rc = process_device(src, 0, in_len, blk, 0, out_len, float_io, own_stream_);
+    if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
+    static const bool poll_done = std::getenv("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
+    bool signalled = false;
+    if (poll_done && !direct_in && hipStreamWriteValue32(own_stream_, const_cast<uint32_t *>(done), 1u, 0) == hipSuccess) {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+      for (uint32_t spins = 0; !signalled; spins++) {
+        signalled = __atomic_load_n(const_cast<const uint32_t *>(done), __ATOMIC_ACQUIRE) == 1u;
+        if (signalled) break;
+        __builtin_ia32_pause();
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+    if (!signalled) HIP_TRY(hipStreamSynchronize(own_stream_));
+    drain.armed = false;
+  }
+  if (*out_len == 0) return rc;  // (the guard returns the block)
+  guard.p = nullptr;
+  *block = blk;
+  return rc;
+}
+
+void Batch::release_block(void *block) { (void)pool::block_put(block); }
+
 int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io) {
   if (n_streams_ != 1) return SPEEXHIP_ERR_BAD_STATE;
   ON_DEVICE();

@@ -65,6 +65,11 @@ class Batch {
                      uint64_t out_stride, uint32_t *out_len, bool float_io, hipStream_t stream);
   // Host-buffer call for a single-stream batch; synchronous (H2D, kernels, D2H).
   int process_host(const void *in, uint32_t *in_len, void *out, uint32_t *out_len, bool float_io);
+  // The same call with the result left in a pinned block of the pool that the caller then OWNS (release_block):
+  // the kernel writes the block straight through PCIe, so the samples cross memory once on their way out instead
+  // of twice (device or pinned buffer -> copy -> the caller's buffer).  *block = nullptr when nothing was written.
+  int process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len, bool float_io, void **block);
+  static void release_block(void *block);
   // n_chunks consecutive host-buffer calls of a single-stream batch as one launch; outputs are
   // written back to back into `out` (room for the sum of the capacities).
   int process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_t *in_len, void *out,

@@ -1,7 +1,9 @@
 // pool.cpp -- see pool.h.
 #include "pool.h"
 
+#include <algorithm>
 #include <chrono>
+#include <iterator>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -73,6 +75,82 @@ void *take(Shelf &sh, size_t cls) {
 }
 
 }  // namespace
+
+// ---- the slab of caller-owned result blocks (pool.h) -- first fit over a sorted free list, 4 KiB granules ----
+namespace {
+struct Slab {
+  std::mutex mu;
+  char *base = nullptr;
+  size_t bytes = 0;
+  bool tried = false;
+  std::map<size_t, size_t> free_at;    // offset -> length
+  std::map<size_t, size_t> taken;      // offset -> length
+};
+Slab &slab() {
+  static Slab *s = new Slab();  // never destroyed, like the pool
+  return *s;
+}
+}  // namespace
+
+bool block_get(void **ptr, size_t bytes) {
+  *ptr = nullptr;
+  Slab &sl = slab();
+  std::lock_guard<std::mutex> lock(sl.mu);
+  if (!sl.tried) {
+    sl.tried = true;
+    size_t mb = 64;
+    if (const char *e = std::getenv("SPEEXHIP_TAKE_MB")) mb = static_cast<size_t>(std::strtoull(e, nullptr, 10));
+    if (mb != 0) {
+      MissTimer timer("hipHostMalloc (slab of result blocks)", mb << 20);
+      void *p = nullptr;
+      if (hipHostMalloc(&p, mb << 20, hipHostMallocDefault) == hipSuccess) {
+        sl.base = static_cast<char *>(p);
+        sl.bytes = mb << 20;
+        sl.free_at[0] = sl.bytes;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+  }
+  if (sl.base == nullptr) return false;
+  const size_t want = (std::max<size_t>(bytes, 1) + 4095) & ~static_cast<size_t>(4095);
+  for (auto it = sl.free_at.begin(); it != sl.free_at.end(); ++it) {
+    if (it->second < want) continue;
+    const size_t off = it->first, len = it->second;
+    sl.free_at.erase(it);
+    if (len > want) sl.free_at[off + want] = len - want;
+    sl.taken[off] = want;
+    *ptr = sl.base + off;
+    return true;
+  }
+  return false;
+}
+
+bool block_put(void *ptr) {
+  Slab &sl = slab();
+  std::lock_guard<std::mutex> lock(sl.mu);
+  if (sl.base == nullptr || ptr < static_cast<void *>(sl.base) || ptr >= static_cast<void *>(sl.base + sl.bytes)) return false;
+  const size_t off = static_cast<size_t>(static_cast<char *>(ptr) - sl.base);
+  auto it = sl.taken.find(off);
+  if (it == sl.taken.end()) return false;
+  size_t start = off, len = it->second;
+  sl.taken.erase(it);
+  auto next = sl.free_at.lower_bound(start);
+  if (next != sl.free_at.end() && next->first == start + len) {  // merge with the free range behind
+    len += next->second;
+    next = sl.free_at.erase(next);
+  }
+  if (next != sl.free_at.begin()) {  // ... and with the one in front
+    auto prev = std::prev(next);
+    if (prev->first + prev->second == start) {
+      start = prev->first;
+      len += prev->second;
+      sl.free_at.erase(prev);
+    }
+  }
+  sl.free_at[start] = len;
+  return true;
+}
 
 size_t size_class(size_t bytes) {
   if (bytes <= kMinClass) return kMinClass;
@@ -252,6 +330,18 @@ size_t release_idle() {
     for (auto &v : s.events) {
       events.insert(events.end(), v.second.begin(), v.second.end());
       v.second.clear();
+    }
+  }
+  {  // the slab of result blocks, when nobody holds one (the next ..._take call makes it again)
+    Slab &sl = slab();
+    std::lock_guard<std::mutex> lock(sl.mu);
+    if (sl.base != nullptr && sl.taken.empty()) {
+      pin.push_back(sl.base);
+      bytes += sl.bytes;
+      sl.base = nullptr;
+      sl.bytes = 0;
+      sl.free_at.clear();
+      sl.tried = false;
     }
   }
   for (void *p : dev) (void)hipFree(p);

@@ -37,6 +37,14 @@ void stream_put(int device, hipStream_t s);
 hipError_t event_get(int device, hipEvent_t *e);
 void event_put(int device, hipEvent_t e);
 
+// Result blocks that a caller OWNS after a host-buffer call (Batch::process_host_take; the N-API addon's external
+// Buffers): carved out of one pinned slab (SPEEXHIP_TAKE_MB, default 64 MiB, 0 = none) made by the first request,
+// so that no call ever pays hipHostMalloc for its result -- a caller that keeps its blocks (JavaScript Buffers wait
+// for the garbage collector) exhausts the slab instead of growing pinned memory, and block_get says so: false =
+// nothing free right now (the caller falls back to the copying call).  block_put: false = not one of these blocks.
+bool block_get(void **ptr, size_t bytes);
+bool block_put(void *ptr);
+
 // Returns everything idle to the driver; the number of bytes released.
 size_t release_idle();
 

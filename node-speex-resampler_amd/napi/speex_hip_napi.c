@@ -137,6 +137,18 @@ static int buffer_or_null(napi_env env, napi_value v, void **data, size_t *bytes
   return napi_get_buffer_info(env, v, data, bytes) == napi_ok;
 }
 
+/* external Buffers over pinned blocks of the library (process_common) */
+static const size_t kExternalMin = 4096;            /* below this a copy is cheaper than a finalizer */
+static size_t g_external_bytes = 0;
+static int g_no_external = 0; /* SPEEXHIP_NAPI_COPY=1: always copy (A/B, tests) */
+static void finalize_block(napi_env env, void *data, void *hint) {
+  const size_t bytes = (size_t)hint;
+  int64_t adjusted = 0;
+  speexhip_block_release(data);
+  __atomic_fetch_sub(&g_external_bytes, bytes, __ATOMIC_RELAXED);
+  (void)napi_adjust_external_memory(env, -(int64_t)bytes, &adjusted);
+}
+
 /* process / processFloat (handle, chunk: Buffer|null, inFrames, outCapacityFrames) -> Buffer
  * (fresh copy of the frames written): the src/index.ts:90-115 sequence without the WASM heap. */
 static napi_value process_common(napi_env env, napi_callback_info info, size_t sample_bytes) {
@@ -168,6 +180,41 @@ static napi_value process_common(napi_env env, napi_callback_info info, size_t s
    * is held from before the peek until the call has returned. */
   uint32_t will_use = 0, will_make = 0;
   speexhip_resampler_peek(st, in_len, out_len, sample_bytes == 4, &will_use, &will_make);
+  const size_t made_bytes = (size_t)will_make * frame_bytes;
+  /* Round 4: results of a few KB and more stay where the kernel wrote them -- a pinned block of the library's
+   * pool -- and become an EXTERNAL Buffer (a fresh, caller-owned Buffer like src/index.ts:111-115 returns; its
+   * finalizer hands the block back to the pool): the samples cross memory once on their way out instead of twice.
+   * Bounded: the blocks come out of one pinned slab (SPEEXHIP_TAKE_MB, 64 MiB); while JavaScript holds so many of
+   * them that none fits (Buffers kept alive, or a garbage collector that has not run yet) the library says NO_BLOCK
+   * without touching the state and the copying path below serves the call. */
+  int take_rc = SPEEXHIP_ERR_NO_BLOCK;
+  void *block = NULL;
+  uint32_t take_in = in_len, take_out = out_len;
+  if (made_bytes >= kExternalMin && !g_no_external)
+    take_rc = sample_bytes == 2
+                  ? speexhip_resampler_process_interleaved_int_take(st, (const int16_t *)in_data, &take_in, &take_out, (int16_t **)&block)
+                  : speexhip_resampler_process_interleaved_float_take(st, (const float *)in_data, &take_in, &take_out, (float **)&block);
+  if (take_rc != SPEEXHIP_ERR_NO_BLOCK) { /* (NO_BLOCK: the state is untouched -> the copying path below) */
+    int rc = take_rc;
+    uint32_t cap_len = take_out;
+    UNLOCK(h);
+    if (rc != 0 || cap_len != will_make || block == NULL) {
+      speexhip_block_release(block);
+      napi_throw_error(env, NULL, speexhip_resampler_strerror(rc != 0 ? rc : SPEEXHIP_ERR_BAD_STATE));
+      return NULL;
+    }
+    napi_value ext;
+    __atomic_fetch_add(&g_external_bytes, made_bytes, __ATOMIC_RELAXED);
+    if (napi_create_external_buffer(env, made_bytes, block, finalize_block, (void *)made_bytes, &ext) != napi_ok) {
+      __atomic_fetch_sub(&g_external_bytes, made_bytes, __ATOMIC_RELAXED);
+      speexhip_block_release(block);
+      napi_throw_error(env, NULL, "speexhip N-API failure: napi_create_external_buffer");
+      return NULL;
+    }
+    int64_t adjusted = 0;
+    (void)napi_adjust_external_memory(env, (int64_t)made_bytes, &adjusted); /* the collector sees what the Buffer holds */
+    return ext;
+  }
   napi_value out;
   void *dst = NULL;
   NAPI_OK_LOCKED(h, napi_create_buffer(env, (size_t)will_make * frame_bytes, &dst, &out));
@@ -523,6 +570,8 @@ static napi_value ReleaseCachedMemory(napi_env env, napi_callback_info info) {
 }
 
 static napi_value ModuleInit(napi_env env, napi_value exports) {
+  const char *copy_env = getenv("SPEEXHIP_NAPI_COPY");
+  g_no_external = copy_env != NULL && copy_env[0] != '\0' && copy_env[0] != '0';
   napi_property_descriptor props[] = {
       {"init", NULL, Init, NULL, NULL, NULL, napi_default, NULL},
       {"destroy", NULL, Destroy, NULL, NULL, NULL, napi_default, NULL},

@@ -19,6 +19,7 @@ KERNEL_NAMES = ("direct_single", "direct_double", "interpolate_single", "interpo
 # reference codes (deps/speex/speex_resampler.h:104-113) + 6 = HIP failure
 ERR_SUCCESS, ERR_ALLOC_FAILED, ERR_BAD_STATE, ERR_INVALID_ARG, ERR_PTR_OVERLAP, ERR_OVERFLOW = 0, 1, 2, 3, 4, 5
 ERR_DEVICE = 6
+ERR_NO_BLOCK = 7  # the ..._take calls: no pinned result block free right now, state untouched
 
 EXPORTS = [
     "speexhip_resampler_init", "speexhip_resampler_destroy",
@@ -48,6 +49,8 @@ EXPORTS = [
     "speexhip_resampler_get_channel_position", "speexhip_debug_fail_device_allocs",
     "speexhip_release_cached_memory", "speexhip_debug_plan",
     "speexhip_resampler_release_stream", "speexhip_batch_release_stream", "speexhip_debug_device_clock",
+    "speexhip_resampler_process_interleaved_int_take", "speexhip_resampler_process_interleaved_float_take",
+    "speexhip_block_release",
 ]
 
 
@@ -113,6 +116,12 @@ def lib():
         L.speexhip_batch_destroy.argtypes = [p]
         L.speexhip_batch_set_mode.restype = i32
         L.speexhip_batch_set_mode.argtypes = [p, i32]
+        for fn, st in ((L.speexhip_resampler_process_interleaved_int_take, C.c_int16),
+                       (L.speexhip_resampler_process_interleaved_float_take, C.c_float)):
+            fn.restype = i32
+            fn.argtypes = [p, C.c_void_p, pu32, pu32, C.POINTER(C.POINTER(st))]
+        L.speexhip_block_release.restype = None
+        L.speexhip_block_release.argtypes = [C.c_void_p]
         L.speexhip_debug_device_clock.restype = i32
         L.speexhip_debug_device_clock.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.speexhip_resampler_release_stream.restype = i32
@@ -345,6 +354,36 @@ class Resampler:
         rc = lib().speexhip_resampler_set_mode(self._h, mode)
         if rc:
             raise ValueError(strerror(rc))
+
+    def process_take(self, frames, out_capacity, float_io=False, keep=False):
+        """The host-buffer call whose result stays in a pinned block of the library (what the N-API addon wraps in
+        an external Buffer).  Returns (samples, consumed): a copy with the block released, or -- keep=True -- a
+        view over the block plus the block's address as a third item (release with release_block)."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32 if float_io else np.int16)
+        n = frames.shape[0]
+        il, ol = C.c_uint32(n), C.c_uint32(out_capacity)
+        ctype = C.c_float if float_io else C.c_int16
+        blk = C.POINTER(ctype)()
+        fn = (lib().speexhip_resampler_process_interleaved_float_take if float_io
+              else lib().speexhip_resampler_process_interleaved_int_take)
+        rc = fn(self._h, frames.ctypes.data_as(C.c_void_p) if n else None, C.byref(il), C.byref(ol), C.byref(blk))
+        if rc == ERR_NO_BLOCK:
+            raise MemoryError(strerror(rc))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        if not blk:
+            empty = np.zeros((0, self.channels), dtype=frames.dtype)
+            return (empty, il.value, 0) if keep else (empty, il.value)
+        view = np.ctypeslib.as_array(blk, shape=(ol.value * self.channels,)).reshape(ol.value, self.channels)
+        if keep:
+            return view, il.value, C.cast(blk, C.c_void_p).value
+        out = view.copy()
+        lib().speexhip_block_release(C.cast(blk, C.c_void_p))
+        return out, il.value
+
+    @staticmethod
+    def release_block(addr):
+        lib().speexhip_block_release(C.c_void_p(addr))
 
     def release_stream(self):
         """before the caller destroys the stream of this state's last device-pointer call"""

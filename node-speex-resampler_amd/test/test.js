@@ -294,6 +294,34 @@ function poolTest() {
   console.log('state pool: recycled and released, bytes unchanged');
 }
 
+// Round 4: results of >= 4 KB are external Buffers over pinned blocks of the library's pool.  They are the
+// caller's: writable, untouched by later calls, alive after the state is gone, and their blocks go back to the
+// pool when the collector drops them (node --expose-gc lets the test see that; without it the check is skipped).
+function externalBufferTest() {
+  const r = new SpeexResampler(2, 44100, 48000, 7);
+  const a = r.processChunk(lcg(30000, 2, 5));
+  const keep = sha1(a);
+  const copyOfA = Buffer.from(a);
+  for (let k = 0; k < 8; k++) r.processChunk(lcg(30000, 2, 6 + k));   // later calls: other blocks
+  assert(sha1(a) === keep, 'a returned Buffer must not change under later calls');
+  a.writeInt16LE(1234, 0);                                              // the caller may write to it
+  assert(a.readInt16LE(0) === 1234 && a.length === copyOfA.length, 'returned Buffers are writable');
+  r.destroy();
+  assert(a.readInt16LE(0) === 1234 && a.slice(2).equals(copyOfA.slice(2)), 'a returned Buffer outlives its state');
+  if (global.gc) {
+    let held = [];
+    const r2 = new SpeexResampler(2, 44100, 48000, 7);
+    for (let k = 0; k < 40; k++) held.push(r2.processChunk(lcg(200000, 2, k)));  // ~35 MB of blocks held
+    held = null;
+    global.gc();
+    r2.destroy();
+    const released = SpeexResampler.releaseCachedMemory();
+    assert(released > 0 || process.env.SPEEXHIP_POOL_MB === '0' || process.env.SPEEXHIP_NAPI_COPY === '1',
+      'collected Buffers must hand their blocks back to the pool');
+  }
+  console.log('external Buffers: caller-owned, stable, recycled');
+}
+
 (async () => {
   const early = (() => { try { new SpeexResampler(1, 8000, 8000).processChunk(Buffer.alloc(2)); return null; } catch (e) { return e.message; } })();
   assert(early === 'You need to wait for SpeexResampler.initPromise before calling this method', 'initPromise guard');
@@ -304,5 +332,6 @@ function poolTest() {
   errorTest();
   await extensionsTest();
   poolTest();
+  externalBufferTest();
   console.log('ALL NODE TESTS PASSED');
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -260,9 +260,12 @@ def test_node_drop_in_harness():
     """The JS drop-in (index.js -> N-API addon -> libspeexhip): the counterpart of the reference's
     src/test.ts, plus sha1 goldens and the F5 small-chunk case."""
     script = os.path.join(ROOT, "node-speex-resampler_amd", "test", "test.js")
-    res = subprocess.run(["node", script], capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    assert "ALL NODE TESTS PASSED" in res.stdout
+    # twice: results as external Buffers over the library's pinned blocks (round 4: the default from 4 KB) and as
+    # copies (SPEEXHIP_NAPI_COPY=1, every call of rounds 1-3) -- the sha1 goldens hold either way
+    for env in (dict(os.environ), dict(os.environ, SPEEXHIP_NAPI_COPY="1")):
+        res = subprocess.run(["node", "--expose-gc", script], capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+        assert "ALL NODE TESTS PASSED" in res.stdout
 
 
 def test_small_ratio_sliding_window_kernel_variants():
@@ -1584,3 +1587,71 @@ def test_fp64_accumulate_period_kernel_on_every_layout():
     r = speexhip.Resampler(3, 44100, 48000, 10)
     assert r.info()["fast_path"] == 2 and r.info()["accumulate_bits"] == 32
     r.close()
+
+
+def test_owned_block_calls_return_the_bytes_of_the_copying_calls():
+    """Round 4: speexhip_resampler_process_interleaved_{int,float}_take leave the result in a pinned block the caller
+    then owns (the N-API addon's external Buffers).  Same counters, same bytes as the copying call in both modes,
+    over small (polled, pinned in and out), medium and large (H2D copy in, kernel writes the block) calls, empty
+    and capacity-bound calls, a state whose channels stand apart and the zero fallback; blocks are independent of
+    later calls (the caller owns them) and recycle through the pool."""
+    rng = np.random.RandomState(11)
+    for mode in (speexhip.MODE_EXACT, speexhip.MODE_FAST):
+        for (ch, i, o, q) in [(2, 44100, 48000, 7), (1, 24000, 48000, 10), (8, 48000, 44100, 5), (3, 48000, 16000, 4)]:
+            a = speexhip.Resampler(ch, i, o, q, mode=mode)
+            b = speexhip.Resampler(ch, i, o, q, mode=mode)
+            kept = []
+            for call, frames in enumerate([480, 0, 16384, 3, 200000, 1 << 20, 777]):
+                x = orc.lcg_pcm(frames * ch, 3 * call + ch).reshape(frames, ch)
+                cap = (frames * o // i // 3 + 1) if call == 4 else (1 << 21)   # one capacity-bound call
+                fio = call in (2, 6)
+                if fio:
+                    want, wu = a.process_float(x.astype(np.float32), cap)
+                    view, gu, addr = b.process_take(x.astype(np.float32), cap, float_io=True, keep=True)
+                else:
+                    want, wu = a.process(x, cap)
+                    view, gu, addr = b.process_take(x, cap, keep=True)
+                assert gu == wu and view.shape == want.shape and a.position() == b.position(), (mode, ch, i, o, q, call)
+                assert np.array_equal(view, want), (mode, ch, i, o, q, call)
+                if addr:
+                    kept.append((view, want.copy(), addr))
+            for view, want, addr in kept:   # later calls did not touch earlier blocks
+                assert np.array_equal(view, want)
+                speexhip.Resampler.release_block(addr)
+            a.close()
+            b.close()
+    # the blocks come out of one slab (64 MiB): a caller that keeps them all is told NO_BLOCK with the state untouched
+    ch, i, o, q = 2, 44100, 48000, 7
+    a, b = speexhip.Resampler(ch, i, o, q), speexhip.Resampler(ch, i, o, q)
+    x = orc.lcg_pcm((1 << 20) * ch, 9).reshape(1 << 20, ch)
+    held, refused = [], 0
+    for call in range(24):
+        try:
+            view, gu, addr = b.process_take(x, 1 << 21, keep=True)
+        except MemoryError:
+            refused += 1
+            got, gu = b.process(x, 1 << 21)          # what the N-API addon does then
+            view, addr = got, 0
+        want, wu = a.process(x, 1 << 21)
+        assert gu == wu and np.array_equal(view, want) and a.position() == b.position(), call
+        if addr:
+            held.append(addr)
+    assert refused > 0 and len(held) >= 8, (refused, len(held))   # ~4.6 MB per block: 13 fit in 64 MiB
+    for addr in held:
+        speexhip.Resampler.release_block(addr)
+    view, gu, addr = b.process_take(x, 1 << 21, keep=True)        # freed blocks merge back: room again
+    assert addr
+    speexhip.Resampler.release_block(addr)
+    a.close()
+    b.close()
+    # channels moved apart by a per-channel call, then the zero fallback: the ordinary path fills the block
+    ch, i, o, q = 2, 44100, 48000, 5
+    a, b = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT), speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT)
+    x = orc.lcg_pcm(5000 * ch, 1).reshape(5000, ch)
+    for r in (a, b):
+        assert r.channel_call("int", 1, x[:300, 1].copy(), 1000)[0] == 0
+    want, wu = a.process(x, 1 << 20)
+    got, gu = b.process_take(x, 1 << 20)
+    assert gu == wu and np.array_equal(got, want)
+    a.close()
+    b.close()
