@@ -230,6 +230,8 @@ DeviceTables::~DeviceTables() {
   pool::device_put(device, w16_rows);
   pool::device_put(device, slide_rows);
   pool::device_put(device, slide64_rows);
+  pool::device_put(device, pp_rows);
+  pool::device_put(device, pp_w16_rows);
   pool::device_put(device, period64_rows);
   pool::device_put(device, fine64_rows);
 }
@@ -307,6 +309,21 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
     build_period_rows(f, t->w16, &rows);
     rc = upload(&t->w16_rows, rows.data(), rows.size());
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  }
+  if (t->period.usable && period_wants_pp_plans(f, channels)) {
+    t->pp = plan_period(f, channels, kLdsBudget, false, false, true);
+    if (t->pp.usable) {
+      std::vector<float> rows;
+      build_period_rows(f, t->pp, &rows);
+      rc = upload(&t->pp_rows, rows.data(), rows.size());
+      if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+      t->pp_w16 = plan_period_w16(f, channels, kLdsBudget, t->pp);
+      if (t->pp_w16.usable) {
+        build_period_rows(f, t->pp_w16, &rows);
+        rc = upload(&t->pp_w16_rows, rows.data(), rows.size());
+        if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+      }
+    }
   }
   t->slide = plan_slide(f, channels);
   if (t->slide.usable && !t->period.usable) {
@@ -467,6 +484,8 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   d_slide_rows_ = tables->slide_rows;
   d_slide64_rows_ = tables->slide64_rows;
   d_period64_rows_ = tables->period64_rows;
+  d_period_pp_rows_ = tables->pp_rows;
+  d_period_pp_w16_rows_ = tables->pp_w16_rows;
   d_period64_fine_rows_ = tables->fine64_rows;
   const std::vector<float> no_table;
   filter_ = f;
@@ -482,6 +501,8 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   slide_ = tables->slide;
   slide64_ = tables->slide64;
   period64_ = tables->period64;
+  period_pp_ = tables->pp;
+  period_pp_w16_ = tables->pp_w16;
   period64_fine_ = tables->fine64;
   return SPEEXHIP_ERR_SUCCESS;
 }
@@ -940,6 +961,13 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
       e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, d_descs, packed ? &pack : nullptr,
                          n_streams_, float_io, stream);
+    } else if (fast && period_pp_.usable &&
+               period_launch_prefers_pp(filter_, (!float_io && !float_seen_ && period_w16_.usable) ? period_w16_ : period_, descs,
+                                        n_streams_)) {
+      // mono, wide windows: phase pairs (one period per lane, half the window per tile) where this launch gains
+      const bool w16 = !float_io && !float_seen_ && period_pp_w16_.usable;
+      e = launch_period(filter_, w16 ? period_pp_w16_ : period_pp_, w16 ? d_period_pp_w16_rows_ : d_period_pp_rows_, nullptr,
+                        nullptr, channels_, descs, d_descs, packed ? &pack : nullptr, n_streams_, float_io, stream);
     } else if (fast && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
                (w16_always() || period_launch_prefers_w16(filter_, period_, period_fine_.usable, descs, n_streams_)))
       // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- unless

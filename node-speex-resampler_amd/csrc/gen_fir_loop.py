@@ -348,6 +348,121 @@ struct FirLoopAsm64<%d, %d, %d, %s> {
         return pro + body + ["s_waitcnt lgkmcnt(0)"]
 
 
+class VariantPP(Variant):
+    """Phase pairs for single-channel lanes (round 4): a lane owns ONE period and 2R phases of it -- the two halves
+    of a packed FMA are two PHASES of one sample (tap pair from an aligned SGPR pair, the sample broadcast:
+    op_sel_hi picks its half for both lanes of the pack) where the CT = 1 variants above give the halves to two
+    PERIODS of one tap.  A tile is then 64 periods instead of 128: half the LDS window for the same lanes -- what the
+    wide windows of down-sampling ratios need (mono 48k -> 11.025k: 640 frames per period) -- at twice the tap bytes
+    per FMA.  Same SGPR homes as the fp32 scheme with 2S steps; a bank is S steps of 2R taps; the bank's samples sit
+    in the low halves of aligned VGPR pairs (one pair per step).  W16: an int16 window, converted behind the wait."""
+
+    def __init__(self, R, S, padded, w16):
+        Variant.__init__(self, R, 2 * S, 1, 1, padded, w16)
+        self.S = S
+        self.vbase = {10: 56, 5: 64}[R]
+        self.name = "PP_R%d_S%d_P%d_W%d" % (R, S, int(padded), int(w16))
+
+    def reg(self, k):           # step k (0 .. 2S-1) of a trip: the sample in the low half of v[reg : reg+1]
+        return self.vbase + 2 * k
+
+    def vgprs(self):
+        return list(range(self.vbase, self.vbase + 4 * self.S))
+
+    def fma_bank(self, which, lo, hi):
+        out = []
+        for u in range(self.S):
+            k = u if which == "A" else self.S + u
+            x = self.reg(k)
+            for i in range(lo, hi):
+                r = tap_reg(self.banks[which], (u * self.R + i) * 2)
+                assert r % 2 == 0
+                out.append("v_pk_fma_f32 %%[a%d], s[%d:%d], v[%d:%d], %%[a%d] op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (i, r, r + 1, x, x + 1, i))
+        return out
+
+    def sample_reads(self, which, first_step):
+        out = []
+        for u in range(self.S):
+            k = u if which == "A" else self.S + u
+            o = (first_step + u) * self.eb
+            out.append("ds_read_%s v%d, %%[addr] offset:%d" % ("i16" if self.w16 else "b32", self.reg(k), o))
+        return out
+
+    def converts(self, which):
+        if not self.w16:
+            return []
+        return ["v_cvt_f32_i32_e32 v%d, v%d" % (self.reg(k), self.reg(k)) for k in
+                ([u for u in range(self.S)] if which == "A" else [self.S + u for u in range(self.S)])]
+
+    def loop(self, label, cnt, lo, hi):
+        S, R = self.S, self.R
+        bank_bytes = 4 * S * 2 * R
+        adv = 2 * S * self.eb
+        body = ["s_sub_u32 %%[%s], %%[%s], 1" % (cnt, cnt), "s_cbranch_scc1 %d1f" % label, "%d0:" % label]
+        body += ["s_waitcnt lgkmcnt(0)"] + self.tap_loads("B", bank_bytes) + self.sample_reads("B", S)
+        body += self.converts("A") + self.fma_bank("A", lo, hi)
+        body += ["s_waitcnt lgkmcnt(0)"]
+        if self.padded:
+            body += ["s_sub_u32 %[wrap], %[wrap], 1", "s_cmp_eq_u32 %[wrap], 0",
+                     "s_cselect_b32 %[tmp], %[advpad], " + str(adv), "s_cselect_b32 %[wrap], %[wrapstep], %[wrap]",
+                     "v_add_u32 %[addr], %[tmp], %[addr]"]
+        else:
+            body += ["v_add_u32 %%[addr], %d, %%[addr]" % adv]
+        body += self.tap_loads("A", 2 * bank_bytes) + self.sample_reads("A", 0)
+        body += self.converts("B") + self.fma_bank("B", lo, hi)
+        body += ["s_add_u32 %%[off], %%[off], 0x%x" % (2 * bank_bytes), "s_sub_u32 %%[%s], %%[%s], 1" % (cnt, cnt),
+                 "s_cbranch_scc0 %d0b" % label, "%d1:" % label]
+        return body
+
+    def function(self):
+        R = self.R
+        asm = "\n".join('      "%s\\n"' % l for l in self.lines())
+        outs = ['[a%d] "+v"(acc[%d])' % (i, i) for i in range(R)] + ['[addr] "+v"(addr)']
+        outs += ['[off] "+s"(off)', '[main] "+s"(main)']
+        if R == 10:
+            outs += ['[head] "+s"(head)', '[tail] "+s"(tail)']
+        ins = ['[rows] "s"(rows_g)']
+        if self.padded:
+            outs += ['[wrap] "+s"(to_wrap)', '[tmp] "=&s"(tmp)']
+            ins += ['[advpad] "s"(adv_pad)', '[wrapstep] "s"(wrap_step)']
+        clob = ['"s%d"' % r for r in bank_regs(self.banks["A"]) + bank_regs(self.banks["B"])] + ['"v%d"' % r for r in self.vgprs()]
+        return '''template <>
+struct FirLoopAsmPP<%d, %s, %s> {
+  static constexpr bool available = true;
+  static constexpr int steps_per_bank = %d;
+  // as FirLoopAsm::run; acc[i] = phases 2i and 2i + 1 of the lane's period; rows_g: [trip][step][2R] floats
+  static __device__ __forceinline__ void run(f32x2 (&acc)[%d], const float *rows_g, uint32_t addr, uint32_t head, uint32_t main,
+                                             uint32_t tail, uint32_t to_wrap, uint32_t wrap_step, uint32_t adv_pad) {
+    uint32_t off = 0, tmp;
+    (void)tmp; (void)head; (void)tail; (void)to_wrap; (void)wrap_step; (void)adv_pad;
+    asm volatile(
+%s
+      : %s
+      : %s
+      : %s, "scc", "memory");
+  }
+};
+''' % (R, "true" if self.padded else "false", "true" if self.w16 else "false", self.S, R, asm,
+       ", ".join(outs), ", ".join(ins), ", ".join(clob))
+
+    def lines(self):
+        pro = self.tap_loads("A", 0) + self.sample_reads("A", 0)
+        if self.R == 10:
+            body = self.loop(1, "head", 0, 5) + self.loop(2, "main", 0, 10) + self.loop(3, "tail", 5, 10)
+        else:
+            body = self.loop(2, "main", 0, self.R)
+        return pro + body + ["s_waitcnt lgkmcnt(0)"]
+
+
+def variants_pp():
+    out = []
+    for w16 in (False, True):
+        for padded in (False, True):
+            out.append(VariantPP(10, 1, padded, w16))
+        out.append(VariantPP(5, R5_STEPS // 2, False, w16))
+    return out
+
+
 def variants64():
     out = []
     for CT, CF in ((2, 2), (2, 4), (2, 6), (2, 8), (1, 1)):
@@ -392,11 +507,22 @@ struct FirLoopAsm64 {
 '''
 
 
+HEADPP = '''
+// ---- phase pairs for single-channel lanes (round 4; gen_fir_loop.py, VariantPP) ----
+template <int R, bool PADDED, bool W16>
+struct FirLoopAsmPP {
+  static constexpr bool available = false;
+};
+
+'''
+
+
 def main():
-    src = HEAD + "\n".join(v.function() for v in variants()) + HEAD64 + "\n".join(v.function() for v in variants64())
+    src = (HEAD + "\n".join(v.function() for v in variants()) + HEAD64 + "\n".join(v.function() for v in variants64()) +
+           HEADPP + "\n".join(v.function() for v in variants_pp()))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fir_loop_asm.inc")
     open(path, "w").write(src)
-    print("wrote %s: %d + %d variants, %d lines" % (path, len(variants()), len(variants64()), src.count("\n")))
+    print("wrote %s: %d + %d + %d variants, %d lines" % (path, len(variants()), len(variants64()), len(variants_pp()), src.count("\n")))
 
 
 if __name__ == "__main__":

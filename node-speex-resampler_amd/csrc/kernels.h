@@ -70,11 +70,18 @@ struct PeriodPlan {         // per filter, fixed at init
                              // calls only; twice the periods per tile where the float window limits them
   bool a64 = false;          // fp64 accumulator (round 4): the tap rows are doubles, a loop trip is half as many steps,
                              // rows_floats counts doubles
+  bool pp = false;           // phase pairs (round 4; mono): a lane owns ONE period and 2r phases per group -- a tile is
+                             // 64 periods, not 128 (half the window), the rows are [step][2r]
   size_t rows_floats = 0, window_bytes = 0;
 };
-PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16 = false, bool a64 = false);
+PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16 = false, bool a64 = false,
+                       bool pp = false);
 PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16 = false,
-                         bool a64 = false);
+                         bool a64 = false, bool pp = false);
+// Does this mono filter get phase-pair plans beside its two-period ones (wide windows: num >= 320), and should THIS
+// launch run over them?  `two` = the two-period plan the launch would take otherwise (kernels_period.hip).
+bool period_wants_pp_plans(const FilterSpec &f, uint32_t channels);
+bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const StreamDesc *h_descs, uint32_t n_streams);
 // The int16-window plan of a filter whose float plan is `t`, .usable only where it pays: at least 5/4 of the
 // periods per tile (the loop converts every sample it reads: ~20 % more vector instructions per tile).
 PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_budget, const PeriodPlan &t);

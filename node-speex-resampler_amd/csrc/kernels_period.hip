@@ -6,6 +6,9 @@ namespace speexhip {
 // the fp64-accumulate instances (kernels_period64.hip): launch the one of plan `t`'s layout
 hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack,
                              dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
+// the phase-pair instances for mono (kernels_period_pp.hip)
+hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack,
+                              dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
 namespace {
 
 const size_t kSlack = 16;  // floats: window starts on the input's 16-byte grid, staged by 8
@@ -25,12 +28,19 @@ uint32_t default_r(const FilterSpec &f) {
   if (forced == 5 || forced == 10) return forced;
   return (f.den + 9) / 10 <= 8 ? 5u : 10u;
 }
+// ... of a phase-pair plan: a group is 2r phases, so the same reasoning puts the line at den <= 160
+uint32_t default_r_pp(const FilterSpec &f) {
+  const char *e = std::getenv("SPEEXHIP_R");
+  const uint32_t forced = e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
+  if (forced == 5 || forced == 10) return forced;
+  return (f.den + 19) / 20 <= 8 ? 5u : 10u;
+}
 
 }  // namespace
 
-PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16, bool a64) {
-  PeriodPlan t = plan_period_r(f, channels, lds_budget, default_r(f), w16, a64);
-  if (!t.usable && t.r != 10) t = plan_period_r(f, channels, lds_budget, 10, w16, a64);
+PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16, bool a64, bool pp) {
+  PeriodPlan t = plan_period_r(f, channels, lds_budget, pp ? default_r_pp(f) : default_r(f), w16, a64, pp);
+  if (!t.usable && t.r != 10) t = plan_period_r(f, channels, lds_budget, 10, w16, a64, pp);
   return t;
 }
 
@@ -38,7 +48,7 @@ PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_bu
   PeriodPlan w;
   static const bool off = std::getenv("SPEEXHIP_NO_W16") != nullptr;  // diagnostics: A/B
   if (!t.usable || off) return w;
-  w = plan_period_r(f, channels, lds_budget, t.r, true);
+  w = plan_period_r(f, channels, lds_budget, t.r, true, false, t.pp);
   static const bool force = std::getenv("SPEEXHIP_FORCE_W16") != nullptr;  // diagnostics: every layout that has one
   // What the int16 window costs is two conversions per sample read: +20 % vector instructions where a read
   // feeds 10 packed FMAs (R = 10, channel pairs), +40 % at R = 5, and single-channel lanes convert two
@@ -47,34 +57,45 @@ PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_bu
   // mono 48k->11.025k 58 -> 116: 289 -> 197; but stereo 44.1k->8k (R = 5) 41 -> 64 only 304 -> 272 and mono
   // 44.1k->16k 86 -> 128 nothing (196 -> 198).  So: 5/4 of the periods for R = 10 on channel pairs, 7/4 otherwise.
   const bool cheap = t.r == 10 && t.ct == 2;
-  if (w.usable && !force && 4 * w.lane_periods < (cheap ? 5 : 7) * t.lane_periods) w.usable = false;
+  // (phase pairs: a tile is 64 periods either way; what the int16 window buys there is a second and third workgroup
+  //  per CU -- taken when the float window leaves room for one only)
+  const bool pp_fits_more = t.pp && w.usable && t.window_bytes > 80 * 1024 && w.window_bytes <= 80 * 1024;
+  if (w.usable && !force && !pp_fits_more && 4 * w.lane_periods < (cheap ? 5 : 7) * t.lane_periods) w.usable = false;
   return w;
 }
 
 // w16: plan for an int16 LDS window (2-byte elements; pad, half_offset ... count elements either way)
-PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16, bool a64) {
+PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16, bool a64, bool pp) {
   PeriodPlan t;
   t.r = r;
   t.w16 = w16;
   t.a64 = a64;
   const size_t eb = w16 ? 2 : 4;  // bytes per LDS element
-  // steps per loop iteration (two banks); the fp64 loop's banks hold half as many taps (doubles in the same SGPRs)
-  const uint32_t it_steps = 2 * bank_taps(t.r) / t.r / (a64 ? 2 : 1);
+  // Phase pairs for mono (round 4): the two halves of a packed FMA are two phases of one sample instead of two
+  // periods of one tap, so a tile is 64 periods instead of 128 -- half the window for the same lanes (wide windows:
+  // mono 48k -> 11.025k has 640 frames per period) -- at twice the tap bytes per FMA and half the FMAs between two
+  // waits of the loop.  Planned beside the two-period plans for wide windows; chosen per launch
+  // (period_launch_prefers_pp).
+  t.pp = pp && !a64 && channels == 1;
+  // steps per loop iteration (two banks); the fp64 loop's banks hold half as many taps (doubles in the same SGPRs),
+  // and so do the phase-pair loop's (two phases per packed FMA)
+  const uint32_t it_steps = 2 * bank_taps(t.r) / t.r / ((a64 || t.pp) ? 2 : 1);
+  const uint32_t gw = t.pp ? 2 * t.r : t.r;  // phases per group
   t.ct = (channels % 2 == 0) ? 2 : 1;
   t.cgroups = channels / t.ct;
-  t.groups = (f.den + t.r - 1) / t.r;
+  t.groups = (f.den + gw - 1) / gw;
   uint32_t dmax = 0;  // largest shift of a row inside its group
   for (uint32_t g = 0; g < t.groups; g++) {
-    const uint64_t d0 = (static_cast<uint64_t>(g) * t.r * f.num) / f.den;
-    const uint32_t r_last = std::min<uint32_t>(g * t.r + t.r - 1, f.den - 1);
+    const uint64_t d0 = (static_cast<uint64_t>(g) * gw * f.num) / f.den;
+    const uint32_t r_last = std::min<uint32_t>(g * gw + gw - 1, f.den - 1);
     dmax = std::max<uint32_t>(dmax, static_cast<uint32_t>((static_cast<uint64_t>(r_last) * f.num) / f.den - d0));
   }
   t.row_len = (f.taps + dmax + it_steps - 1) / it_steps * it_steps;
   t.l4 = t.row_len / it_steps;
-  t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * t.r * f.num) / f.den) + t.row_len;
+  t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * gw * f.num) / f.den) + t.row_len;
   t.lane_periods = 64 / t.cgroups;  // revised below once the window size is known
   // + one iteration (40 floats) of zero padding: the tap pipeline prefetches one past the end
-  t.rows_floats = static_cast<size_t>(t.groups) * t.row_len * t.r + it_steps * t.r;
+  t.rows_floats = static_cast<size_t>(t.groups) * t.row_len * gw + it_steps * gw;
   // Bank padding: the lanes of a wave read the window num*channels floats apart.  Pick the pad
   // (multiple of 4 floats, inserted after every period) with the fewest lanes of a half-wave on
   // the same bank (ds_read_b32) / bank pair (ds_read_b64); 1 = conflict-free.  (Measured on
@@ -118,7 +139,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
     const uint32_t row_len = (f.taps + dmax + 3 + 3) / 4 * 4;
     bool ok = true;
     for (uint32_t g = 0; g < t.groups && ok; g++) {
-      const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
+      const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * gw * f.num) / f.den);
       if (dg + row_len + 4 <= f.num) continue;                 // never reaches the boundary
       const uint32_t k = (dg % 4 + 4 - f.num % 4) % 4;  // delta' = dg - k == num (mod 4)
       ok = dg >= k && ((dg - k) + row_len + 4 <= 2 * f.num || f.num % 4 == 0);
@@ -126,8 +147,8 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
     if (ok) {
       t.row_len = row_len;
       t.l4 = row_len / it_steps;  // (it_steps: 4, or 2 with an fp64 accumulator; the boundary tables count 4-step units)
-      t.rows_floats = static_cast<size_t>(t.groups) * t.row_len * t.r + it_steps * t.r;
-      t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * t.r * f.num) / f.den) + t.row_len;
+      t.rows_floats = static_cast<size_t>(t.groups) * t.row_len * gw + it_steps * gw;
+      t.tail_frames = static_cast<uint32_t>((static_cast<uint64_t>(t.groups - 1) * gw * f.num) / f.den) + t.row_len;
     } else {
       t.pad = 0;
     }
@@ -137,7 +158,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   auto window_bytes_for = [&](uint32_t lane_periods) {
     // (single-channel lanes read their second period at pl + ceil(periods/2): an odd tile still
     //  reads -- and discards -- one period past its last, so size the image for an even count)
-    if (t.ct == 1) lane_periods = (lane_periods + 1) / 2 * 2;
+    if (t.ct == 1 && !t.pp) lane_periods = (lane_periods + 1) / 2 * 2;
     const size_t pad_floats = static_cast<size_t>(t.pad) * (lane_periods + t.tail_frames / f.num + 2);
     size_t bytes = (((static_cast<size_t>(lane_periods) - 1) * f.num + t.tail_frames + it_steps) * channels + pad_floats) * eb +
                    kSlack * eb;
@@ -149,7 +170,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // periods, stereo 48k->44.1k 225 -> 190 us with 62 of 64).  Otherwise weigh a second workgroup
   // (~20 %) against the lanes it costs.
   // (single-channel lanes carry two periods each, see lane_ctx)
-  const uint32_t full = 64 / t.cgroups * (t.ct == 1 ? 2 : 1);
+  const uint32_t full = 64 / t.cgroups * ((t.ct == 1 && !t.pp) ? 2 : 1);
   const size_t half_lds = 80 * 1024;
   uint32_t fit_half = 0, fit_all = 0;
   for (uint32_t lp = full; lp >= 1; lp--) {
@@ -171,13 +192,14 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // tap rows of an fp64 accumulator
   if ((w16 || a64) && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1))) t.usable = false;
   if (a64 && w16) t.usable = false;
+  if (t.pp && t.pad != 0 && t.r != 10) t.usable = false;
   return t;
 }
 
 // Start-of-group adjustment for a padded window: k frames early so that (num - delta') % 4 == 0
 static uint32_t group_shift(const FilterSpec &f, const PeriodPlan &t, uint32_t g) {
   if (t.pad == 0) return 0;
-  const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
+  const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * (t.pp ? 2 * t.r : t.r) * f.num) / f.den);
   if (dg + t.row_len + 4 <= f.num) return 0;  // this group never reaches the period boundary
   return (dg % 4 + 4 - f.num % 4) % 4;
 }
@@ -206,9 +228,10 @@ void build_period_rows_t(const FilterSpec &f, const PeriodPlan &t, std::vector<E
   //   wrap[g]   = iteration before which the window pointer skips the bank padding (~0u: never)
   //   trips[g]  = head | tail << 4 | iterations << 8 (fir_group): iterations of the group's loop, of which the
   //               first `head` touch only rows 0..R/2-1 and the last `tail` only rows R/2..R-1
-  const uint32_t it_steps = 2 * bank_taps(t.r) / t.r / (t.a64 ? 2 : 1);
+  const uint32_t it_steps = 2 * bank_taps(t.r) / t.r / ((t.a64 || t.pp) ? 2 : 1);
+  const uint32_t gw = t.pp ? 2 * t.r : t.r;  // phases per group (phase pairs: two per accumulator)
   for (uint32_t g = 0; g < t.groups; g++) {
-    const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * t.r * f.num) / f.den);
+    const uint32_t dg = static_cast<uint32_t>((static_cast<uint64_t>(g) * gw * f.num) / f.den);
     const uint32_t k = group_shift(f, t, g);
     const uint32_t delta = dg - k;
     uint32_t wrap = 0xffffffffu;
@@ -219,21 +242,21 @@ void build_period_rows_t(const FilterSpec &f, const PeriodPlan &t, std::vector<E
   static const bool no_trim = std::getenv("SPEEXHIP_NO_TRIM") != nullptr;  // diagnostics: A/B of the trimming
   std::vector<double> h(f.taps);
   for (uint32_t g = 0; g < t.groups; g++) {
-    const uint64_t d0 = (static_cast<uint64_t>(g) * t.r * f.num) / f.den - group_shift(f, t, g);
+    const uint64_t d0 = (static_cast<uint64_t>(g) * gw * f.num) / f.den - group_shift(f, t, g);
     // iterations in which each half of the rows has a non-zero tap: [first, last]
     uint32_t first[2] = {0xffffffffu, 0xffffffffu}, last[2] = {0, 0};
-    for (uint32_t i = 0; i < t.r; i++) {
-      const uint32_t r = g * t.r + i;
+    for (uint32_t i = 0; i < gw; i++) {
+      const uint32_t r = g * gw + i;
       if (r >= f.den) continue;  // padding phases of the last group stay zero
       const uint32_t phase = static_cast<uint32_t>((static_cast<uint64_t>(r) * f.num) % f.den);
       const uint32_t shift = static_cast<uint32_t>((static_cast<uint64_t>(r) * f.num) / f.den - d0);
-      const uint32_t half = (t.r == 10 && i >= t.r / 2) ? 1 : 0;
+      const uint32_t half = (t.r == 10 && i >= gw / 2) ? 1 : 0;
       first[half] = std::min(first[half], shift / it_steps);
       last[half] = std::max(last[half], (shift + f.taps - 1) / it_steps);
       phase_taps(f, phase, h.data());
       for (uint32_t j = 0; j < f.taps; j++) {
         const uint32_t s = j + shift;
-        (*rows)[(static_cast<size_t>(g) * t.row_len + s) * t.r + i] = static_cast<E>(h[j]);
+        (*rows)[(static_cast<size_t>(g) * t.row_len + s) * gw + i] = static_cast<E>(h[j]);
       }
     }
     uint32_t total = std::max(last[0], last[1]) + 1, head = 0, tail = 0;
@@ -300,6 +323,34 @@ bool period_launch_prefers_w16(const FilterSpec &f, const PeriodPlan &t, bool ha
   if (split_count(t, tiles, n_streams, 2 * device_compute_units()) == 1) return true;
   const uint64_t T = static_cast<uint64_t>(tiles) * n_streams;
   return (T >= 48 && !has_fine) || (n_streams >= 4 && T >= 32);
+}
+
+// Phase pairs (mono; plan_period_r, FirLoopAsmPP) against two-period lanes, same box, profiles/r04_pp_ab.txt and
+// r04_pp_ab2.txt (launch us, two-period -> phase pairs):
+//   32 streams x 131 072 frames: 48k->11.025k 57.0 -> 43.1, 48k->22.05k 44.5 -> 35.7, 44.1k->32k 46.2 -> 31.9,
+//     44.1k->8k 50.3 -> 32.2, 44.1k->16k 42.6 -> 29.2, 32k->44.1k 48.0 -> 42.1, 96k->44.1k q5 33.9 -> 27.8;
+//     8 streams: 21.8 -> 18.5, 23.2 -> 12.9, 19.1 -> 16.1, 18.8 -> 12.7, 18.4 -> 12.0, 25.1 -> 19.3, 20.1 -> 11.9;
+//   32 streams x 2^20 frames: 44.1k->32k 210.5 -> 160.6 and 44.1k->16k 189.6 -> 142.5 (two-period tiles fill 86 of 128
+//     lane slots there), 44.1k->8k 165.5 -> 165.2, but 48k->22.05k 195.4 -> 216.5, 96k->44.1k 144.3 -> 161.6 and
+//     48k->11.025k (int16 window, 116 periods) 179.5 -> 326.7: a phase-pair loop has 10 packed FMAs between two waits,
+//     not 20, and twice the tap bytes (tools/ubench_pair.hip: 105 against 120 TF at full occupancy);
+//   one stream: -15 % ... +18 %, no pattern; narrow windows (44.1k->48k, 48k->44.1k): two-period lanes 10-45 % ahead.
+// Hence: plans for wide windows only (num >= 320: 128 periods of two-period lanes cannot share a CU with a second
+// workgroup), and a launch takes them when it is a batch that two-period tiles leave at most one per CU, or a launch
+// of several generations whose two-period plan fills under three quarters of its lane slots.  SPEEXHIP_PP=0 / 1:
+// never / whenever planned.
+bool period_wants_pp_plans(const FilterSpec &f, uint32_t channels) {
+  static const int env_pp = std::getenv("SPEEXHIP_PP") ? std::atoi(std::getenv("SPEEXHIP_PP")) : -1;
+  if (channels != 1 || env_pp == 0) return false;
+  return env_pp == 1 || static_cast<size_t>(f.num) * 4 * 128 >= 160 * 1024;
+}
+bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const StreamDesc *h_descs, uint32_t n_streams) {
+  static const int env_pp = std::getenv("SPEEXHIP_PP") ? std::atoi(std::getenv("SPEEXHIP_PP")) : -1;
+  if (env_pp >= 0) return env_pp != 0;
+  const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
+  const uint64_t tiles = static_cast<uint64_t>((max_periods + two.lane_periods - 1) / two.lane_periods) * n_streams;
+  if (tiles <= device_compute_units()) return n_streams >= 2;  // (one stream: -15 % ... +18 %, no pattern: two-period stays)
+  return 4 * two.lane_periods < 3 * 128;                       // several generations: only where lanes go unused
 }
 
 // `fine` (may be null / unusable): the same filter planned with R = 5.  A launch that is a single
@@ -410,7 +461,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   p.wave_groups = wave_groups;
   p.tail_frames = t.tail_frames;
   p.pad = t.pad;
-  p.half_periods = t.ct == 1 ? (t.lane_periods + 1) / 2 : 0;
+  p.half_periods = (t.ct == 1 && !t.pp) ? (t.lane_periods + 1) / 2 : 0;
   p.half_offset = p.half_periods * (f.num * channels + t.pad);
   p.wrap_step = f.num % 4 == 0 ? f.num / 4 : 0x40000000u;
   p.period_magic = period_magic_of(f.num * channels);
@@ -485,6 +536,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // (an int16 window -- t.w16 -- exists for int16 calls on the layouts the ISA loop is generated for: ONE or CGV)
   if (t.w16 && float_io) return hipErrorInvalidValue;
   if (t.a64) return dispatch_period64(t, p, d_descs, pack, grid, threads, float_io, stream);  // kernels_period64.hip
+  if (t.pp) return dispatch_period_pp(t, p, d_descs, pack, grid, threads, float_io, stream);   // kernels_period_pp.hip
   // (LRC: the kernel of the layout, or its tap-range-shares twin)
 #define SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, W)                                                                                    \
   (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, true>(p, d_descs, pack, grid, threads, t.window_bytes, stream)              \

@@ -112,7 +112,7 @@ struct LaneCtx {
   uint64_t K_lane;  // canonical output index of the lane's period, phase 0
 };
 
-template <int CT, bool ONE_GROUP, bool PADDED, int CGF = 0>
+template <int CT, bool ONE_GROUP, bool PADDED, int CGF = 0, bool PP = false>
 __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshift, uint32_t m_lo,
                                             uint32_t m_cnt, uint32_t lane) {
   // ONE_GROUP: the frame is exactly one channel group (mono, stereo): the sample stride is a
@@ -128,9 +128,10 @@ __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshi
   const uint32_t pl = ONE_GROUP ? lane : lane / cgroups;  // period of this lane inside the tile
   // CT == 1 (odd channel counts): a packed FMA has no second channel to work on, so the lane takes
   // a second PERIOD instead, half a tile further (p.half_periods): .x = period pl, .y = pl + half.
-  const uint32_t lane_max = CT == 1 ? p.half_periods : p.lane_periods;
+  // (PP -- phase pairs, round 4: a single-channel lane with ONE period and 2R phases of it; FirLoopAsmPP)
+  const uint32_t lane_max = (CT == 1 && !PP) ? p.half_periods : p.lane_periods;
   c.live = pl < lane_max && pl < m_cnt;
-  c.live_b = CT == 1 && pl < lane_max && pl + p.half_periods < m_cnt;
+  c.live_b = CT == 1 && !PP && pl < lane_max && pl + p.half_periods < m_cnt;
   // PADDED: the LDS image carries p.pad floats after every period (num frames) so that the
   // lanes of a wave -- num*C floats apart, a multiple of the bank count for e.g. 8 channels at
   // num = 160 -- hit distinct banks; the per-step offset is then wave-uniform scalar arithmetic.
@@ -486,6 +487,114 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
   }
 }
 
+// Phase pairs (round 4; FirLoopAsmPP): single-channel lanes with one period and 2R phases -- acc[i] = phases 2i, 2i + 1
+// of group g.  rows: [group][trip][step][2R] floats; trips of 2 * steps_per_bank steps (2 for R = 10, 6 for R = 5).
+// part / parts: tap-range shares (fir_tile_parts): this wave runs trips [total*part/parts, total*(part+1)/parts).
+template <int R, bool PADDED, bool W16>
+__device__ __forceinline__ void fir_group_pp(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
+                                             const LaneCtx &c, uint32_t g, bool skip_all, uint32_t part, uint32_t parts,
+                                             f32x2 (&acc)[R]) {
+  using Isa = FirLoopAsmPP<R, PADDED, W16>;
+  static_assert(Isa::available, "phase pairs run their ISA loop");
+  constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
+  constexpr uint32_t kPerIt = 4 / kStepsPerTrip;  // (the padded plan's boundary tables count 4-step iterations)
+  constexpr uint32_t EB = W16 ? 2u : 4u;
+  auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+  const uint32_t delta_g = p.delta[g];
+  const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+  const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u, total = trips >> 8;
+  const uint32_t t0 = sgpr(total * part / parts), t1 = sgpr(total * (part + 1) / parts);
+  auto overlap = [&](uint32_t lo, uint32_t hi) {
+    const uint32_t a = max(t0, lo), b = min(t1, hi);
+    return b > a ? b - a : 0u;
+  };
+  const uint32_t main_end = total - tail;
+  uint32_t wraps = 0, to_wrap = 0;
+  const uint32_t wrap_step = p.wrap_step * kPerIt;
+  if constexpr (PADDED) {
+    const uint32_t to_wrap0 = p.delta[p.groups + g] * kPerIt;
+    to_wrap = to_wrap0;
+    if (to_wrap0 != 0 && t0 >= to_wrap0) {
+      const uint32_t past = t0 - to_wrap0;
+      wraps = 1 + past / wrap_step;
+      to_wrap = wrap_step - past % wrap_step;
+    } else if (to_wrap0 != 0) {
+      to_wrap = to_wrap0 - t0;
+    }
+  }
+  const float *rows_g = rows + (static_cast<size_t>(g) * p.l4 + t0) * (kStepsPerTrip * 2 * R);
+  const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) +
+                        ((c.xlane + delta_g) + t0 * kStepsPerTrip + wraps * p.pad) * EB;
+  const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
+  const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
+                                                        static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
+  Isa::run(acc, rows_s, addr, sgpr(overlap(0, head)), sgpr(overlap(head, main_end)), sgpr(overlap(main_end, total)), sgpr(to_wrap),
+           sgpr(wrap_step), sgpr((kStepsPerTrip + p.pad) * EB));
+}
+
+// ... and its stores: the lane's 2R phases of group g are 2R consecutive samples of a mono stream -- whole dwords
+// around at most two odd samples (the run may start on the upper half of a dword: k_shift odd, an odd den), float
+// runs as 16-byte pieces; a run cut by the call's ends or the last group's padding phases goes sample by sample.
+template <int R, typename T>
+__device__ __forceinline__ void store_group_pp(const PeriodParams &p, const StreamDesc &d, const LaneCtx &c, uint32_t g,
+                                               const f32x2 (&acc)[R]) {
+  constexpr int N = 2 * R;
+  const int64_t k0 = static_cast<int64_t>(c.K_lane) + static_cast<int64_t>(g) * N - d.k_shift;
+  const int64_t lo64 = k0 < 0 ? -k0 : 0;
+  const int64_t hi64 = min(static_cast<int64_t>(N), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * N,
+                                                       static_cast<int64_t>(d.n_out) - k0));
+  G<T> *o = out_ptr<T>(d) + k0;
+  if constexpr (sizeof(T) == 2) {
+    if (lo64 == 0 && hi64 == N && (reinterpret_cast<uintptr_t>(d.out) & 1u) == 0) {
+      g_u32 *od;
+      if ((reinterpret_cast<uintptr_t>(o) & 2u) == 0) {
+        uint32_t w[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) w[i] = round_pack_pcm(acc[i].x, acc[i].y);
+        od = (g_u32 *)o;
+#pragma unroll
+        for (int j = 0; j + 4 <= R; j += 4) *(g_u32x4_a4 *)(od + j) = u32x4_a4{w[j], w[j + 1], w[j + 2], w[j + 3]};
+        if constexpr (R % 4 >= 2) *(g_u32x2_a4 *)(od + R / 4 * 4) = u32x2_a4{w[R / 4 * 4], w[R / 4 * 4 + 1]};
+        if constexpr (R % 2 != 0) od[R - 1] = w[R - 1];
+      } else {
+        // the run starts on the upper half of a dword: sample 0, the R - 1 dwords that straddle the pairs, sample N - 1
+        o[0] = static_cast<int16_t>(round_pack_pcm(acc[0].x, 0.f) & 0xffffu);
+        uint32_t w[R - 1];
+#pragma unroll
+        for (int i = 0; i + 1 < R; i++) w[i] = round_pack_pcm(acc[i].y, acc[i + 1].x);
+        od = (g_u32 *)(o + 1);
+#pragma unroll
+        for (int j = 0; j + 4 <= R - 1; j += 4) *(g_u32x4_a4 *)(od + j) = u32x4_a4{w[j], w[j + 1], w[j + 2], w[j + 3]};
+        if constexpr ((R - 1) % 4 >= 2) *(g_u32x2_a4 *)(od + (R - 1) / 4 * 4) = u32x2_a4{w[(R - 1) / 4 * 4], w[(R - 1) / 4 * 4 + 1]};
+        if constexpr ((R - 1) % 2 != 0) od[R - 2] = w[R - 2];
+        o[N - 1] = static_cast<int16_t>(round_pack_pcm(acc[R - 1].y, 0.f) & 0xffffu);
+      }
+      return;
+    }
+  } else {
+    if (lo64 == 0 && hi64 == N) {
+      G<float> *of = (G<float> *)o;
+#pragma unroll
+      for (int i = 0; i + 1 < R; i += 2) {
+        float a0 = acc[i].x, a1 = acc[i].y, a2 = acc[i + 1].x, a3 = acc[i + 1].y;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));  // (opaque copies, as for the stereo float stores)
+        *(G<f32x4_a4> *)(of + 2 * i) = f32x4_a4{a0, a1, a2, a3};
+      }
+      if constexpr (R % 2 != 0) *(G<f32x2_a4> *)(of + 2 * (R - 1)) = f32x2_a4{acc[R - 1].x, acc[R - 1].y};
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    if (i < lo64 || i >= hi64) continue;
+    const float v = (i & 1) ? acc[i / 2].y : acc[i / 2].x;
+    if constexpr (sizeof(T) == 4)
+      o[i] = v;
+    else
+      o[i] = static_cast<int16_t>(round_pack_pcm(v, 0.f) & 0xffffu);
+  }
+}
+
 // The kernel's parameters and the workgroup's descriptor as they lie in memory (the kernel-argument segment; the
 // descriptor ring for large batches), in the constant address space: what is read through these comes by scalar
 // loads.  The ISA loop names 40 tap SGPRs; with the parameters and the descriptor held in registers across it
@@ -522,7 +631,9 @@ struct KernArgs {  // layout of resample_period's kernel arguments
 
 // FIR of one tile (m_cnt periods starting at m_lo) for the phase groups owned by this wave,
 // followed by round / interleave / store.  `zsplit` of `nsplit` workgroups share the tile's groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool A64 = false>
+// AM: arithmetic of the FIR loop -- 0 = fp32 chain (FirLoopAsm or the C++ loop), 1 = fp64 accumulator (FirLoopAsm64),
+// 2 = phase pairs for single-channel lanes (FirLoopAsmPP)
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, int AM = 0>
 __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDesc &d0, KParams pp,
                                          const float *__restrict__ rows, KDesc dp, const float *xs, uint32_t xshift,
                                          uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit,
@@ -530,9 +641,9 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
   // (layouts that run the C++ loop keep the copies the kernel already holds: re-reading them there only added
   //  register pressure -- scratch in every such instance)
 #ifndef SPEEXHIP_CXX_FIR_LOOP
-  constexpr bool kReload = A64 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available;
+  constexpr bool kReload = AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available;
 #else
-  constexpr bool kReload = A64;
+  constexpr bool kReload = AM != 0;
 #endif
   auto params = [&]() -> PeriodParams {
     if constexpr (kReload) return load_k(pp);
@@ -542,7 +653,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
   //  further group on the copy read behind the previous one's loop: a read in FRONT of the first loop as well put
   //  a scalar-load round trip between the staging barrier and the FIR of every workgroup, ~0.2 us that a
   //  one-generation launch cannot hide)
-  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p0, xshift, m_lo, m_cnt, lane);
+  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED, CGF, AM == 2>(p0, xshift, m_lo, m_cnt, lane);
   const uint32_t g_step = p0.wave_groups * nsplit;
   uint32_t g = zsplit * p0.wave_groups + wave;
   if (g >= p0.groups) return;
@@ -554,7 +665,9 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
 #ifdef SPEEXHIP_STAMPS
     const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime(), fir_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if constexpr (A64) {
+    if constexpr (AM == 2) {
+      fir_group_pp<R, PADDED, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, 0u, 1u, acc);
+    } else if constexpr (AM == 1) {
       // fp64 sums, then the reference's store of its double sum into a float (resample.c:417, :544)
       double acc64[R][2];
 #pragma unroll
@@ -587,7 +700,10 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
       else
         d = d0;
       if (q.prio & 2u) __builtin_amdgcn_s_setprio(2);
-      store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
+      if constexpr (AM == 2)
+        store_group_pp<R, T>(q, d, c, g, acc);
+      else
+        store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
       if (q.prio & 2u) set_fir_priority(q);
       STAMP(6);
     }
@@ -650,7 +766,7 @@ __device__ __forceinline__ void fir_group_part(const PeriodParams &p, const floa
 
 // One group per wave-set (the host launches tap-range shares only when a share's groups fit its waves:
 // the partial sums overwrite the window).  Wave w: group w % wave_groups of the share, part w / wave_groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool PP = false>
 __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restrict__ rows, KDesc dp, float *xs,
                                                uint32_t xshift, uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
                                                uint32_t zsplit) {
@@ -663,7 +779,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
   for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
   {
     const PeriodParams p = load_k(pp);
-    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p, xshift, m_lo, m_cnt, lane);
+    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF, PP>(p, xshift, m_lo, m_cnt, lane);
     wg = p.wave_groups;
     parts = p.ksplit;
     part = 0;
@@ -674,7 +790,11 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
     }
     g = zsplit * wg + gw;
     valid = g < p.groups;
-    if (valid) fir_group_part<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, part, parts, acc);
+    if constexpr (PP) {
+      if (valid) fir_group_pp<R, PADDED, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, part, parts, acc);
+    } else {
+      if (valid) fir_group_part<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, part, parts, acc);
+    }
   }
   __syncthreads();  // every wave is done with the window
   // partial sums of part j >= 1, group-wave gw: block (j - 1) * wg + gw of R x 64 pairs, lanes side by side
@@ -694,7 +814,10 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
   const PeriodParams q = load_k(pp);
   if ((q.skip & 8u) || !c.live) return;
   const StreamDesc d = load_k(dp);
-  store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
+  if constexpr (PP)
+    store_group_pp<R, T>(q, d, c, g, acc);
+  else
+    store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
 }
 
 // (Mono int16 left through an LDS image -- one row per period, whole rows written 16 bytes per lane -- from
@@ -716,7 +839,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
 // Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
 // shares of its phase groups.
 template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T, int CGF = 0, bool W16 = false, bool KS = false,
-          bool A64 = false>
+          int AM = 0>
 __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
     PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
@@ -802,26 +925,26 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
     const __attribute__((address_space(4))) KernArgs *ka =
         (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
-    fir_tile_parts<R, CT, ONE_GROUP, PADDED, T, CGF, W16>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
-                                                         threadIdx.x & 63u, blockIdx.z);
+    fir_tile_parts<R, CT, ONE_GROUP, PADDED, T, CGF, W16, AM == 2>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
+                                                                  threadIdx.x & 63u, blockIdx.z);
     return;
   } else {
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
   const __attribute__((address_space(4))) KernArgs *ka =
       (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
   const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
-  fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF, W16, A64>(p, d, &ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
+  fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF, W16, AM>(p, d, &ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
                                                   threadIdx.x & 63u, blockIdx.z, gridDim.z);
   }
 }
 
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool KS = false, bool A64 = false>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool KS = false, int AM = 0>
 hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   constexpr bool kParts = false;
 #else
-  constexpr bool kParts = KS && FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available;
+  constexpr bool kParts = KS && (AM == 2 || (AM == 0 && FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available));
 #endif
   if constexpr (KS && !kParts) {  // (no ISA loop for this layout: the host never asks for tap-range shares of it)
     return hipErrorInvalidValue;
@@ -830,14 +953,14 @@ hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const Des
   if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
   static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
   if (pack != nullptr)
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS, A64>, seen_packed);
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS, AM>, seen_packed);
   else
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS, A64>, seen_ring);
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS, AM>, seen_ring);
   if (pack != nullptr)
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS, A64>), grid, dim3(threads), lds_bytes, stream,
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS, AM>), grid, dim3(threads), lds_bytes, stream,
                        p, p.rows, nullptr, *pack);
   else
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS, A64>), grid, dim3(threads), lds_bytes, stream,
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS, AM>), grid, dim3(threads), lds_bytes, stream,
                        p, p.rows, d_descs, empty);
   return hipGetLastError();
   }

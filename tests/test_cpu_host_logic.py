@@ -442,7 +442,8 @@ def test_generated_fir_loop_is_in_step_with_its_generator():
     spec.loader.exec_module(gen)
     committed = open(os.path.join(os.path.dirname(path), "fir_loop_asm.inc")).read()
     assert committed == (gen.HEAD + "\n".join(v.function() for v in gen.variants()) + gen.HEAD64 +
-                         "\n".join(v.function() for v in gen.variants64())), "run python csrc/gen_fir_loop.py"
+                         "\n".join(v.function() for v in gen.variants64()) + gen.HEADPP +
+                         "\n".join(v.function() for v in gen.variants_pp())), "run python csrc/gen_fir_loop.py"
     for v in gen.variants():
         lines = v.lines()
         loops = 3 if v.R == 10 else 1
@@ -479,3 +480,20 @@ def test_generated_fir_loop_is_in_step_with_its_generator():
                 assert m and int(m.group(1)) % 2 == 0 and int(m.group(3)) % 2 == 0, (v.name, l)
                 assert int(m.group(1)) in used and int(m.group(2)) in used, (v.name, l)
         assert max(v.vgprs()) < (64 if v.R == 10 else 128) and min(v.vgprs()) % 2 == 0, v.name
+    # the phase-pair variants (round 4, mono): one packed FMA per PAIR of phases, the tap pair in an aligned SGPR
+    # pair, the sample broadcast from the low half of an aligned VGPR pair; one sample read per step
+    assert len(gen.variants_pp()) == 6
+    for v in gen.variants_pp():
+        lines = v.lines()
+        loops = 3 if v.R == 10 else 1
+        rows = (5 + 10 + 5) if v.R == 10 else v.R
+        fmas = [l for l in lines if l.startswith("v_pk_fma_f32")]
+        assert len(fmas) == 2 * v.S * rows, v.name
+        assert all(l.endswith("op_sel:[0,0,0] op_sel_hi:[1,0,1]") for l in fmas), v.name
+        for l in fmas:
+            m = re.match(r"v_pk_fma_f32 %\[a\d+\], s\[(\d+):(\d+)\], v\[(\d+):(\d+)\]", l)
+            assert m and int(m.group(1)) % 2 == 0 and int(m.group(3)) % 2 == 0, (v.name, l)
+        assert sum(1 for l in lines if l.startswith("ds_read")) == (loops * 2 + 1) * v.S, v.name
+        assert sum(1 for l in lines if l.startswith("v_cvt")) == (loops * 2 * v.S if v.w16 else 0), v.name
+        assert sum(1 for l in lines if l == "s_waitcnt lgkmcnt(0)") == 2 * loops + 1, v.name
+        assert max(v.vgprs()) < (64 if v.R == 10 else 128), v.name

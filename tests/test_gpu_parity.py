@@ -1655,3 +1655,39 @@ def test_owned_block_calls_return_the_bytes_of_the_copying_calls():
     assert gu == wu and np.array_equal(got, want)
     a.close()
     b.close()
+
+
+def test_phase_pair_plans_for_mono_on_every_launch():
+    """Round 4: mono filters with wide windows (num >= 320) also get PHASE-PAIR plans -- a lane owns one period and two
+    phases per packed FMA (FirLoopAsmPP) instead of two periods, so a tile is 64 periods and half the window -- and a
+    launch takes them by a rule (period_launch_prefers_pp: batches that two-period tiles leave at most one per CU).
+    SPEEXHIP_PP=1 (read once per process) plans them for EVERY mono filter and runs every mono launch over them: the
+    mono cases of the golden, layout, tap-range-share, int16-window, packed-store and control tests, +-1 LSB."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEEXHIP_PP="1")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "(mono or every_golden_case or many_rates or window_layout_variants or edge_cases or tap_range_shares "
+                          "or int16_window_plan_serves or history_after or float_entry or control_scripts_fast or many_generation) "
+                          "and not phase_pair"],   # (not this test again)
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    # ... and by the rule: a batch of a wide-window decimator runs over them, one big stream does not; both match
+    import torch
+    ch, i, o, q, S, F = 1, 44100, 8000, 7, 8, 131072
+    b = speexhip.Batch(S, ch, i, o, q)
+    x = np.stack([orc.lcg_pcm(F * ch, 70 + s).reshape(F, ch) for s in range(S)])
+    d_in = torch.from_numpy(x).cuda()
+    cap = F * o // i + 64
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    for call in range(2):
+        used, made = b.process_device(d_in.data_ptr(), F * ch, F, d_out.data_ptr(), cap * ch, cap, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for s in (0, 3, 7):
+        ref = orc.Oracle(ch, i, o, q)
+        ref.process(x[s], cap)
+        want, wu = ref.process(x[s], cap)
+        assert used[s] == wu and made[s] == want.shape[0]
+        assert_close(out[s, : made[s]], want, "phase pairs by rule, stream %d" % s)
+    b.close()
