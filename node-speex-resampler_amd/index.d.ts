@@ -47,7 +47,12 @@ declare class SpeexResampler {
 
     constructor(channels: number, inRate: number, outRate: number, quality?: number);
 
-    /** interleaved s16le PCM in, resampled s16le PCM out */
+    /**
+     * interleaved s16le PCM in, resampled s16le PCM out: a fresh Buffer the caller owns, like the reference's.
+     * Results of 4 KB and more are external Buffers over pinned memory of the native library (no copy on the way
+     * out; the memory returns to the library when the Buffer is collected); an application that keeps more than
+     * 64 MiB of them alive (SPEEXHIP_TAKE_MB) gets ordinary copies beyond that.  SPEEXHIP_NAPI_COPY=1: copies always.
+     */
     processChunk(chunk: Buffer): Buffer;
 
     /** consecutive chunks in one GPU launch; result[i] equals processChunk(chunks[i]) */

@@ -8,7 +8,7 @@
 # and, AFTER the PMC passes (bench.py reads profiles/pmc_traffic.json), the bench lines of every
 # workload (parity block in each; cpu_baseline in the 1-stream ones)   -> r0N_bench_lines.jsonl
 # Results land in gpurun_out/prof_r0N/; copy the summaries into profiles/ by hand.
-N=${1:-03}
+N=${1:-04}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_r$N; rm -rf $O; mkdir -p $O; cd $R
 cd /tmp && export TMPDIR=/tmp
 for CFG in cfg2 cfg3 cfg4 f3; do
@@ -32,6 +32,12 @@ for S in 1 32; do
   ST=100; [ $S = 32 ] && ST=20
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg3exact_s$S -- python3 $R/bench.py --config cfg3 --mode exact --streams $S --steps $ST --warmup 5 --reps 3 --no-cpu-baseline --no-parity > $O/trace_cfg3exact_s$S.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg2float_s$S -- python3 $R/bench.py --io float --streams $S --steps $ST --warmup 5 --reps 3 --no-cpu-baseline --no-parity > $O/trace_cfg2float_s$S.log 2>&1
+done
+# round 4: configs[2] on the fp32 chain (MODE_FAST_F32) beside its fp64-accumulate default, and the period kernel's fp64 instances
+for S in 1 32; do
+  ST=100; [ $S = 32 ] && ST=20
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg3f32chain_s$S -- python3 $R/bench.py --config cfg3 --mode fast_f32 --streams $S --steps $ST --warmup 5 --reps 3 --no-cpu-baseline --no-parity > $O/trace_cfg3f32chain_s$S.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_q10period_s$S -- python3 $R/bench.py --custom 2,44100,48000,10 --streams $S --steps $ST --warmup 5 --reps 3 --no-cpu-baseline --no-parity > $O/trace_q10period_s$S.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg2exact_s1 -- python3 $R/bench.py --mode exact --steps 100 --warmup 5 --reps 3 --no-cpu-baseline --no-parity > $O/trace_cfg2exact_s1.log 2>&1
 cd $R
@@ -85,6 +91,10 @@ done
 python bench.py --mode exact --steps 200 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --config cfg3 --mode exact --steps 100 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --config cfg3 --mode exact --streams 32 --steps 20 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+for S in 1 32; do
+  python bench.py --config cfg3 --mode fast_f32 --streams $S --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+  python bench.py --custom 2,44100,48000,10 --streams $S --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+done
 python bench.py --io float --steps 300 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 python bench.py --io float --streams 32 --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 # mono (not a BASELINE config; the store path of round 3): 44.1k->48k q7, int16 and float
