@@ -366,6 +366,14 @@ SPEEXHIP_API int speexhip_resampler_get_channel_position(SpeexHipResamplerState 
 SPEEXHIP_API int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
                                      uint32_t out[8]);
 
+/* ... and the round-4 plans beside it: out[0] = 5 / 4 when FAST runs the configuration through the fp64-accumulate
+ * period / slide kernel (quality 9, 10: out[1] = phases per wave / periods per lane, out[2] = periods per tile,
+ * out[3] = row length, out[4] = LDS bytes, out[5] = bank padding / row stride, out[6] = trips per row, out[7] = tap
+ * steps per iteration of the slide kernel), 6 when the mono filter also has phase-pair plans (wide windows: same
+ * fields as the period plan, out[7] = periods per tile of their int16-window plan), 0 otherwise. */
+SPEEXHIP_API int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
+                                       uint32_t out[8]);
+
 /* Which kind of box is this?  Runs ~0.3 ms of packed fp32 FMAs with LDS reads on every CU and reports the shader
  * clock (GHz) the chip held meanwhile (median / slowest workgroup): the pool's boxes differ by 4-6 %, so bench
  * lines and the perf gate (tests/test_gpu_perf_gate.py) quote it.  Diagnostics; blocks the calling thread. */

@@ -262,6 +262,54 @@ int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uin
     return static_cast<int>(SPEEXHIP_ERR_SUCCESS);
   });
 }
+int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels, uint32_t out[8]) {
+  if (out == nullptr || channels == 0) return SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] {
+    speexhip::FilterSpec f;
+    const int rc = speexhip::design_filter_frac(ratio_num, ratio_den, ratio_num, ratio_den, quality, &f, false);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    std::memset(out, 0, 8 * sizeof(uint32_t));
+    const bool double_kind = f.kind == speexhip::kDirectDouble || f.kind == speexhip::kInterpolateDouble;
+    const speexhip::PeriodPlan base = speexhip::plan_period(f, channels, speexhip::lds_budget());
+    if (double_kind && base.usable) {
+      const speexhip::PeriodPlan t = speexhip::plan_period(f, channels, speexhip::lds_budget(), false, true);
+      if (t.usable) {
+        out[0] = 5;
+        out[1] = t.r;
+        out[2] = t.lane_periods;
+        out[3] = t.row_len;
+        out[4] = static_cast<uint32_t>(t.window_bytes);
+        out[5] = t.pad;
+        out[6] = t.l4;
+      }
+    } else if (double_kind && speexhip::plan_slide(f, channels).usable) {
+      const speexhip::SlidePlan sl = speexhip::plan_slide64(f, channels);
+      if (sl.usable) {
+        out[0] = 4;
+        out[1] = sl.p;
+        out[3] = sl.row_len;
+        out[4] = static_cast<uint32_t>(speexhip::slide_lds_bytes(sl, 2));
+        out[5] = sl.row_stride;
+        out[7] = sl.p * sl.num;
+      }
+    }
+    // phase-pair plans of mono filters with wide windows (any quality below 9)
+    if (!double_kind && base.usable && speexhip::period_wants_pp_plans(f, channels)) {
+      const speexhip::PeriodPlan t = speexhip::plan_period(f, channels, speexhip::lds_budget(), false, false, true);
+      if (t.usable) {
+        out[0] = 6;
+        out[1] = t.r;
+        out[2] = t.lane_periods;
+        out[3] = t.row_len;
+        out[4] = static_cast<uint32_t>(t.window_bytes);
+        out[5] = t.pad;
+        const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, speexhip::lds_budget(), t);
+        out[7] = w16.usable ? w16.lane_periods : 0;
+      }
+    }
+    return static_cast<int>(SPEEXHIP_ERR_SUCCESS);
+  });
+}
 void speexhip_debug_fail_device_allocs(int n) { speexhip::debug_fail_device_allocs(n); }
 uint64_t speexhip_release_cached_memory(void) {
   const uint64_t tables = speexhip::release_cached_tables();  // first: they return their buffers to the pool

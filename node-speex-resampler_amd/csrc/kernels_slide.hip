@@ -195,6 +195,9 @@ const Slide64Shape kShapes64[] = {
     {1, 1, 8}, {1, 2, 8}, {1, 3, 8}, {1, 4, 4}, {1, 5, 4}, {1, 6, 4}, {2, 1, 8}, {2, 3, 4}, {2, 5, 2}, {3, 1, 4},
     {3, 2, 4}, {3, 5, 2}, {4, 1, 4}, {4, 5, 1}, {5, 1, 4}, {5, 2, 2}, {5, 3, 2}, {5, 4, 1}, {5, 6, 1}, {6, 1, 2},
     {6, 5, 1}, {7, 1, 2}, {8, 1, 2}, {8, 3, 1}, {9, 1, 2}, {10, 1, 2}, {12, 1, 1}, {16, 1, 1}, {20, 1, 1}, {24, 1, 1},
+    // 7:2 and 9:2 (56k -> 16k, 72k -> 16k): odd channel counts only -- the fp32 kernel's phase-pair shapes of 7:1 and
+    // 9:1 cover den = 2 as well, and whatever the slide kernel runs has its fp64 twin
+    {7, 2, 2}, {9, 2, 1},
 };
 }  // namespace
 

@@ -381,6 +381,8 @@ hipError_t launch_slide64_shape(const SlidePlan &t, const SlideParams &p, const 
   SPEEXHIP_S64_CASE(1, 16, 1)
   SPEEXHIP_S64_CASE(1, 20, 1)
   SPEEXHIP_S64_CASE(1, 24, 1)
+  SPEEXHIP_S64_CASE(2, 7, 2)
+  SPEEXHIP_S64_CASE(1, 9, 2)
 #undef SPEEXHIP_S64_CASE
   return hipErrorInvalidValue;
 }

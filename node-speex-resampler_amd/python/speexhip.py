@@ -50,7 +50,7 @@ EXPORTS = [
     "speexhip_release_cached_memory", "speexhip_debug_plan",
     "speexhip_resampler_release_stream", "speexhip_batch_release_stream", "speexhip_debug_device_clock",
     "speexhip_resampler_process_interleaved_int_take", "speexhip_resampler_process_interleaved_float_take",
-    "speexhip_block_release",
+    "speexhip_block_release", "speexhip_debug_plan64",
 ]
 
 
@@ -236,6 +236,17 @@ def plan_call_ex(num, den, in_len, out_cap, float_entry, block_in, last, frac, m
     if rc != 0:
         raise ValueError(strerror(rc))
     return c.value, p.value, l.value, f.value, m.value
+
+
+def debug_plan64(ratio_num, ratio_den, quality, channels):
+    """the round-4 plans: fp64-accumulate kernels (fast_path 5 / 4) or phase pairs for mono (6); host-only"""
+    out = (C.c_uint32 * 8)()
+    rc = lib().speexhip_debug_plan64(ratio_num, ratio_den, quality, channels, out)
+    if rc:
+        raise ValueError(strerror(rc))
+    v = list(out)
+    return {"fast_path": v[0], "r_or_p": v[1], "lane_periods": v[2], "row_len": v[3], "lds_bytes": v[4],
+            "pad_or_stride": v[5], "trips": v[6], "last": v[7]}
 
 
 def device_clock():

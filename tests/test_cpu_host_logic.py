@@ -497,3 +497,50 @@ def test_generated_fir_loop_is_in_step_with_its_generator():
         assert sum(1 for l in lines if l.startswith("v_cvt")) == (loops * 2 * v.S if v.w16 else 0), v.name
         assert sum(1 for l in lines if l == "s_waitcnt lgkmcnt(0)") == 2 * loops + 1, v.name
         assert max(v.vgprs()) < (64 if v.R == 10 else 128), v.name
+
+
+def test_round4_planners_fp64_accumulate_and_phase_pairs():
+    """The plans added in round 4, without a GPU (speexhip_debug_plan64): quality 9 and 10 run the fp64-accumulate twins
+    of the fast kernels wherever the fp32 ones run (slide: every shape; period: the ISA loop's layouts), within the
+    SGPR / LDS bounds their kernels are built for; mono filters with wide windows (num >= 320) get phase-pair plans
+    of 64 periods per tile whose int16 window is taken when it makes room for a second workgroup."""
+    rates = [8000, 11025, 12000, 16000, 22050, 24000, 32000, 40000, 44100, 48000, 56000, 64000, 72000, 80000,
+             88200, 96000, 128000, 160000, 176400, 192000]
+    seen = {0: 0, 4: 0, 5: 0, 6: 0}
+    for i in rates:
+        for o in rates:
+            for q, ch in ((10, 1), (9, 2), (10, 3), (9, 8), (7, 1), (5, 1)):
+                try:
+                    base = speexhip.debug_plan(i, o, q, ch)
+                    t = speexhip.debug_plan64(i, o, q, ch)
+                except ValueError:
+                    continue
+                seen[t["fast_path"]] += 1
+                if q >= 9:
+                    if base["fast_path"] == 3:
+                        assert t["fast_path"] == 4, (i, o, q, ch, base, t)       # every slide shape has its fp64 twin
+                        steps = t["last"]
+                        assert t["row_len"] % (2 * steps) == 0 and t["lds_bytes"] <= 160 * 1024, (i, o, q, ch, t)
+                        den = o // np.gcd(i, o)
+                        assert steps * den <= 30, (i, o, q, ch, t)                # one bank of tap doubles in SGPR pairs
+                    elif base["fast_path"] == 2:
+                        assert t["fast_path"] == (5 if ch in (1, 2, 4, 6, 8) else 0), (i, o, q, ch, base, t)
+                        if t["fast_path"] == 5:
+                            assert t["r_or_p"] in (5, 10) and t["lds_bytes"] <= 150 * 1024, (i, o, q, ch, t)
+                            assert t["row_len"] == t["trips"] * (2 if t["r_or_p"] == 10 else 6), (i, o, q, ch, t)
+                            assert not (t["r_or_p"] == 5 and t["pad_or_stride"]), (i, o, q, ch, t)
+                    else:
+                        assert t["fast_path"] == 0
+                else:
+                    num = i // np.gcd(i, o)
+                    wide = base["fast_path"] == 2 and num >= 320
+                    assert (t["fast_path"] == 6) == wide, (i, o, q, ch, base, t)
+                    if wide:
+                        assert 16 <= t["lane_periods"] <= 64 and t["lds_bytes"] <= 150 * 1024, (i, o, q, ch, t)
+                        assert t["last"] in (0,) or t["last"] <= 64, (i, o, q, ch, t)
+    assert min(seen.values()) > 0, seen
+    p64 = speexhip.debug_plan64
+    assert p64(24000, 48000, 10, 1)["fast_path"] == 4 and p64(24000, 48000, 10, 1)["r_or_p"] == 8    # BASELINE configs[2]
+    assert p64(44100, 48000, 10, 2)["fast_path"] == 5 and p64(44100, 48000, 10, 3)["fast_path"] == 0
+    assert p64(44100, 48000, 7, 1)["fast_path"] == 0 and p64(48000, 22050, 7, 1)["fast_path"] == 6
+    assert p64(48000, 11025, 7, 1)["last"] >= 60      # its int16 window: two workgroups per CU instead of one

@@ -1467,7 +1467,8 @@ _SLIDE64_RATIOS = [(8000, 8000), (24000, 48000), (16000, 48000), (12000, 48000),
                    (48000, 24000), (32000, 48000), (16000, 40000), (48000, 16000), (48000, 32000), (24000, 40000),
                    (32000, 8000), (32000, 40000), (40000, 8000), (40000, 16000), (40000, 24000), (40000, 32000),
                    (40000, 48000), (48000, 8000), (48000, 40000), (56000, 8000), (64000, 8000), (32000, 12000),
-                   (72000, 8000), (80000, 8000), (96000, 8000), (128000, 8000), (160000, 8000), (192000, 8000)]
+                   (72000, 8000), (80000, 8000), (96000, 8000), (128000, 8000), (160000, 8000), (192000, 8000),
+                   (56000, 16000), (72000, 16000)]   # 7:2, 9:2: slide shapes of odd channel counts only
 
 
 def test_fp64_accumulate_slide_kernel_on_every_shape():
@@ -1483,6 +1484,10 @@ def test_fp64_accumulate_slide_kernel_on_every_shape():
             ref = orc.Oracle(ch, i, o, q)
             r = speexhip.Resampler(ch, i, o, q)
             info = r.info()
+            if (i, o) in ((56000, 16000), (72000, 16000)) and ch == 2:
+                assert info["fast_path"] == 0     # (no fp32 slide shape for channel pairs there: exact kernel)
+                r.close()
+                continue
             assert info["fast_path"] == 4 and info["accumulate_bits"] == 64, (ch, i, o, q, info)
             for call, frames in enumerate([1, 30000, 777, 50001]):
                 x = orc.lcg_pcm(frames * ch, 17 * call + ch + n).reshape(frames, ch)
