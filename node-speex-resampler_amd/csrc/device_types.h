@@ -30,13 +30,12 @@ struct StreamDesc {
                         // every workgroup used to make in its prologue)
 };
 
-// Batches of up to 32 streams (BASELINE configs[4]'s share of one GPU) carry their descriptors in the
-// kernel-argument segment: 2.3 KB of the 4 KB a launch may pass.  (8 until round 3: a 32-stream launch then
-// went through the pinned -> device ring, i.e. a copy of 2.3 KB -- a blit kernel in front of every launch --
-// and every workgroup fetched its descriptor with a load that could only be issued once the ring's pointer
-// had arrived from the kernel arguments: two memory round trips before the first staging load instead of one.)
+// A launch carries up to 32 streams (BASELINE configs[4]'s share of one GPU) and their descriptors travel in its
+// kernel-argument segment: 2.5 KB of the 4 KB a launch may pass -- no copy in front of the launch, no dependent load in
+// the kernels.  Larger batches run as one launch per 32 streams (engine.cpp, run_plans; until round 4 they were one
+// launch through a pinned -> device descriptor ring, for which every kernel existed in a second form).
 static const int kMaxPackedStreams = 32;
-struct DescPack {  // small batches travel in the kernel-argument segment (no H2D copy)
+struct DescPack {  // the descriptors of one launch, in its kernel-argument segment
   StreamDesc d[kMaxPackedStreams];
 };
 

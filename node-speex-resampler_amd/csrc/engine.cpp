@@ -213,12 +213,6 @@ int Batch::setup() {
   const FilterSpec designed = filter_;
   int rc = install_filter(designed, std::vector<float>(), designed.taps - 1);  // resample.c:721-725: silence
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  if (n_streams_ > static_cast<uint32_t>(kMaxPackedStreams)) {
-    const size_t ring_bytes = sizeof(StreamDesc) * n_streams_ * kRing;
-    HIP_TRY(pool::pinned_get(reinterpret_cast<void **>(&h_ring_), ring_bytes));
-    HIP_TRY(pool::device_get(device_, reinterpret_cast<void **>(&d_ring_), ring_bytes));
-    for (int i = 0; i < kRing; i++) HIP_TRY(pool::event_get(device_, &ring_done_[i]));
-  }
   return SPEEXHIP_ERR_SUCCESS;  // (install_filter waited for its own uploads)
 }
 
@@ -721,9 +715,6 @@ Batch::~Batch() {
   tables_.reset();  // shared (DeviceTables): the cache keeps them for the next state with this filter
   pool::device_put(device_, d_hist_[0]);
   pool::device_put(device_, d_hist_[1]);
-  pool::device_put(device_, d_ring_);
-  pool::pinned_put(h_ring_);
-  for (int i = 0; i < kRing; i++) pool::event_put(device_, ring_done_[i]);
   pool::device_put(device_, d_stage_in_);
   pool::device_put(device_, d_stage_out_);
   pool::pinned_put(h_pin_in_);
@@ -850,8 +841,7 @@ int Batch::run_channel(uint32_t c, const void *d_in, uint32_t in_stride, uint32_
     geo.lds_bytes = 0;
     geo.outs_per_block = 256;
   }
-  const hipError_t e = launch_exact(filter_, geo, d_table_, 1, nullptr, &pack, 1, plan.produced, float_io, stream,
-                                    &strides, zero_mode_);
+  const hipError_t e = launch_exact(filter_, geo, d_table_, 1, &pack, 1, plan.produced, float_io, stream, &strides, zero_mode_);
   if (hip_failed(e, "kernel launch")) return SPEEXHIP_ERR_DEVICE;
   if (d.hist_keep != 0)
     HIP_TRY(hipMemcpy2DAsync(d_hist_[hist_cur_] + c, channels_ * sizeof(float), d_hist_[hist_cur_ ^ 1] + c,
@@ -884,64 +874,65 @@ int Batch::process_split(const void *d_in, uint32_t *in_len, void *d_out, uint32
   return zero_mode_ ? SPEEXHIP_ERR_ALLOC_FAILED : SPEEXHIP_ERR_SUCCESS;
 }
 
-// One launch that carries every stream from plans[s].begin to plans[s].end.  in_frames[s] =
-// frames readable at the stream's input pointer.
+// Every stream from plans[s].begin to plans[s].end: one launch per 32 streams (kMaxPackedStreams: the descriptors
+// of a launch travel in its kernel arguments -- no descriptor copy, no dependent load in the kernels).  in_frames[s]
+// = frames readable at the stream's input pointer.
+// (Until round 4 a batch of more than 32 streams was ONE launch whose descriptors went through a pinned -> device
+//  ring, and every kernel existed twice -- reading its descriptor from the arguments or from the ring: half of the
+//  library's code objects, half of its build time and of what a process loads at its first call, for launches that
+//  are many generations long anyway; BASELINE configs[4] is 32 streams per GPU.  A launch's ragged end costs ~14 us
+//  of a 32-stream launch's ~200: what a 64-stream batch pays for being two launches.)
 int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_frames, void *d_out,
                      uint64_t out_stride, const CallPlan *plans, bool float_io, hipStream_t stream) {
   const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
-  const bool packed = n_streams_ <= static_cast<uint32_t>(kMaxPackedStreams);
-  DescPack pack;
-  StreamDesc *descs = pack.d;
-  int slot = 0;
-  if (packed) {
-    std::memset(&pack, 0, sizeof(pack));
-  } else {
-    slot = ring_next_;
-    ring_next_ = (ring_next_ + 1) % kRing;
-    if (ring_busy_[slot]) {  // the launch that last used this slot must have read it
-      HIP_TRY(hipEventSynchronize(ring_done_[slot]));
-      ring_busy_[slot] = false;
-    }
-    descs = h_ring_ + static_cast<size_t>(slot) * n_streams_;
-  }
-
-  uint32_t max_out = 0;
-  bool any_work = false;
-  for (uint32_t s = 0; s < n_streams_; s++) {
-    const CallPlan &plan = plans[s];
-    StreamDesc &d = descs[s];
-    d.in = d_in ? static_cast<const char *>(d_in) + s * in_stride * es : nullptr;
-    d.hist = d_hist_[hist_cur_] + s * hist_elems_;
-    d.out = static_cast<char *>(d_out) + s * out_stride * es;
-    d.hist_next = d_hist_[hist_cur_ ^ 1] + s * hist_elems_;
-    d.in_frames = in_frames[s];
-    d.n_out = plan.produced;
-    d.consumed = plan.magic_used + plan.consumed;  // frames of V past the history
-    d.hist_frames = filter_.taps - 1 + plan.begin.magic;
-    d.hist_keep = filter_.taps - 1 + plan.end.magic;
-    d.last0 = plan.begin.last;
-    d.frac0 = plan.begin.frac;
-    d.k_shift = phase_index_of(filter_.num, filter_.den, plan.begin.frac);
-    d.base_shift = plan.begin.last -
-                   static_cast<int32_t>((static_cast<uint64_t>(d.k_shift) * filter_.num) / filter_.den);
-    d.tile_begin = 0;
-    d.m_total = static_cast<uint32_t>((static_cast<uint64_t>(d.k_shift) + d.n_out + filter_.den - 1) / filter_.den);
-    max_out = std::max(max_out, plan.produced);
-    any_work = any_work || plan.produced != 0 || d.consumed != 0;
-  }
-
+  const uint32_t kChunk = static_cast<uint32_t>(kMaxPackedStreams);
   if (float_io) float_seen_ = true;  // (from here on the histories may hold non-integer samples)
-  if (any_work) {
-    // Calls on one batch are ordered (each reads the history the previous one left and the
-    // ping-pong buffers alternate): a call enqueued on another stream than the previous one
-    // waits for it on the device.
-    const int chain_rc = chain_to(stream);
-    if (chain_rc != SPEEXHIP_ERR_SUCCESS) return chain_rc;
-    const StreamDesc *d_descs = nullptr;
-    if (!packed) {
-      StreamDesc *dst = d_ring_ + static_cast<size_t>(slot) * n_streams_;
-      HIP_TRY(hipMemcpyAsync(dst, descs, sizeof(StreamDesc) * n_streams_, hipMemcpyHostToDevice, stream));
-      d_descs = dst;
+  bool chained = false;
+  for (uint32_t s0 = 0; s0 < n_streams_; s0 += kChunk) {
+    const uint32_t n = std::min(kChunk, n_streams_ - s0);
+    DescPack pack;
+    std::memset(&pack, 0, sizeof(pack));
+    StreamDesc *descs = pack.d;
+    uint32_t max_out = 0;
+    bool any_work = false;
+    for (uint32_t j = 0; j < n; j++) {
+      const uint32_t s = s0 + j;
+      const CallPlan &plan = plans[s];
+      StreamDesc &d = descs[j];
+      d.in = d_in ? static_cast<const char *>(d_in) + s * in_stride * es : nullptr;
+      d.hist = d_hist_[hist_cur_] + s * hist_elems_;
+      d.out = static_cast<char *>(d_out) + s * out_stride * es;
+      d.hist_next = d_hist_[hist_cur_ ^ 1] + s * hist_elems_;
+      d.in_frames = in_frames[s];
+      d.n_out = plan.produced;
+      d.consumed = plan.magic_used + plan.consumed;  // frames of V past the history
+      d.hist_frames = filter_.taps - 1 + plan.begin.magic;
+      d.hist_keep = filter_.taps - 1 + plan.end.magic;
+      d.last0 = plan.begin.last;
+      d.frac0 = plan.begin.frac;
+      d.k_shift = phase_index_of(filter_.num, filter_.den, plan.begin.frac);
+      d.base_shift = plan.begin.last -
+                     static_cast<int32_t>((static_cast<uint64_t>(d.k_shift) * filter_.num) / filter_.den);
+      d.tile_begin = 0;
+      d.m_total = static_cast<uint32_t>((static_cast<uint64_t>(d.k_shift) + d.n_out + filter_.den - 1) / filter_.den);
+      max_out = std::max(max_out, plan.produced);
+      any_work = any_work || plan.produced != 0 || d.consumed != 0;
+    }
+    if (!any_work) {
+      // (nothing to run for these streams -- but the ping-pong below flips for the whole batch: their histories
+      //  must move to the other buffer with everybody else's, which the kernels do even for an idle stream)
+      bool others = false;
+      for (uint32_t s = 0; s < n_streams_ && !others; s++)
+        others = plans[s].produced != 0 || plans[s].magic_used + plans[s].consumed != 0;
+      if (!others) continue;
+    }
+    if (!chained) {
+      // Calls on one batch are ordered (each reads the history the previous one left and the
+      // ping-pong buffers alternate): a call enqueued on another stream than the previous one
+      // waits for it on the device.
+      const int chain_rc = chain_to(stream);
+      if (chain_rc != SPEEXHIP_ERR_SUCCESS) return chain_rc;
+      chained = true;
     }
     hipError_t e;
     const bool fast = mode_ != SPEEXHIP_MODE_EXACT;
@@ -950,46 +941,35 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       geo.staged = false;
       geo.lds_bytes = 0;
       geo.outs_per_block = 256;
-      e = launch_exact(filter_, geo, d_table_, channels_, d_descs, packed ? &pack : nullptr, n_streams_, max_out,
-                       float_io, stream, nullptr, true);
+      e = launch_exact(filter_, geo, d_table_, channels_, &pack, n, max_out, float_io, stream, nullptr, true);
     } else if (fast && acc64() && period64_.usable) {
       // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
       e = launch_period(filter_, period64_, reinterpret_cast<const float *>(d_period64_rows_), &period64_fine_,
-                        reinterpret_cast<const float *>(d_period64_fine_rows_), channels_, descs, d_descs,
-                        packed ? &pack : nullptr, n_streams_, float_io, stream);
+                        reinterpret_cast<const float *>(d_period64_fine_rows_), channels_, descs, &pack, n, float_io, stream);
     } else if (fast && acc64() && !period_.usable && slide64_.usable) {
-      // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
-      e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, d_descs, packed ? &pack : nullptr,
-                         n_streams_, float_io, stream);
+      e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, &pack, n, float_io, stream);
     } else if (fast && period_pp_.usable &&
-               period_launch_prefers_pp(filter_, (!float_io && !float_seen_ && period_w16_.usable) ? period_w16_ : period_, descs,
-                                        n_streams_)) {
+               period_launch_prefers_pp(filter_, (!float_io && !float_seen_ && period_w16_.usable) ? period_w16_ : period_, descs, n)) {
       // mono, wide windows: phase pairs (one period per lane, half the window per tile) where this launch gains
       const bool w16 = !float_io && !float_seen_ && period_pp_w16_.usable;
       e = launch_period(filter_, w16 ? period_pp_w16_ : period_pp_, w16 ? d_period_pp_w16_rows_ : d_period_pp_rows_, nullptr,
-                        nullptr, channels_, descs, d_descs, packed ? &pack : nullptr, n_streams_, float_io, stream);
+                        nullptr, channels_, descs, &pack, n, float_io, stream);
     } else if (fast && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
-               (w16_always() || period_launch_prefers_w16(filter_, period_, period_fine_.usable, descs, n_streams_)))
+               (w16_always() || period_launch_prefers_w16(filter_, period_, period_fine_.usable, descs, n))) {
       // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- unless
       // the launch is too small for that to pay (period_launch_prefers_w16)
-      e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, d_descs,
-                        packed ? &pack : nullptr, n_streams_, false, stream);
-    else if (fast && period_.usable)
-      e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs,
-                        d_descs, packed ? &pack : nullptr, n_streams_, float_io, stream);
-    else if (fast && slide_.usable)
-      e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, d_descs,
-                       packed ? &pack : nullptr, n_streams_, float_io, stream);
-    else
-      e = launch_exact(filter_, exact_geo_, d_table_, channels_, d_descs, packed ? &pack : nullptr,
-                       n_streams_, max_out, float_io, stream);
-    if (hip_failed(e, "kernel launch")) return SPEEXHIP_ERR_DEVICE;
-    if (!packed) {
-      HIP_TRY(hipEventRecord(ring_done_[slot], stream));
-      ring_busy_[slot] = true;
+      e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, &pack, n, false, stream);
+    } else if (fast && period_.usable) {
+      e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs, &pack, n,
+                        float_io, stream);
+    } else if (fast && slide_.usable) {
+      e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, &pack, n, float_io, stream);
+    } else {
+      e = launch_exact(filter_, exact_geo_, d_table_, channels_, &pack, n, max_out, float_io, stream);
     }
-    hist_cur_ ^= 1;
+    if (hip_failed(e, "kernel launch")) return SPEEXHIP_ERR_DEVICE;
   }
+  if (chained) hist_cur_ ^= 1;
   for (uint32_t s = 0; s < n_streams_; s++)
     for (uint32_t c = 0; c < channels_; c++) P(s, c) = plans[s].end;
   return SPEEXHIP_ERR_SUCCESS;

@@ -190,14 +190,6 @@ class Batch {
     return mode_ == SPEEXHIP_MODE_FAST && (filter_.kind == kDirectDouble || filter_.kind == kInterpolateDouble);
   }
 
-  // descriptor transport for batches larger than kMaxPackedStreams
-  static const int kRing = 32;
-  StreamDesc *h_ring_ = nullptr;  // pinned
-  StreamDesc *d_ring_ = nullptr;
-  hipEvent_t ring_done_[kRing] = {};
-  bool ring_busy_[kRing] = {};
-  int ring_next_ = 0;
-
   // Calls on one batch are chained: a call on another stream than the previous one waits for it on the device
   // (an event recorded on the previous stream at that moment), control calls and the destructor wait for the
   // previous stream on the host.  So the stream of a device-pointer call must outlive the state's next call --

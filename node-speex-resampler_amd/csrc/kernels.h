@@ -56,7 +56,7 @@ struct ExactStrides {
   uint32_t in, out, hist;
 };
 hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float *d_table,
-                        uint32_t channels, const StreamDesc *d_descs, const DescPack *pack,
+                        uint32_t channels, const DescPack *pack,
                         uint32_t n_streams, uint32_t max_n_out, bool float_io, hipStream_t stream,
                         const ExactStrides *strides = nullptr, bool zero = false);
 
@@ -91,7 +91,7 @@ void build_period_rows64(const FilterSpec &f, const PeriodPlan &t, std::vector<d
 // `fine`: the same filter planned with r = 5 (or null); single-generation launches take it
 hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, const PeriodPlan *fine,
                          const float *d_rows_fine, uint32_t channels, const StreamDesc *h_descs,
-                         const StreamDesc *d_descs, const DescPack *pack, uint32_t n_streams, bool float_io,
+                         const DescPack *pack, uint32_t n_streams, bool float_io,
                          hipStream_t stream);
 
 // Should this int16 launch run over the int16-window plan rather than `t` (the float-window plan, `has_fine`: with
@@ -109,7 +109,7 @@ SlidePlan plan_slide(const FilterSpec &f, uint32_t channels);
 size_t slide_lds_bytes(const SlidePlan &t, uint32_t waves);  // LDS of a workgroup of `waves` waves
 void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float> *rows);
 hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
-                        const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                        const StreamDesc *h_descs, const DescPack *pack,
                         uint32_t n_streams, bool float_io, hipStream_t stream);
 
 // ---- ... with an fp64 accumulator (kernels_slide64_impl.h, round 4): the reference's "double" kernels (quality 9
@@ -118,7 +118,7 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
 SlidePlan plan_slide64(const FilterSpec &f, uint32_t channels);
 void build_slide64_rows(const FilterSpec &f, const SlidePlan &t, std::vector<double> *rows);
 hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double *d_rows, uint32_t channels,
-                          const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                          const StreamDesc *h_descs, const DescPack *pack,
                           uint32_t n_streams, bool float_io, hipStream_t stream);
 
 }  // namespace speexhip

@@ -57,11 +57,10 @@ __device__ __forceinline__ void cubic_weights(float f, float w[4]) {
 
 // T = sample type of the call: int16_t (round + saturate on the way out, resample.c:1018-1022)
 // or float (the FIR value as is, resample.c:927-963).
-template <int KIND, int CT, bool STAGED, bool PACKED, typename T>
-__global__ __launch_bounds__(256) void resample_exact(ExactParams p, const StreamDesc *__restrict__ streams,
-                                                      DescPack pack) {
+template <int KIND, int CT, bool STAGED, typename T>
+__global__ __launch_bounds__(256) void resample_exact(ExactParams p, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
+  const StreamDesc d = pack.d[blockIdx.y];  // (the launch's descriptors travel in the kernel arguments: device_types.h)
   const uint32_t C = p.channels;
   const uint32_t hist_frames = d.hist_frames;
 
@@ -217,43 +216,33 @@ __global__ __launch_bounds__(256) void resample_exact(ExactParams p, const Strea
 }
 
 template <int KIND, int CT, bool STAGED, typename T>
-hipError_t launch_k(const ExactParams &p, const StreamDesc *d_descs, const DescPack *pack,
-                    dim3 grid, size_t lds_bytes, hipStream_t stream) {
-  DescPack empty;
-  if (pack != nullptr) {
-    auto kern = resample_exact<KIND, CT, STAGED, true, T>;
-    static std::atomic<uint64_t> seen{0};  // allow the full 160 KiB of dynamic LDS, once per device
-    opt_in_lds_on_this_device(kern, seen);
-    hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, nullptr, *pack);
-  } else {
-    auto kern = resample_exact<KIND, CT, STAGED, false, T>;
-    static std::atomic<uint64_t> seen{0};
-    opt_in_lds_on_this_device(kern, seen);
-    memset(&empty, 0, sizeof(empty));
-    hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, d_descs, empty);
-  }
+hipError_t launch_k(const ExactParams &p, const DescPack *pack, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+  auto kern = resample_exact<KIND, CT, STAGED, T>;
+  static std::atomic<uint64_t> seen{0};  // allow the full 160 KiB of dynamic LDS, once per device
+  opt_in_lds_on_this_device(kern, seen);
+  hipLaunchKernelGGL(kern, grid, dim3(p.outs_per_block), lds_bytes, stream, p, *pack);
   return hipGetLastError();
 }
 
 template <int KIND, typename T>
-hipError_t launch_kind(const ExactParams &p, const StreamDesc *d, const DescPack *pack, int ct,
+hipError_t launch_kind(const ExactParams &p, const DescPack *pack, int ct,
                        bool staged, dim3 grid, size_t lds, hipStream_t s) {
   if (ct == 2)
-    return staged ? launch_k<KIND, 2, true, T>(p, d, pack, grid, lds, s)
-                  : launch_k<KIND, 2, false, T>(p, d, pack, grid, 0, s);
-  return staged ? launch_k<KIND, 1, true, T>(p, d, pack, grid, lds, s)
-                : launch_k<KIND, 1, false, T>(p, d, pack, grid, 0, s);
+    return staged ? launch_k<KIND, 2, true, T>(p, pack, grid, lds, s)
+                  : launch_k<KIND, 2, false, T>(p, pack, grid, 0, s);
+  return staged ? launch_k<KIND, 1, true, T>(p, pack, grid, lds, s)
+                : launch_k<KIND, 1, false, T>(p, pack, grid, 0, s);
 }
 
 template <typename T>
-hipError_t launch_typed(const FilterSpec &f, const ExactParams &p, const StreamDesc *d, const DescPack *pack,
+hipError_t launch_typed(const FilterSpec &f, const ExactParams &p, const DescPack *pack,
                         const ExactGeometry &g, dim3 grid, hipStream_t s) {
   switch (f.kind) {
-    case kDirectSingle: return launch_kind<kDirectSingle, T>(p, d, pack, g.ct, g.staged, grid, g.lds_bytes, s);
-    case kDirectDouble: return launch_kind<kDirectDouble, T>(p, d, pack, g.ct, g.staged, grid, g.lds_bytes, s);
+    case kDirectSingle: return launch_kind<kDirectSingle, T>(p, pack, g.ct, g.staged, grid, g.lds_bytes, s);
+    case kDirectDouble: return launch_kind<kDirectDouble, T>(p, pack, g.ct, g.staged, grid, g.lds_bytes, s);
     case kInterpolateSingle:
-      return launch_kind<kInterpolateSingle, T>(p, d, pack, g.ct, g.staged, grid, g.lds_bytes, s);
-    default: return launch_kind<kInterpolateDouble, T>(p, d, pack, g.ct, g.staged, grid, g.lds_bytes, s);
+      return launch_kind<kInterpolateSingle, T>(p, pack, g.ct, g.staged, grid, g.lds_bytes, s);
+    default: return launch_kind<kInterpolateDouble, T>(p, pack, g.ct, g.staged, grid, g.lds_bytes, s);
   }
 }
 
@@ -283,7 +272,7 @@ ExactGeometry exact_geometry(const FilterSpec &f, uint32_t channels, size_t lds_
 }
 
 hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float *d_table,
-                        uint32_t channels, const StreamDesc *d_descs, const DescPack *pack,
+                        uint32_t channels, const DescPack *pack,
                         uint32_t n_streams, uint32_t max_n_out, bool float_io, hipStream_t stream,
                         const ExactStrides *strides, bool zero) {
   ExactParams p;
@@ -302,8 +291,8 @@ hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float
   p.zero = zero ? 1u : 0u;
   const uint32_t blocks = (max_n_out + g.outs_per_block - 1) / g.outs_per_block;
   dim3 grid(blocks + 1, n_streams, g.channel_groups);
-  return float_io ? launch_typed<float>(f, p, d_descs, pack, g, grid, stream)
-                  : launch_typed<int16_t>(f, p, d_descs, pack, g, grid, stream);
+  return float_io ? launch_typed<float>(f, p, pack, g, grid, stream)
+                  : launch_typed<int16_t>(f, p, pack, g, grid, stream);
 }
 
 }  // namespace speexhip

@@ -4,10 +4,10 @@
 
 namespace speexhip {
 // the fp64-accumulate instances (kernels_period64.hip): launch the one of plan `t`'s layout
-hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack,
+hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                              dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
 // the phase-pair instances for mono (kernels_period_pp.hip)
-hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack,
+hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                               dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
 namespace {
 
@@ -302,7 +302,7 @@ uint32_t split_count(const PeriodPlan &t, uint32_t tiles, uint32_t n_streams, ui
 }
 
 hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
-                              const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                              const StreamDesc *h_descs, const DescPack *pack,
                               uint32_t n_streams, bool float_io, hipStream_t stream);
 }  // namespace
 
@@ -360,20 +360,20 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
 // in launches of several generations R = 10 wins: 32 streams 210 vs 225 us).
 hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, const PeriodPlan *fine,
                          const float *d_rows_fine, uint32_t channels, const StreamDesc *h_descs,
-                         const StreamDesc *d_descs, const DescPack *pack, uint32_t n_streams, bool float_io,
+                         const DescPack *pack, uint32_t n_streams, bool float_io,
                          hipStream_t stream) {
   if (fine != nullptr && fine->usable && d_rows_fine != nullptr) {
     const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
     const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
     if (split_count(t, tiles, n_streams, 2 * device_compute_units()) > 1)
-      return launch_period_plan(f, *fine, d_rows_fine, channels, h_descs, d_descs, pack, n_streams, float_io, stream);
+      return launch_period_plan(f, *fine, d_rows_fine, channels, h_descs, pack, n_streams, float_io, stream);
   }
-  return launch_period_plan(f, t, d_rows, channels, h_descs, d_descs, pack, n_streams, float_io, stream);
+  return launch_period_plan(f, t, d_rows, channels, h_descs, pack, n_streams, float_io, stream);
 }
 
 namespace {
 hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
-                              const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                              const StreamDesc *h_descs, const DescPack *pack,
                               uint32_t n_streams, bool float_io, hipStream_t stream) {
   const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
@@ -535,12 +535,12 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   }
   // (an int16 window -- t.w16 -- exists for int16 calls on the layouts the ISA loop is generated for: ONE or CGV)
   if (t.w16 && float_io) return hipErrorInvalidValue;
-  if (t.a64) return dispatch_period64(t, p, d_descs, pack, grid, threads, float_io, stream);  // kernels_period64.hip
-  if (t.pp) return dispatch_period_pp(t, p, d_descs, pack, grid, threads, float_io, stream);   // kernels_period_pp.hip
+  if (t.a64) return dispatch_period64(t, p, pack, grid, threads, float_io, stream);  // kernels_period64.hip
+  if (t.pp) return dispatch_period_pp(t, p, pack, grid, threads, float_io, stream);   // kernels_period_pp.hip
   // (LRC: the kernel of the layout, or its tap-range-shares twin)
 #define SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, W)                                                                                    \
-  (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, true>(p, d_descs, pack, grid, threads, t.window_bytes, stream)              \
-                : launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, false>(p, d_descs, pack, grid, threads, t.window_bytes, stream))
+  (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, true>(p, pack, grid, threads, t.window_bytes, stream)              \
+                : launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, false>(p, pack, grid, threads, t.window_bytes, stream))
 #define SPEEXHIP_LRC(RV, CTV, ONE, PADV, TV, CGV) SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, false)
 #define SPEEXHIP_PERIOD_CASE_R(RV, CTV, ONE, PADV)                                                                                      \
   return float_io ? SPEEXHIP_LRC(RV, CTV, ONE, PADV, float, 0)                                                                           \

@@ -12,12 +12,12 @@
 
 namespace speexhip {
 
-hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack,
+hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                              dim3 grid, uint32_t threads, bool float_io, hipStream_t stream) {
 #define SPEEXHIP_P64(RV, CTV, ONE, PADV, CGV)                                                                             \
-  return float_io ? launch_rc<RV, CTV, ONE, PADV, float, CGV, false, false, 1>(p, d_descs, pack, grid, threads,        \
+  return float_io ? launch_rc<RV, CTV, ONE, PADV, float, CGV, false, false, 1>(p, pack, grid, threads,        \
                                                                                   t.window_bytes, stream)                 \
-                  : launch_rc<RV, CTV, ONE, PADV, int16_t, CGV, false, false, 1>(p, d_descs, pack, grid, threads,      \
+                  : launch_rc<RV, CTV, ONE, PADV, int16_t, CGV, false, false, 1>(p, pack, grid, threads,      \
                                                                                     t.window_bytes, stream)
   const bool padded = t.pad != 0;
   if (!t.a64 || t.w16 || (padded && t.r != 10)) return hipErrorInvalidValue;

@@ -625,7 +625,6 @@ __device__ __forceinline__ X load_k(const __attribute__((address_space(4))) X *p
 struct KernArgs {  // layout of resample_period's kernel arguments
   PeriodParams p;
   const float *rows;
-  const StreamDesc *streams;
   DescPack pack;
 };
 
@@ -838,10 +837,9 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
 //
 // Workgroup = one tile (blockIdx.x) of one stream (blockIdx.y), optionally one of gridDim.z
 // shares of its phase groups.
-template <int R, int CT, bool ONE_GROUP, bool PADDED, bool PACKED, typename T, int CGF = 0, bool W16 = false, bool KS = false,
-          int AM = 0>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool KS = false, int AM = 0>
 __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdgpu_num_sgpr(80))) void resample_period(
-    PeriodParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
+    PeriodParams p, const float *__restrict__ rows, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   // A workgroup that starts beside another one's FIR loop competes with 16 older waves for every
   // issue slot: its few hundred prologue and staging instructions -- the ones that put its window
@@ -864,7 +862,7 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
   // exiting workgroup happens to have: pure arithmetic, no memory access): the kernel arguments and
   // the descriptor then arrive through one batch of scalar loads and a single wait instead of one
   // round trip per early exit (four dependent waits, ~1.0 us from start to the first staging load).
-  const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
+  const StreamDesc d = pack.d[blockIdx.y];
   if (!(p.prio & 1u)) __builtin_amdgcn_s_setprio(0);  // diagnostics: A/B of the raised prologue priority
   const uint32_t m_total = d.m_total;  // periods touched by this call: ceil((k_shift + n_out) / den), from the host
   const uint32_t m_lo = blockIdx.x * p.lane_periods;
@@ -924,7 +922,7 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
   if constexpr (KS) {  // every wave of the workgroup works on a group (fir_tile_parts)
     const __attribute__((address_space(4))) KernArgs *ka =
         (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
+    const KDesc dp = &ka->pack.d[blockIdx.y];
     fir_tile_parts<R, CT, ONE_GROUP, PADDED, T, CGF, W16, AM == 2>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
                                                                   threadIdx.x & 63u, blockIdx.z);
     return;
@@ -932,15 +930,15 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
   const __attribute__((address_space(4))) KernArgs *ka =
       (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-  const KDesc dp = PACKED ? &ka->pack.d[blockIdx.y] : reinterpret_cast<KDesc>(reinterpret_cast<uintptr_t>(streams + blockIdx.y));
+  const KDesc dp = &ka->pack.d[blockIdx.y];
   fir_tile<R, CT, ONE_GROUP, PADDED, T, CGF, W16, AM>(p, d, &ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
                                                   threadIdx.x & 63u, blockIdx.z, gridDim.z);
   }
 }
 
 template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false, bool KS = false, int AM = 0>
-hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
-                     uint32_t threads, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_rc(const PeriodParams &p, const DescPack *pack, dim3 grid, uint32_t threads, size_t lds_bytes,
+                     hipStream_t stream) {
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   constexpr bool kParts = false;
 #else
@@ -949,20 +947,11 @@ hipError_t launch_rc(const PeriodParams &p, const StreamDesc *d_descs, const Des
   if constexpr (KS && !kParts) {  // (no ISA loop for this layout: the host never asks for tap-range shares of it)
     return hipErrorInvalidValue;
   } else {
-  DescPack empty;
-  if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
-  static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
-  if (pack != nullptr)
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS, AM>, seen_packed);
-  else
-    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS, AM>, seen_ring);
-  if (pack != nullptr)
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, true, T, CGF, W16, KS, AM>), grid, dim3(threads), lds_bytes, stream,
-                       p, p.rows, nullptr, *pack);
-  else
-    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, false, T, CGF, W16, KS, AM>), grid, dim3(threads), lds_bytes, stream,
-                       p, p.rows, d_descs, empty);
-  return hipGetLastError();
+    static std::atomic<uint64_t> seen{0};
+    opt_in_lds_on_this_device(resample_period<R, CT, ONE_GROUP, PADDED, T, CGF, W16, KS, AM>, seen);
+    hipLaunchKernelGGL((resample_period<R, CT, ONE_GROUP, PADDED, T, CGF, W16, KS, AM>), grid, dim3(threads), lds_bytes, stream,
+                       p, p.rows, *pack);
+    return hipGetLastError();
   }
 }
 

@@ -10,12 +10,12 @@
 
 namespace speexhip {
 
-hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const StreamDesc *d_descs, const DescPack *pack,
+hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                               dim3 grid, uint32_t threads, bool float_io, hipStream_t stream) {
   if (!t.pp || t.a64 || t.ct != 1 || t.cgroups != 1 || (t.pad != 0 && t.r != 10) || (t.w16 && float_io)) return hipErrorInvalidValue;
 #define SPEEXHIP_PP_KS(RV, PADV, TV, W)                                                                                       \
-  return p.ksplit > 1 ? launch_rc<RV, 1, true, PADV, TV, 0, W, true, 2>(p, d_descs, pack, grid, threads, t.window_bytes, stream) \
-                      : launch_rc<RV, 1, true, PADV, TV, 0, W, false, 2>(p, d_descs, pack, grid, threads, t.window_bytes, stream)
+  return p.ksplit > 1 ? launch_rc<RV, 1, true, PADV, TV, 0, W, true, 2>(p, pack, grid, threads, t.window_bytes, stream) \
+                      : launch_rc<RV, 1, true, PADV, TV, 0, W, false, 2>(p, pack, grid, threads, t.window_bytes, stream)
 #define SPEEXHIP_PP(RV, PADV)                          \
   {                                                    \
     if (float_io) SPEEXHIP_PP_KS(RV, PADV, float, false); \

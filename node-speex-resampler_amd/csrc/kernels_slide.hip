@@ -15,21 +15,16 @@
 namespace speexhip {
 
 template <typename T>
-hipError_t launch_slide_shape(const SlidePlan &t, const SlideParams &p, const StreamDesc *d_descs, const DescPack *pack,
+hipError_t launch_slide_shape(const SlidePlan &t, const SlideParams &p, const DescPack *pack,
                               dim3 grid, uint32_t threads, size_t lds, hipStream_t stream);
-extern template hipError_t launch_slide_shape<int16_t>(const SlidePlan &, const SlideParams &, const StreamDesc *,
-                                                       const DescPack *, dim3, uint32_t, size_t, hipStream_t);
-extern template hipError_t launch_slide_shape<float>(const SlidePlan &, const SlideParams &, const StreamDesc *,
-                                                     const DescPack *, dim3, uint32_t, size_t, hipStream_t);
+extern template hipError_t launch_slide_shape<int16_t>(const SlidePlan &, const SlideParams &, const DescPack *, dim3, uint32_t, size_t, hipStream_t);
+extern template hipError_t launch_slide_shape<float>(const SlidePlan &, const SlideParams &, const DescPack *, dim3, uint32_t, size_t, hipStream_t);
 
 template <typename T>
-hipError_t launch_slide64_shape(const SlidePlan &t, const SlideParams &p, const double *rows, const StreamDesc *d_descs,
-                                const DescPack *pack, dim3 grid, uint32_t threads, size_t lds, hipStream_t stream);
-extern template hipError_t launch_slide64_shape<int16_t>(const SlidePlan &, const SlideParams &, const double *,
-                                                         const StreamDesc *, const DescPack *, dim3, uint32_t, size_t,
+hipError_t launch_slide64_shape(const SlidePlan &t, const SlideParams &p, const double *rows, const DescPack *pack, dim3 grid, uint32_t threads, size_t lds, hipStream_t stream);
+extern template hipError_t launch_slide64_shape<int16_t>(const SlidePlan &, const SlideParams &, const double *, const DescPack *, dim3, uint32_t, size_t,
                                                          hipStream_t);
-extern template hipError_t launch_slide64_shape<float>(const SlidePlan &, const SlideParams &, const double *,
-                                                       const StreamDesc *, const DescPack *, dim3, uint32_t, size_t,
+extern template hipError_t launch_slide64_shape<float>(const SlidePlan &, const SlideParams &, const double *, const DescPack *, dim3, uint32_t, size_t,
                                                        hipStream_t);
 
 namespace {
@@ -122,7 +117,7 @@ void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float
 }
 
 hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
-                        const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                        const StreamDesc *h_descs, const DescPack *pack,
                         uint32_t n_streams, bool float_io, hipStream_t stream) {
   uint32_t max_periods = 0;
   for (uint32_t s = 0; s < n_streams; s++) {
@@ -181,8 +176,8 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   }
   const uint32_t threads = waves * p.parts * 64;
   p.threads = threads;
-  return float_io ? launch_slide_shape<float>(t, p, d_descs, pack, grid, threads, lds, stream)
-                  : launch_slide_shape<int16_t>(t, p, d_descs, pack, grid, threads, lds, stream);
+  return float_io ? launch_slide_shape<float>(t, p, pack, grid, threads, lds, stream)
+                  : launch_slide_shape<int16_t>(t, p, pack, grid, threads, lds, stream);
 }
 
 
@@ -249,7 +244,7 @@ void build_slide64_rows(const FilterSpec &f, const SlidePlan &t, std::vector<dou
 }
 
 hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double *d_rows, uint32_t channels,
-                          const StreamDesc *h_descs, const StreamDesc *d_descs, const DescPack *pack,
+                          const StreamDesc *h_descs, const DescPack *pack,
                           uint32_t n_streams, bool float_io, hipStream_t stream) {
   uint32_t max_periods = 0;
   for (uint32_t s = 0; s < n_streams; s++) {
@@ -298,8 +293,8 @@ hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double 
   }
   const uint32_t threads = waves * p.parts * 64;
   p.threads = threads;
-  return float_io ? launch_slide64_shape<float>(t, p, d_rows, d_descs, pack, grid, threads, lds, stream)
-                  : launch_slide64_shape<int16_t>(t, p, d_rows, d_descs, pack, grid, threads, lds, stream);
+  return float_io ? launch_slide64_shape<float>(t, p, d_rows, pack, grid, threads, lds, stream)
+                  : launch_slide64_shape<int16_t>(t, p, d_rows, pack, grid, threads, lds, stream);
 }
 
 }  // namespace speexhip

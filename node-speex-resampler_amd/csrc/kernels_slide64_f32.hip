@@ -2,6 +2,5 @@
 // (speex_resampler_process_interleaved_float, deps/speex/resample.c:1038-1059)
 #include "kernels_slide64_impl.h"
 namespace speexhip {
-template hipError_t launch_slide64_shape<float>(const SlidePlan &, const SlideParams &, const double *, const StreamDesc *,
-                                                const DescPack *, dim3, uint32_t, size_t, hipStream_t);
+template hipError_t launch_slide64_shape<float>(const SlidePlan &, const SlideParams &, const double *,                                                 const DescPack *, dim3, uint32_t, size_t, hipStream_t);
 }

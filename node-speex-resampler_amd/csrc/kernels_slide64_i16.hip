@@ -2,6 +2,5 @@
 // (speex_resampler_process_interleaved_int, deps/speex/resample.c:1061-1082)
 #include "kernels_slide64_impl.h"
 namespace speexhip {
-template hipError_t launch_slide64_shape<int16_t>(const SlidePlan &, const SlideParams &, const double *, const StreamDesc *,
-                                                  const DescPack *, dim3, uint32_t, size_t, hipStream_t);
+template hipError_t launch_slide64_shape<int16_t>(const SlidePlan &, const SlideParams &, const double *,                                                   const DescPack *, dim3, uint32_t, size_t, hipStream_t);
 }

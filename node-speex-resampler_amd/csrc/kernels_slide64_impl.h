@@ -65,11 +65,11 @@ __device__ __forceinline__ void fma64(double &acc, const double &tap, const doub
 __device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 
 // P: periods per lane; NUM / DEN: the ratio; U = P*NUM tap steps per iteration.
-template <int P, int NUM, int DEN, bool PACKED, typename T>
+template <int P, int NUM, int DEN, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void resample_slide64(
-    SlideParams p, const double *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
+    SlideParams p, const double *__restrict__ rows, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
+  const StreamDesc d = pack.d[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
     roll_history<T>(p.channels, d, p.threads);
     return;
@@ -325,21 +325,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
 }
 
 template <int P, int NUM, int DEN, typename T>
-hipError_t launch_s64(const SlideParams &p, const double *rows, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
-                      uint32_t threads, size_t lds_bytes, hipStream_t stream) {
-  DescPack empty;
-  if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
-  static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
-  if (pack != nullptr)
-    opt_in_lds_on_this_device(resample_slide64<P, NUM, DEN, true, T>, seen_packed);
-  else
-    opt_in_lds_on_this_device(resample_slide64<P, NUM, DEN, false, T>, seen_ring);
-  if (pack != nullptr)
-    hipLaunchKernelGGL((resample_slide64<P, NUM, DEN, true, T>), grid, dim3(threads), lds_bytes, stream, p, rows, nullptr,
-                       *pack);
-  else
-    hipLaunchKernelGGL((resample_slide64<P, NUM, DEN, false, T>), grid, dim3(threads), lds_bytes, stream, p, rows, d_descs,
-                       empty);
+hipError_t launch_s64(const SlideParams &p, const double *rows, const DescPack *pack, dim3 grid, uint32_t threads,
+                      size_t lds_bytes, hipStream_t stream) {
+  static std::atomic<uint64_t> seen{0};
+  opt_in_lds_on_this_device(resample_slide64<P, NUM, DEN, T>, seen);
+  hipLaunchKernelGGL((resample_slide64<P, NUM, DEN, T>), grid, dim3(threads), lds_bytes, stream, p, rows, *pack);
   return hipGetLastError();
 }
 
@@ -347,10 +337,9 @@ hipError_t launch_s64(const SlideParams &p, const double *rows, const StreamDesc
 
 // the instantiation table: (periods per lane, num, den) as kShapes64 lists them (kernels_slide.hip)
 template <typename T>
-hipError_t launch_slide64_shape(const SlidePlan &t, const SlideParams &p, const double *rows, const StreamDesc *d_descs,
-                                const DescPack *pack, dim3 grid, uint32_t threads, size_t lds, hipStream_t stream) {
+hipError_t launch_slide64_shape(const SlidePlan &t, const SlideParams &p, const double *rows, const DescPack *pack, dim3 grid, uint32_t threads, size_t lds, hipStream_t stream) {
 #define SPEEXHIP_S64_CASE(PP, NUMV, DENV) \
-  if (t.p == PP && t.num == NUMV && t.np == DENV) return launch_s64<PP, NUMV, DENV, T>(p, rows, d_descs, pack, grid, threads, lds, stream);
+  if (t.p == PP && t.num == NUMV && t.np == DENV) return launch_s64<PP, NUMV, DENV, T>(p, rows, pack, grid, threads, lds, stream);
   SPEEXHIP_S64_CASE(8, 1, 1)
   SPEEXHIP_S64_CASE(8, 1, 2)
   SPEEXHIP_S64_CASE(8, 1, 3)

@@ -2,6 +2,6 @@
 #include "kernels_slide_impl.h"
 
 namespace speexhip {
-template hipError_t launch_slide_shape<float>(const SlidePlan &, const SlideParams &, const StreamDesc *, const DescPack *, dim3,
+template hipError_t launch_slide_shape<float>(const SlidePlan &, const SlideParams &, const DescPack *, dim3,
                                            uint32_t, size_t, hipStream_t);
 }  // namespace speexhip

@@ -72,11 +72,11 @@ __device__ __forceinline__ void fma_bcast_x(f32x2 &acc, const f32x2 &tap_pair, c
 // P: periods per lane; NUM: input frames per period; U = P*NUM tap steps per iteration.
 // DENSE: the frame is exactly one lane's samples (mono for phase pairs, stereo for channel pairs): the
 // channel count is a compile-time constant and every LDS offset of the FIR loop an immediate.
-template <int P, int NUM, int NP, bool PAIR_CH, bool DENSE, bool PACKED, typename T>
+template <int P, int NUM, int NP, bool PAIR_CH, bool DENSE, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void resample_slide(
-    SlideParams p, const float *__restrict__ rows, const StreamDesc *__restrict__ streams, DescPack pack) {
+    SlideParams p, const float *__restrict__ rows, DescPack pack) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
-  const StreamDesc d = PACKED ? pack.d[blockIdx.y] : streams[blockIdx.y];
+  const StreamDesc d = pack.d[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
     roll_history<T>(p.channels, d, p.threads);
     return;
@@ -407,21 +407,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
 }
 
 template <int P, int NUM, int NP, bool PAIR_CH, bool DENSE, typename T>
-hipError_t launch_up(const SlideParams &p, const StreamDesc *d_descs, const DescPack *pack, dim3 grid,
-                     uint32_t threads, size_t lds_bytes, hipStream_t stream) {
-  DescPack empty;
-  if (pack == nullptr) std::memset(&empty, 0, sizeof(empty));
-  static std::atomic<uint64_t> seen_packed{0}, seen_ring{0};
-  if (pack != nullptr)
-    opt_in_lds_on_this_device(resample_slide<P, NUM, NP, PAIR_CH, DENSE, true, T>, seen_packed);
-  else
-    opt_in_lds_on_this_device(resample_slide<P, NUM, NP, PAIR_CH, DENSE, false, T>, seen_ring);
-  if (pack != nullptr)
-    hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, DENSE, true, T>), grid, dim3(threads), lds_bytes, stream, p,
-                       p.rows, nullptr, *pack);
-  else
-    hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, DENSE, false, T>), grid, dim3(threads), lds_bytes, stream, p,
-                       p.rows, d_descs, empty);
+hipError_t launch_up(const SlideParams &p, const DescPack *pack, dim3 grid, uint32_t threads, size_t lds_bytes,
+                     hipStream_t stream) {
+  static std::atomic<uint64_t> seen{0};
+  opt_in_lds_on_this_device(resample_slide<P, NUM, NP, PAIR_CH, DENSE, T>, seen);
+  hipLaunchKernelGGL((resample_slide<P, NUM, NP, PAIR_CH, DENSE, T>), grid, dim3(threads), lds_bytes, stream, p, p.rows, *pack);
   return hipGetLastError();
 }
 
@@ -429,12 +419,12 @@ hipError_t launch_up(const SlideParams &p, const StreamDesc *d_descs, const Desc
 
 // the instantiation table: one launch per (periods per lane, num, accumulator pairs, packing) x dense / strided
 template <typename T>
-hipError_t launch_slide_shape(const SlidePlan &t, const SlideParams &p, const StreamDesc *d_descs, const DescPack *pack,
+hipError_t launch_slide_shape(const SlidePlan &t, const SlideParams &p, const DescPack *pack,
                               dim3 grid, uint32_t threads, size_t lds, hipStream_t stream) {
 #define SPEEXHIP_SLIDE_CASE(PP, NUMV, NPV, CHV)                                                                       \
   if (t.p == PP && t.num == NUMV && t.np == NPV && t.pair_ch == CHV) {                                                \
-    if (t.cgroups == 1) return launch_up<PP, NUMV, NPV, CHV, true, T>(p, d_descs, pack, grid, threads, lds, stream);   \
-    return launch_up<PP, NUMV, NPV, CHV, false, T>(p, d_descs, pack, grid, threads, lds, stream);                     \
+    if (t.cgroups == 1) return launch_up<PP, NUMV, NPV, CHV, true, T>(p, pack, grid, threads, lds, stream);   \
+    return launch_up<PP, NUMV, NPV, CHV, false, T>(p, pack, grid, threads, lds, stream);                     \
   }
   SPEEXHIP_SLIDE_CASE(8, 1, 1, true)
   SPEEXHIP_SLIDE_CASE(8, 1, 2, true)

@@ -191,7 +191,7 @@ def test_python_mirror_of_processChunk_applies_the_capacity_rule(golden):
 def test_batched_streams_device_pointers_ragged():
     import torch
     ch, i, o, q = 2, 44100, 48000, 7
-    for S in (3, 12, 36):  # 36 > kMaxPackedStreams (32) exercises the descriptor ring
+    for S in (3, 12, 36):  # 36 > kMaxPackedStreams (32): two launches
         frames = 30000
         lens = [frames - 137 * s for s in range(S)]
         xs = np.stack([orc.lcg_pcm(frames * ch, 500 + s).reshape(frames, ch) for s in range(S)])
@@ -302,10 +302,10 @@ def test_small_ratio_sliding_window_kernel_variants():
         r.close()
 
 
-def test_many_ragged_streams_through_the_descriptor_ring():
-    """40 streams (> 8: descriptors travel through the pinned -> device ring instead of the kernel
-    arguments) with ragged lengths: the grid is sized for the longest stream, so the shorter ones
-    leave workgroups with empty tiles."""
+def test_many_ragged_streams_in_launches_of_32():
+    """40 streams (> 32: the batch runs as two launches of 32 and 8 streams, each with its descriptors in its
+    kernel arguments; until round 4 one launch through a descriptor ring) with ragged lengths: a launch's grid is
+    sized for its longest stream, so the shorter ones leave workgroups with empty tiles."""
     import torch
     ch, i, o, q, S, frames = 2, 44100, 48000, 7, 40, 100000
     lens = [frames - 997 * (s % 7) for s in range(S)]
@@ -331,7 +331,7 @@ def test_many_ragged_streams_through_the_descriptor_ring():
 def test_configs4_per_gpu_share_32_streams_at_full_size():
     """BASELINE.json configs[4] as one GPU sees it at N = 8: 32 independent stereo streams
     44.1k->48k q7, one 2^20-frame chunk each per call, through the batched device-pointer entry
-    (one launch, descriptors through the ring).  Two consecutive calls (the second starts from a
+    (one launch, descriptors in its kernel arguments).  Two consecutive calls (the second starts from a
     non-trivial position and a full history); six streams checked against the oracle: +-1 LSB,
     counters, position, history; the other streams through a property (distinct inputs give
     distinct outputs of the same length)."""
@@ -1144,7 +1144,7 @@ def test_bench_n_rank_path_end_to_end_on_one_gpu():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
     # BASELINE configs[4] in its full shape -- 8 ranks, 256 streams, 32 per rank, each rank's launch fed through
-    # its descriptor ring -- on this one GPU (short chunks): what an 8-GPU node will run (tools/scale.sh)
+    # its launches of 32 -- on this one GPU (short chunks): what an 8-GPU node will run (tools/scale.sh)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-streams", "256", "--steps", "3",
                         "--warmup", "1", "--reps", "2", "--frames", "65536", "--preheat-ms", "10"], env=env,
                        capture_output=True, text=True, timeout=900)
