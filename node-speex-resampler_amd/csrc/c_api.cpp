@@ -288,7 +288,7 @@ int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, u
         out[0] = 4;
         out[1] = sl.p;
         out[3] = sl.row_len;
-        out[4] = static_cast<uint32_t>(speexhip::slide_lds_bytes(sl, 2));
+        out[4] = static_cast<uint32_t>(speexhip::slide_lds_bytes(sl, 2) * (sl.p * f.den >= 4 ? 2 : 1));  // (image in doubles)
         out[5] = sl.row_stride;
         out[7] = sl.p * sl.num;
       }

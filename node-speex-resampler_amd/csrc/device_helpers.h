@@ -219,8 +219,10 @@ __device__ __forceinline__ uint32_t padded_pos(const WindowGeom &g, uint32_t j) 
 // the floats of one group, image floats j .. j+GS-1 (j a multiple of GS): 16-byte LDS writes
 // (8-byte ones where the padding leaves the group only 8-byte aligned) unless the group
 // straddles a padding boundary
-template <typename T>
-__device__ __forceinline__ void commit_group(float *xs, const WindowGeom &g, uint32_t j, const u32x4 &w) {
+// (E: the element type of the LDS image -- float, or double for the fp64-accumulate slide kernel, which then reads its
+//  samples already widened; positions count elements either way)
+template <typename T, typename E = float>
+__device__ __forceinline__ void commit_group(E *xs, const WindowGeom &g, uint32_t j, const u32x4 &w) {
   constexpr int GS = PerLoad<T>::value;
   float f[GS];
   unpack_group(w, f, T());
@@ -230,7 +232,18 @@ __device__ __forceinline__ void commit_group(float *xs, const WindowGeom &g, uin
     a = padded_pos(g, j);
     contiguous = padded_pos(g, j + GS - 1) - a == GS - 1;
   }
-  if (contiguous && (a & 3u) == 0) {
+  if constexpr (sizeof(E) == 8) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    if (contiguous && (a & 1u) == 0) {
+#pragma unroll
+      for (int k = 0; k < GS; k += 2)
+        *reinterpret_cast<f64x2 *>(xs + a + k) = f64x2{static_cast<double>(f[k]), static_cast<double>(f[k + 1])};
+    } else {
+#pragma unroll
+      for (int k = 0; k < GS; k++) xs[padded_pos(g, j + k)] = static_cast<E>(f[k]);
+    }
+    return;
+  } else if (contiguous && (a & 3u) == 0) {
 #pragma unroll
     for (int k = 0; k < GS; k += 4)
       *reinterpret_cast<float4 *>(xs + a + k) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
@@ -243,14 +256,14 @@ __device__ __forceinline__ void commit_group(float *xs, const WindowGeom &g, uin
   }
 }
 
-template <int UNR, typename T>
-__device__ __forceinline__ void window_commit(float *xs, const StreamDesc &d, const WindowGeom &g,
+template <int UNR, typename T, typename E = float>
+__device__ __forceinline__ void window_commit(E *xs, const StreamDesc &d, const WindowGeom &g,
                                               const u32x4 (&w)[UNR]) {
   constexpr int GS = PerLoad<T>::value;
 #pragma unroll
   for (int u = 0; u < UNR; u++) {
     const uint32_t unit = u * g.nthr + threadIdx.x;
-    if (unit < g.n_wide) commit_group<T>(xs, g, GS * (g.u_begin + unit), w[u]);
+    if (unit < g.n_wide) commit_group<T, E>(xs, g, GS * (g.u_begin + unit), w[u]);
   }
   // groups beyond the prefetched UNR per lane (small workgroups, very wide windows): further
   // rounds of UNR loads in flight at a time
@@ -266,13 +279,13 @@ __device__ __forceinline__ void window_commit(float *xs, const StreamDesc &d, co
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
       const uint32_t unit = base + u * g.nthr + threadIdx.x;
-      if (unit < g.n_wide) commit_group<T>(xs, g, GS * (g.u_begin + unit), v[u]);
+      if (unit < g.n_wide) commit_group<T, E>(xs, g, GS * (g.u_begin + unit), v[u]);
     }
   }
   for (uint32_t j = threadIdx.x; j < g.head_end; j += g.nthr)
-    xs[g.pad ? padded_pos(g, j) : j] = rel_sample<T>(d, g.q_base + j, g.hist_elems, g.in_elems);
+    xs[g.pad ? padded_pos(g, j) : j] = static_cast<E>(rel_sample<T>(d, g.q_base + j, g.hist_elems, g.in_elems));
   for (uint32_t j = g.tail_begin + threadIdx.x; j < g.total; j += g.nthr)
-    xs[g.pad ? padded_pos(g, j) : j] = rel_sample<T>(d, g.q_base + j, g.hist_elems, g.in_elems);
+    xs[g.pad ? padded_pos(g, j) : j] = static_cast<E>(rel_sample<T>(d, g.q_base + j, g.hist_elems, g.in_elems));
 }
 
 // ---- the same for a "plain" window: no bank padding, every 16-byte group wholly inside the call's input

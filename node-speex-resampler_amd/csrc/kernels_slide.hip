@@ -196,6 +196,9 @@ const Slide64Shape kShapes64[] = {
 };
 }  // namespace
 
+// the fp64 kernel keeps its LDS image in doubles where a sample read feeds >= 4 FMAs (kernels_slide64_impl.h, LD64)
+static bool slide64_lds_doubles(const SlidePlan &t, uint32_t den) { return t.p * den >= 4; }
+
 SlidePlan plan_slide64(const FilterSpec &f, uint32_t channels) {
   SlidePlan t;
   t.pair_ch = false;
@@ -212,22 +215,28 @@ SlidePlan plan_slide64(const FilterSpec &f, uint32_t channels) {
   const uint32_t steps = t.p * f.num;
   const uint32_t dmax = static_cast<uint32_t>((static_cast<uint64_t>(f.den - 1) * f.num) / f.den);
   t.row_len = (f.taps + dmax + 2 * steps - 1) / (2 * steps) * (2 * steps);  // an even number of iterations
-  // row stride: the lanes of a wave read one float each, lane (block b, channel c) at b*stride + c: the pad with
-  // the fewest lanes of a wave on one bank
+  // row stride: the lanes of a wave read one element each, lane (block b, channel c) at b*stride + c: the pad with
+  // the fewest lanes on one bank -- 64 banks of 4 bytes for the float image; an 8-byte element takes two, and a
+  // wave's ds_read_b64 goes through in half-waves
   const uint32_t row_elems = steps * channels;
   const uint32_t blocks = 64 / channels;
+  const bool ld64 = slide64_lds_doubles(t, f.den);
   uint32_t best = 0xffffffffu;
   t.row_stride = row_elems;
   for (uint32_t pad = 0; pad < 32; pad++) {
     uint32_t count[64] = {0}, worst = 0;
     for (uint32_t b = 0; b < blocks; b++)
-      for (uint32_t c = 0; c < channels; c++) worst = std::max(worst, ++count[(b * (row_elems + pad) + c) % 64]);
+      for (uint32_t c = 0; c < channels; c++) {
+        const uint32_t lane = b * channels + c, at = b * (row_elems + pad) + c;
+        if (ld64 && lane >= 32) continue;
+        worst = std::max(worst, ++count[ld64 ? at % 32 : at % 64]);
+      }
     if (worst < best) {
       best = worst;
       t.row_stride = row_elems + pad;
     }
   }
-  if (slide_lds_bytes(t, 2) > kSlideLdsLimit) t.usable = false;
+  if (slide_lds_bytes(t, 2) * (ld64 ? 2 : 1) > kSlideLdsLimit) t.usable = false;
   return t;
 }
 
@@ -257,7 +266,8 @@ hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double 
   uint32_t waves = max_waves;
   while (waves > 2 && static_cast<uint64_t>(max_periods) * n_streams < 512ull * waves * blocks_per_wave * t.p)
     waves /= 2;
-  while (waves > 2 && slide_lds_bytes(t, waves) > kSlideLdsLimit) waves /= 2;  // (fits with 2: plan_slide64)
+  const size_t eb = slide64_lds_doubles(t, f.den) ? 2 : 1;  // (image in doubles: twice the bytes)
+  while (waves > 2 && slide_lds_bytes(t, waves) * eb > kSlideLdsLimit) waves /= 2;  // (fits with 2: plan_slide64)
   SlideParams p;
   p.rows = nullptr;  // (the fp64 rows travel as a kernel argument of their own)
   p.den = f.den;
@@ -273,7 +283,7 @@ hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double 
   p.skip = skip_mask;
   const uint32_t tile_periods = p.blocks_per_tile * t.p;
   const uint32_t tiles = (max_periods + tile_periods - 1) / tile_periods;
-  size_t lds = slide_lds_bytes(t, waves);
+  size_t lds = slide_lds_bytes(t, waves) * eb;
   dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
   // tap-range parts, by the slide kernel's rule (a wave's chain here: P x den x row_len fp64 FMAs)
   static const int env_parts = std::getenv("SPEEXHIP_SLIDE_PARTS") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_PARTS")) : -1;

@@ -64,18 +64,27 @@ __device__ __forceinline__ void fma64(double &acc, const double &tap, const doub
 // the value of the lane beside this one in its pair (quad_perm [1,0,3,2])
 __device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
 
-// P: periods per lane; NUM / DEN: the ratio; U = P*NUM tap steps per iteration.
-template <int P, int NUM, int DEN, typename T>
+// P: periods per lane; NUM / DEN: the ratio; U = P*NUM tap steps per iteration.  CH: the channel count when it is 1 or 2
+// (every LDS offset of the FIR loop is then an immediate: with the count in a register the loop spent one vector add
+// per sample read on addresses -- 8 of the 152 vector instructions of an iteration of BASELINE configs[2]), else 0.
+template <int P, int NUM, int DEN, int CH, typename T>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void resample_slide64(
     SlideParams p, const double *__restrict__ rows, DescPack pack) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];
+  // The LDS image holds the samples as DOUBLES where a read feeds at least four FMAs (P*DEN >= 4: BASELINE configs[2]
+  // has 16): widened once while staging instead of once per read in the loop -- the conversions were 8 of the 136
+  // vector instructions of its iteration.  Below that (n:1 decimation: one or two FMAs per read) 8-byte reads would
+  // make the LDS the bound, so those shapes keep the float image and widen in the loop.
+  constexpr bool LD64 = P * DEN >= 4;
+  using E = std::conditional_t<LD64, double, float>;
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  E *xs = reinterpret_cast<E *>(lds_raw);
   const StreamDesc d = pack.d[blockIdx.y];
   if (blockIdx.x == gridDim.x - 1) {
     roll_history<T>(p.channels, d, p.threads);
     return;
   }
   if (d.n_out == 0) return;
-  const uint32_t C = p.channels;  // (= p.cgroups: one lane per channel of a lane block)
+  const uint32_t C = CH != 0 ? static_cast<uint32_t>(CH) : p.channels;  // (= p.cgroups: one lane per channel of a lane block)
   const uint32_t K_end = d.k_shift + d.n_out;
   const uint32_t m_total = d.m_total;
   const uint32_t tile_periods = p.blocks_per_tile * P;
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   if (!(p.skip & 2u)) {
     u32x4 w[4];
     window_fetch<4, T>(wg, w);
-    window_commit<4, T>(xs, d, wg, w);
+    window_commit<4, T, E>(xs, d, wg, w);
   }
   __syncthreads();
 
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   const uint32_t c = lane % C;                                // channel of this lane
   const uint32_t lb = wave * p.blocks_per_wave + lane / C;    // lane block inside the tile
   const bool lane_live = (lane / C) < p.blocks_per_wave && lb * P < m_cnt;
-  const float *xrow = xs + wg.xshift + min(lb, p.blocks_per_tile - 1) * p.row_stride + c;
+  const E *xrow = xs + wg.xshift + min(lb, p.blocks_per_tile - 1) * p.row_stride + c;
 
   double acc[P][DEN];
 #pragma unroll
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   auto iteration = [&](auto base_c, double (&tp)[TAPS_IT], auto &tp_next) {
     constexpr int BASE = decltype(base_c)::value;
     if constexpr (!TAP2) load_taps(tp, trow);
-    float raw[U];
+    E raw[U];
     static_for64<OLD, W>([&](auto k_c) {  // the U new samples
       constexpr int k = decltype(k_c)::value;
       raw[k - OLD] = k < U ? xrow[k * C] : xrow[p.row_stride + (k - U) * C];
@@ -324,12 +333,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
   }
 }
 
-template <int P, int NUM, int DEN, typename T>
+template <int P, int NUM, int DEN, int CH, typename T>
 hipError_t launch_s64(const SlideParams &p, const double *rows, const DescPack *pack, dim3 grid, uint32_t threads,
                       size_t lds_bytes, hipStream_t stream) {
   static std::atomic<uint64_t> seen{0};
-  opt_in_lds_on_this_device(resample_slide64<P, NUM, DEN, T>, seen);
-  hipLaunchKernelGGL((resample_slide64<P, NUM, DEN, T>), grid, dim3(threads), lds_bytes, stream, p, rows, *pack);
+  opt_in_lds_on_this_device(resample_slide64<P, NUM, DEN, CH, T>, seen);
+  hipLaunchKernelGGL((resample_slide64<P, NUM, DEN, CH, T>), grid, dim3(threads), lds_bytes, stream, p, rows, *pack);
   return hipGetLastError();
 }
 
@@ -338,8 +347,12 @@ hipError_t launch_s64(const SlideParams &p, const double *rows, const DescPack *
 // the instantiation table: (periods per lane, num, den) as kShapes64 lists them (kernels_slide.hip)
 template <typename T>
 hipError_t launch_slide64_shape(const SlidePlan &t, const SlideParams &p, const double *rows, const DescPack *pack, dim3 grid, uint32_t threads, size_t lds, hipStream_t stream) {
-#define SPEEXHIP_S64_CASE(PP, NUMV, DENV) \
-  if (t.p == PP && t.num == NUMV && t.np == DENV) return launch_s64<PP, NUMV, DENV, T>(p, rows, pack, grid, threads, lds, stream);
+#define SPEEXHIP_S64_CASE(PP, NUMV, DENV)                                                                             \
+  if (t.p == PP && t.num == NUMV && t.np == DENV) {                                                                  \
+    if (t.cgroups == 1) return launch_s64<PP, NUMV, DENV, 1, T>(p, rows, pack, grid, threads, lds, stream);          \
+    if (t.cgroups == 2) return launch_s64<PP, NUMV, DENV, 2, T>(p, rows, pack, grid, threads, lds, stream);          \
+    return launch_s64<PP, NUMV, DENV, 0, T>(p, rows, pack, grid, threads, lds, stream);                              \
+  }
   SPEEXHIP_S64_CASE(8, 1, 1)
   SPEEXHIP_S64_CASE(8, 1, 2)
   SPEEXHIP_S64_CASE(8, 1, 3)
