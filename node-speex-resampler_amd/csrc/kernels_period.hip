@@ -497,19 +497,19 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 #else
   const bool isa_layout = (t.ct == 1 && t.cgroups == 1) || (t.ct == 2 && t.cgroups <= 4);
 #endif
-  // (no tap-range shares for the fp64 accumulator: its partial sums would be doubles -- twice the LDS -- and no KS
-  //  instances are built for it)
-  if (splits > 1 && env_ksplit != 0 && isa_layout && !t.a64 && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
+  if (splits > 1 && env_ksplit != 0 && isa_layout && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
     uint32_t parts = env_ksplit > 0 ? static_cast<uint32_t>(env_ksplit) : max_waves / wave_groups;
     parts = std::min<uint32_t>(parts, max_waves / wave_groups);
     const uint32_t trips = t.l4;  // trips per group row
+    // (the partial sums overwrite the window: R x 64 pairs of floats per wave, or of doubles with an fp64 accumulator)
     while (parts > 1 && (trips / parts < 4 ||
-                         static_cast<size_t>(parts - 1) * wave_groups * t.r * 64 * 8 > t.window_bytes))
+                         static_cast<size_t>(parts - 1) * wave_groups * t.r * 64 * (t.a64 ? 16 : 8) > t.window_bytes))
       parts--;
     // (two parts on a chip already more than half full buy nothing: there the launch is throughput, not one
     //  wave's latency -- 32 mono streams x 131 072 frames of 48k -> 22.05k in 2 shares: 44.8 us without, 48.7 with)
     const bool crowded = static_cast<uint64_t>(tiles) * n_streams * splits * 2 > device_compute_units();
-    if (parts > 1 && (env_ksplit > 0 || (static_cast<uint64_t>(t.r) * t.row_len >= 1800 && !(crowded && parts < 3))))
+    // (a wave's chain in vector instructions: one packed FMA per tap, two v_fma_f64 with an fp64 accumulator)
+    if (parts > 1 && (env_ksplit > 0 || (static_cast<uint64_t>(t.r) * t.row_len * (t.a64 ? 2 : 1) >= 1800 && !(crowded && parts < 3))))
       p.ksplit = parts;
   }
   const uint32_t threads =

@@ -14,11 +14,11 @@ namespace speexhip {
 
 hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                              dim3 grid, uint32_t threads, bool float_io, hipStream_t stream) {
-#define SPEEXHIP_P64(RV, CTV, ONE, PADV, CGV)                                                                             \
-  return float_io ? launch_rc<RV, CTV, ONE, PADV, float, CGV, false, false, 1>(p, pack, grid, threads,        \
-                                                                                  t.window_bytes, stream)                 \
-                  : launch_rc<RV, CTV, ONE, PADV, int16_t, CGV, false, false, 1>(p, pack, grid, threads,      \
-                                                                                    t.window_bytes, stream)
+#define SPEEXHIP_P64_T(RV, CTV, ONE, PADV, TV, CGV)                                                                           \
+  (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, false, true, 1>(p, pack, grid, threads, t.window_bytes, stream)      \
+                : launch_rc<RV, CTV, ONE, PADV, TV, CGV, false, false, 1>(p, pack, grid, threads, t.window_bytes, stream))
+#define SPEEXHIP_P64(RV, CTV, ONE, PADV, CGV) \
+  return float_io ? SPEEXHIP_P64_T(RV, CTV, ONE, PADV, float, CGV) : SPEEXHIP_P64_T(RV, CTV, ONE, PADV, int16_t, CGV)
   const bool padded = t.pad != 0;
   if (!t.a64 || t.w16 || (padded && t.r != 10)) return hipErrorInvalidValue;
   if (t.ct == 1) {
@@ -43,6 +43,7 @@ hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const D
   SPEEXHIP_P64_CG(4)
 #undef SPEEXHIP_P64_CG
 #undef SPEEXHIP_P64
+#undef SPEEXHIP_P64_T
   return hipErrorInvalidValue;
 }
 

@@ -316,24 +316,45 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
 // 2 * steps_per_bank steps (2 for R = 10, 6 for R = 5), the host's tables count in those (build_period_rows64).
 template <int R, int CT, bool PADDED, int CF>
 __device__ __forceinline__ void fir_group64(const PeriodParams &p, const double *__restrict__ rows, const float *xs,
-                                            const LaneCtx &c, uint32_t g, bool skip_all, double (&acc)[R][2]) {
+                                            const LaneCtx &c, uint32_t g, bool skip_all, uint32_t part, uint32_t parts,
+                                            double (&acc)[R][2]) {
   using Isa = FirLoopAsm64<R, CT, CF, PADDED>;
   static_assert(CF != 0 && Isa::available, "the fp64 accumulator runs the ISA loop of its layout");
   constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
-  const uint32_t delta_g = p.delta[g];
-  const float *xp = xs + c.xlane + delta_g * c.C;
-  const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
-  const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u;
-  const double *rows_g = rows + static_cast<size_t>(g) * p.l4 * (kStepsPerTrip * R);
-  const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xp));
+  // (padded windows: the host's boundary tables count 4-step iterations; a trip here is kStepsPerTrip steps)
+  constexpr uint32_t kPerIt = 4 / kStepsPerTrip;
   auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+  const uint32_t delta_g = p.delta[g];
+  const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+  const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u, total = trips >> 8;
+  // tap-range shares (fir_tile_parts64): this wave runs trips [t0, t1) of the group
+  const uint32_t t0 = sgpr(total * part / parts), t1 = sgpr(total * (part + 1) / parts);
+  auto overlap = [&](uint32_t lo, uint32_t hi) {
+    const uint32_t a = max(t0, lo), b = min(t1, hi);
+    return b > a ? b - a : 0u;
+  };
+  const uint32_t main_end = total - tail;
+  uint32_t wraps = 0, to_wrap = 0;
+  const uint32_t wrap_step = p.wrap_step * kPerIt;
+  if constexpr (PADDED) {
+    const uint32_t to_wrap0 = p.delta[p.groups + g] * kPerIt;
+    to_wrap = to_wrap0;
+    if (to_wrap0 != 0 && t0 >= to_wrap0) {
+      const uint32_t past = t0 - to_wrap0;
+      wraps = 1 + past / wrap_step;
+      to_wrap = wrap_step - past % wrap_step;
+    } else if (to_wrap0 != 0) {
+      to_wrap = to_wrap0 - t0;
+    }
+  }
+  const double *rows_g = rows + (static_cast<size_t>(g) * p.l4 + t0) * (kStepsPerTrip * R);
+  const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) +
+                        ((c.xlane + delta_g * c.C) + t0 * kStepsPerTrip * CF + wraps * p.pad) * 4u;
   const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
   const double *rows_s = reinterpret_cast<const double *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
                                                           static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
-  // (padded windows: the host's boundary tables count 4-step iterations; a trip here is kStepsPerTrip steps)
-  constexpr uint32_t kPerIt = 4 / kStepsPerTrip;
-  Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 4u : 0u, sgpr(head), sgpr((trips >> 8) - head - tail), sgpr(tail),
-           sgpr(PADDED ? p.delta[p.groups + g] * kPerIt : 0u), sgpr(p.wrap_step * kPerIt), sgpr((kStepsPerTrip * CF + p.pad) * 4u));
+  Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 4u : 0u, sgpr(overlap(0, head)), sgpr(overlap(head, main_end)),
+           sgpr(overlap(main_end, total)), sgpr(to_wrap), sgpr(wrap_step), sgpr((kStepsPerTrip * CF + p.pad) * 4u));
 }
 
 // Round / interleave / store the R phases of group g for this lane's period: R consecutive
@@ -672,7 +693,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
 #pragma unroll
       for (int i = 0; i < R; i++) acc64[i][0] = acc64[i][1] = 0.0;
       fir_group64<R, CT, PADDED, ONE_GROUP ? CT : 2 * CGF>(p, reinterpret_cast<const double *>(rows), xs, c, g, (p.skip & 4u) != 0,
-                                                           acc64);
+                                                           0u, 1u, acc64);
 #pragma unroll
       for (int i = 0; i < R; i++) acc[i] = f32x2{static_cast<float>(acc64[i][0]), static_cast<float>(acc64[i][1])};
     } else {
@@ -819,6 +840,61 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
     store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
 }
 
+// ... with an fp64 accumulator: the partial sums meet in LDS as doubles (twice the room: launch_period_plan)
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0>
+__device__ __forceinline__ void fir_tile_parts64(KParams pp, const double *__restrict__ rows, KDesc dp, float *xs, uint32_t xshift,
+                                                 uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit) {
+  constexpr int CF = ONE_GROUP ? CT : 2 * CGF;
+  LaneCtx c;
+  uint32_t g, part, gw, wg, parts;
+  bool valid;
+  double acc[R][2];
+#pragma unroll
+  for (int i = 0; i < R; i++) acc[i][0] = acc[i][1] = 0.0;
+  {
+    const PeriodParams p = load_k(pp);
+    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF>(p, xshift, m_lo, m_cnt, lane);
+    wg = p.wave_groups;
+    parts = p.ksplit;
+    part = 0;
+    gw = wave;
+    while (gw >= wg) {  // (wave-uniform; parts <= 16)
+      gw -= wg;
+      part++;
+    }
+    g = zsplit * wg + gw;
+    valid = g < p.groups;
+    if (valid) fir_group64<R, CT, PADDED, CF>(p, rows, xs, c, g, (p.skip & 4u) != 0, part, parts, acc);
+  }
+  __syncthreads();  // every wave is done with the window
+  double *sums = reinterpret_cast<double *>(xs);
+  if (valid && part != 0) {
+    double *mine = sums + (static_cast<size_t>(part - 1) * wg + gw) * (2 * R * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      mine[(2 * i) * 64] = acc[i][0];
+      mine[(2 * i + 1) * 64] = acc[i][1];
+    }
+  }
+  __syncthreads();
+  if (!valid || part != 0) return;
+  for (uint32_t j = 1; j < parts; j++) {
+    const double *theirs = sums + (static_cast<size_t>(j - 1) * wg + gw) * (2 * R * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      acc[i][0] += theirs[(2 * i) * 64];
+      acc[i][1] += theirs[(2 * i + 1) * 64];
+    }
+  }
+  const PeriodParams q = load_k(pp);
+  if ((q.skip & 8u) || !c.live) return;
+  const StreamDesc d = load_k(dp);
+  f32x2 out[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) out[i] = f32x2{static_cast<float>(acc[i][0]), static_cast<float>(acc[i][1])};
+  store_group<R, CT, ONE_GROUP, T>(q, d, c, g, out);
+}
+
 // (Mono int16 left through an LDS image -- one row per period, whole rows written 16 bytes per lane -- from
 //  round 1 to round 3 for launches that fill the chip: 160 -> 138 us for 32 streams of 44.1k -> 48k when a lane's
 //  20-byte runs cost five stores.  With the runs packed into dwords at either alignment (store_group) the
@@ -923,8 +999,12 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
     const __attribute__((address_space(4))) KernArgs *ka =
         (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const KDesc dp = &ka->pack.d[blockIdx.y];
-    fir_tile_parts<R, CT, ONE_GROUP, PADDED, T, CGF, W16, AM == 2>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
-                                                                  threadIdx.x & 63u, blockIdx.z);
+    if constexpr (AM == 1)
+      fir_tile_parts64<R, CT, ONE_GROUP, PADDED, T, CGF>(&ka->p, reinterpret_cast<const double *>(rows), dp, xs, wg.xshift, m_lo,
+                                                         m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
+    else
+      fir_tile_parts<R, CT, ONE_GROUP, PADDED, T, CGF, W16, AM == 2>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
+                                                                    threadIdx.x & 63u, blockIdx.z);
     return;
   } else {
   if (wave >= p.wave_groups) return;  // staging helpers (see launch_period): no phase group of their own
@@ -942,7 +1022,7 @@ hipError_t launch_rc(const PeriodParams &p, const DescPack *pack, dim3 grid, uin
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   constexpr bool kParts = false;
 #else
-  constexpr bool kParts = KS && (AM == 2 || (AM == 0 && FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available));
+  constexpr bool kParts = KS && (AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available);
 #endif
   if constexpr (KS && !kParts) {  // (no ISA loop for this layout: the host never asks for tap-range shares of it)
     return hipErrorInvalidValue;
