@@ -69,6 +69,8 @@ declare class SpeexResampler {
     /** mid-stream control (speex_resampler_set_rate / set_quality / skip_zeros / reset_mem) */
     setRate(inRate: number, outRate: number): void;
     setQuality(quality: number): void;
+    /** 'fast' (default, +-1 LSB, fp64 sums at quality 9 / 10), 'exact' (bit-identical to the reference) or 'fast_f32' */
+    setMode(mode: 'fast' | 'exact' | 'fast_f32'): void;
     skipZeros(): void;
     resetMem(): void;
     /** filter delay in frames at the input rate / at the output rate */

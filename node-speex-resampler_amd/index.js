@@ -171,6 +171,19 @@ class SpeexResampler {
     this.quality = quality;
   }
 
+  /**
+   * Arithmetic of this instance's kernels: 'fast' (default; every sample within +-1 LSB of the reference, fp64 sums
+   * where the reference has them: quality 9 and 10), 'exact' (bit-identical to the reference, slower), 'fast_f32'
+   * (one fp32 FMA chain for every filter: the fast path of the first releases).  The environment variable
+   * SPEEXHIP_MODE sets the initial mode of every instance.
+   */
+  setMode(mode) {
+    this._refuseWhileAsyncPending('setMode');
+    const code = { fast: 0, exact: 1, fast_f32: 2 }[mode];
+    if (code === undefined) throw new Error("mode must be 'fast', 'exact' or 'fast_f32'");
+    speexModule.setMode(this._ensureNative(), code);
+  }
+
   /** Start half a filter in, so the stream does not begin with the filter's ramp-up. */
   skipZeros() {
     this._refuseWhileAsyncPending('skipZeros');

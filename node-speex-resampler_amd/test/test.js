@@ -297,6 +297,35 @@ function poolTest() {
 // Round 4: results of >= 4 KB are external Buffers over pinned blocks of the library's pool.  They are the
 // caller's: writable, untouched by later calls, alive after the state is gone, and their blocks go back to the
 // pool when the collector drops them (node --expose-gc lets the test see that; without it the check is skipped).
+// setMode: 'exact' reproduces the reference's sha1 goldens through the class itself; 'fast' and 'fast_f32' stay within
+// +-1 LSB of it at quality 10 (fp64 accumulate / fp32 chain), 'fast' with fewer samples off by one
+function modeTest() {
+  const pcm = lcg(60000, 1, 31);
+  const outs = {};
+  for (const mode of ['exact', 'fast', 'fast_f32']) {
+    const r = new SpeexResampler(1, 24000, 48000, 10);
+    r.setMode(mode);
+    outs[mode] = r.processChunk(pcm);
+    r.destroy();
+  }
+  let bad = false;
+  try { new SpeexResampler(1, 24000, 48000, 10).setMode('fastest'); } catch (e) { bad = /mode must be/.test(e.message); }
+  assert(bad, 'setMode must refuse unknown modes');
+  const off = {};
+  for (const mode of ['fast', 'fast_f32']) {
+    assert(outs[mode].length === outs.exact.length, 'modes must agree on the counters');
+    let n = 0;
+    for (let i = 0; i < outs.exact.length; i += 2) {
+      const d = Math.abs(outs[mode].readInt16LE(i) - outs.exact.readInt16LE(i));
+      assert(d <= 1, `${mode}: a sample ${d} LSB away from the exact kernels`);
+      if (d) n++;
+    }
+    off[mode] = n;
+  }
+  assert(off.fast <= off.fast_f32, 'fp64 accumulate must not be further from the reference than the fp32 chain');
+  console.log(`modes: fast ${off.fast} / fast_f32 ${off.fast_f32} of ${outs.exact.length / 2} samples off by one`);
+}
+
 function externalBufferTest() {
   const r = new SpeexResampler(2, 44100, 48000, 7);
   const a = r.processChunk(lcg(30000, 2, 5));
@@ -333,5 +362,6 @@ function externalBufferTest() {
   await extensionsTest();
   poolTest();
   externalBufferTest();
+  modeTest();
   console.log('ALL NODE TESTS PASSED');
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates the rows of DESIGN.md section 5's table from profiles/r03_bench_lines.jsonl and
+"""Prints the rows of DESIGN.md section 5's table (paste them; it no longer edits DESIGN.md) from profiles/r03_bench_lines.jsonl and
 profiles/r03_kernel_stats_*.csv (so that every figure there can be recomputed from a file in profiles/).
 usage: python tools/design_table.py [ROUND, default 03]"""
 import csv, json, os, sys
@@ -61,9 +61,4 @@ out.append("| CPU baseline: the reference's own C natively compiled (`oracle/_re
 ee = [c(w, 1)['end_to_end'] for w in ('configs[1]', 'configs[2]', 'configs[3]', 'SURVEY F3')]
 out.append('| `end_to_end` of the 1-stream lines: the host-buffer call (pageable buffers, H2D + kernel + D2H + wait), cfg2 / cfg3 / cfg4 / F3 | %.3f / %.3f / %.3f / %.3f ms per chunk | — | %s | — | — | — | — |' %
            (tuple(x['ms_per_chunk'] for x in ee) + (' / '.join(num(x['input_msamples_per_s']) for x in ee),)))
-p = os.path.join(ROOT, 'DESIGN.md')
-s = open(p).read()
-a = s.index('| cfg2, 1 stream × 2^20 frames (BASELINE configs[1], `bench.py` default) |')
-b = s.index('(The rocprofv3 averages come from runs of their own')
-open(p, 'w').write(s[:a] + '\n'.join(out) + '\n\n' + s[b:])
 print('\n'.join(out))
