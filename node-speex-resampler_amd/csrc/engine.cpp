@@ -949,8 +949,10 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
     } else if (fast && acc64() && !period_.usable && slide64_.usable) {
       e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, &pack, n, float_io, stream);
     } else if (fast && period_pp_.usable &&
-               period_launch_prefers_pp(filter_, (!float_io && !float_seen_ && period_w16_.usable) ? period_w16_ : period_, descs, n)) {
-      // mono, wide windows: phase pairs (one period per lane, half the window per tile) where this launch gains
+               period_launch_prefers_pp(filter_, (!float_io && !float_seen_ && period_w16_.usable) ? period_w16_ : period_,
+                                        (!float_io && !float_seen_ && period_pp_w16_.usable) ? period_pp_w16_ : period_pp_, descs, n)) {
+      // up to three channels, wide windows: phase pairs (lane = (period, channel), half the window per tile) where this
+      // launch gains
       const bool w16 = !float_io && !float_seen_ && period_pp_w16_.usable;
       e = launch_period(filter_, w16 ? period_pp_w16_ : period_pp_, w16 ? d_period_pp_w16_rows_ : d_period_pp_rows_, nullptr,
                         nullptr, channels_, descs, &pack, n, float_io, stream);

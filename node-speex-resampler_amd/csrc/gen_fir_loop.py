@@ -357,11 +357,12 @@ class VariantPP(Variant):
     per FMA.  Same SGPR homes as the fp32 scheme with 2S steps; a bank is S steps of 2R taps; the bank's samples sit
     in the low halves of aligned VGPR pairs (one pair per step).  W16: an int16 window, converted behind the wait."""
 
-    def __init__(self, R, S, padded, w16):
-        Variant.__init__(self, R, 2 * S, 1, 1, padded, w16)
+    def __init__(self, R, S, CF, padded, w16):
+        # CF: samples per frame = channels (1, 2, 3): a lane is (period, channel), its samples CF elements apart
+        Variant.__init__(self, R, 2 * S, 1, CF, padded, w16)
         self.S = S
         self.vbase = {10: 56, 5: 64}[R]
-        self.name = "PP_R%d_S%d_P%d_W%d" % (R, S, int(padded), int(w16))
+        self.name = "PP_R%d_S%d_CF%d_P%d_W%d" % (R, S, CF, int(padded), int(w16))
 
     def reg(self, k):           # step k (0 .. 2S-1) of a trip: the sample in the low half of v[reg : reg+1]
         return self.vbase + 2 * k
@@ -384,7 +385,7 @@ class VariantPP(Variant):
         out = []
         for u in range(self.S):
             k = u if which == "A" else self.S + u
-            o = (first_step + u) * self.eb
+            o = (first_step + u) * self.CF * self.eb
             out.append("ds_read_%s v%d, %%[addr] offset:%d" % ("i16" if self.w16 else "b32", self.reg(k), o))
         return out
 
@@ -397,7 +398,7 @@ class VariantPP(Variant):
     def loop(self, label, cnt, lo, hi):
         S, R = self.S, self.R
         bank_bytes = 4 * S * 2 * R
-        adv = 2 * S * self.eb
+        adv = 2 * S * self.CF * self.eb
         body = ["s_sub_u32 %%[%s], %%[%s], 1" % (cnt, cnt), "s_cbranch_scc1 %d1f" % label, "%d0:" % label]
         body += ["s_waitcnt lgkmcnt(0)"] + self.tap_loads("B", bank_bytes) + self.sample_reads("B", S)
         body += self.converts("A") + self.fma_bank("A", lo, hi)
@@ -427,7 +428,7 @@ class VariantPP(Variant):
             ins += ['[advpad] "s"(adv_pad)', '[wrapstep] "s"(wrap_step)']
         clob = ['"s%d"' % r for r in bank_regs(self.banks["A"]) + bank_regs(self.banks["B"])] + ['"v%d"' % r for r in self.vgprs()]
         return '''template <>
-struct FirLoopAsmPP<%d, %s, %s> {
+struct FirLoopAsmPP<%d, %d, %s, %s> {
   static constexpr bool available = true;
   static constexpr int steps_per_bank = %d;
   // as FirLoopAsm::run; acc[i] = phases 2i and 2i + 1 of the lane's period; rows_g: [trip][step][2R] floats
@@ -442,7 +443,7 @@ struct FirLoopAsmPP<%d, %s, %s> {
       : %s, "scc", "memory");
   }
 };
-''' % (R, "true" if self.padded else "false", "true" if self.w16 else "false", self.S, R, asm,
+''' % (R, self.CF, "true" if self.padded else "false", "true" if self.w16 else "false", self.S, R, asm,
        ", ".join(outs), ", ".join(ins), ", ".join(clob))
 
     def lines(self):
@@ -456,10 +457,11 @@ struct FirLoopAsmPP<%d, %s, %s> {
 
 def variants_pp():
     out = []
-    for w16 in (False, True):
-        for padded in (False, True):
-            out.append(VariantPP(10, 1, padded, w16))
-        out.append(VariantPP(5, R5_STEPS // 2, False, w16))
+    for CF in (1, 2, 3):
+        for w16 in (False, True):
+            for padded in (False, True):
+                out.append(VariantPP(10, 1, CF, padded, w16))
+            out.append(VariantPP(5, R5_STEPS // 2, CF, False, w16))
     return out
 
 
@@ -508,8 +510,8 @@ struct FirLoopAsm64 {
 
 
 HEADPP = '''
-// ---- phase pairs for single-channel lanes (round 4; gen_fir_loop.py, VariantPP) ----
-template <int R, bool PADDED, bool W16>
+// ---- phase pairs: lane = (period, channel), two phases per packed FMA (round 4; gen_fir_loop.py, VariantPP) ----
+template <int R, int CF, bool PADDED, bool W16>
 struct FirLoopAsmPP {
   static constexpr bool available = false;
 };

@@ -78,10 +78,11 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
                        bool pp = false);
 PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16 = false,
                          bool a64 = false, bool pp = false);
-// Does this mono filter get phase-pair plans beside its two-period ones (wide windows: num >= 320), and should THIS
-// launch run over them?  `two` = the two-period plan the launch would take otherwise (kernels_period.hip).
+// Does this filter of up to three channels get phase-pair plans beside its other ones (wide windows: num >= 320), and
+// should THIS launch run over `pp`?  `two` = the plan the launch would take otherwise (kernels_period.hip).
 bool period_wants_pp_plans(const FilterSpec &f, uint32_t channels);
-bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const StreamDesc *h_descs, uint32_t n_streams);
+bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const PeriodPlan &pp, const StreamDesc *h_descs,
+                              uint32_t n_streams);
 // The int16-window plan of a filter whose float plan is `t`, .usable only where it pays: at least 5/4 of the
 // periods per tile (the loop converts every sample it reads: ~20 % more vector instructions per tile).
 PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_budget, const PeriodPlan &t);

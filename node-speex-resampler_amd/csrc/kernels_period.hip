@@ -76,12 +76,12 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // mono 48k -> 11.025k has 640 frames per period) -- at twice the tap bytes per FMA and half the FMAs between two
   // waits of the loop.  Planned beside the two-period plans for wide windows; chosen per launch
   // (period_launch_prefers_pp).
-  t.pp = pp && !a64 && channels == 1;
+  t.pp = pp && !a64 && channels <= 3;  // (lane = (period, channel): mono, stereo, three channels)
   // steps per loop iteration (two banks); the fp64 loop's banks hold half as many taps (doubles in the same SGPRs),
   // and so do the phase-pair loop's (two phases per packed FMA)
   const uint32_t it_steps = 2 * bank_taps(t.r) / t.r / ((a64 || t.pp) ? 2 : 1);
   const uint32_t gw = t.pp ? 2 * t.r : t.r;  // phases per group
-  t.ct = (channels % 2 == 0) ? 2 : 1;
+  t.ct = (channels % 2 == 0 && !t.pp) ? 2 : 1;
   t.cgroups = channels / t.ct;
   t.groups = (f.den + gw - 1) / gw;
   uint32_t dmax = 0;  // largest shift of a row inside its group
@@ -190,7 +190,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   t.usable = f.den >= 7 && t.cgroups <= 64 && 4 * t.lane_periods >= full && t.window_bytes <= lds_budget;
   // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py); so are the
   // tap rows of an fp64 accumulator
-  if ((w16 || a64) && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1))) t.usable = false;
+  if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1))) t.usable = false;
   if (a64 && w16) t.usable = false;
   if (t.pp && t.pad != 0 && t.r != 10) t.usable = false;
   return t;
@@ -301,9 +301,13 @@ uint32_t split_count(const PeriodPlan &t, uint32_t tiles, uint32_t n_streams, ui
   return splits;
 }
 
+// probe != null: the launch's shape only (tiles, shares, waves), nothing is launched
+struct PeriodShape {
+  uint32_t tiles, splits, wave_groups, ksplit, threads;
+};
 hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
                               const StreamDesc *h_descs, const DescPack *pack,
-                              uint32_t n_streams, bool float_io, hipStream_t stream);
+                              uint32_t n_streams, bool float_io, hipStream_t stream, PeriodShape *probe = nullptr);
 }  // namespace
 
 // Which window for an int16 launch of a ratio that has both?  The int16 window's tiles hold twice the periods
@@ -341,16 +345,45 @@ bool period_launch_prefers_w16(const FilterSpec &f, const PeriodPlan &t, bool ha
 // never / whenever planned.
 bool period_wants_pp_plans(const FilterSpec &f, uint32_t channels) {
   static const int env_pp = std::getenv("SPEEXHIP_PP") ? std::atoi(std::getenv("SPEEXHIP_PP")) : -1;
-  if (channels != 1 || env_pp == 0) return false;
+  if (channels > 3 || env_pp == 0) return false;
+  // (a full tile of the other lanes -- 128 periods of mono, 64 of stereo, 42 of three channels -- is 512 num bytes
+  //  of window: from num = 320 it cannot share a CU)
   return env_pp == 1 || static_cast<size_t>(f.num) * 4 * 128 >= 160 * 1024;
 }
-bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const StreamDesc *h_descs, uint32_t n_streams) {
+bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const PeriodPlan &pp, const StreamDesc *h_descs,
+                              uint32_t n_streams) {
   static const int env_pp = std::getenv("SPEEXHIP_PP") ? std::atoi(std::getenv("SPEEXHIP_PP")) : -1;
   if (env_pp >= 0) return env_pp != 0;
-  const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
-  const uint64_t tiles = static_cast<uint64_t>((max_periods + two.lane_periods - 1) / two.lane_periods) * n_streams;
-  if (tiles <= device_compute_units()) return n_streams >= 2;  // (one stream: -15 % ... +18 %, no pattern: two-period stays)
-  return 4 * two.lane_periods < 3 * 128;                       // several generations: only where lanes go unused
+  const uint32_t cus = device_compute_units();
+  const uint32_t slots = 64 / two.cgroups * (two.ct == 1 ? 2 : 1);  // periods a full tile of the other plan holds
+  const bool unfilled = 4 * two.lane_periods < 3 * slots;
+  if (two.cgroups == 1 && two.ct == 1) {  // mono (profiles/r04_pp_ab2.txt)
+    const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
+    const uint64_t tiles = static_cast<uint64_t>((max_periods + two.lane_periods - 1) / two.lane_periods) * n_streams;
+    if (tiles <= cus) return n_streams >= 2;  // (one stream: -15 % ... +18 %, no pattern: two-period stays)
+    return unfilled;                          // several generations: only where lanes go unused
+  }
+  // Stereo and three channels (profiles/r04_pp_ab3.txt): phase pairs win where they keep at least as many waves on a
+  // SIMD as the other lanes would and at least ~4 -- their loop has 10 packed FMAs between two waits, not 20: at two
+  // waves per SIMD stereo 48k->11.025k took 160 us instead of 79 --, in batches of about a generation (48k->22.05k
+  // 62.8 -> 40.9 us, 44.1k->8k 72.7 -> 52.2, three channels 44.1k->32k 117.8 -> 66.2; 8 streams 25-44 -> 16-26), and
+  // in longer launches only with twice that and lanes the other plan leaves unused (three channels 44.1k->32k, 32 x 2^20
+  // frames: 642 -> 459 us; 44.1k->16k at 4 waves per SIMD lost, 578 -> 681).
+  if (n_streams < 2) return false;
+  PeriodShape so{}, sp{};
+  if (launch_period_plan(f, two, nullptr, two.ct * two.cgroups, h_descs, nullptr, n_streams, false, nullptr, &so) != hipSuccess ||
+      launch_period_plan(f, pp, nullptr, pp.cgroups, h_descs, nullptr, n_streams, false, nullptr, &sp) != hipSuccess)
+    return false;
+  auto waves_per_simd = [&](const PeriodPlan &t, const PeriodShape &sh) {
+    const uint64_t wgs = static_cast<uint64_t>(sh.tiles) * n_streams * sh.splits;
+    const uint64_t per_cu = (wgs + cus - 1) / cus;
+    const uint64_t fit = std::max<uint64_t>(1, std::min<uint64_t>((160 * 1024) / std::max<size_t>(t.window_bytes, 1), 32 / std::max<uint32_t>(sh.threads / 64, 1)));
+    return static_cast<double>(std::min(per_cu, fit)) * sh.wave_groups * sh.ksplit / 4.0;
+  };
+  const double wo = waves_per_simd(two, so), wp = waves_per_simd(pp, sp);
+  if (wp < 3.5 || wp < wo) return false;
+  const uint64_t wgs_other = static_cast<uint64_t>(so.tiles) * n_streams * so.splits;
+  return wgs_other <= 2ull * cus || (unfilled && wp >= 6.0);
 }
 
 // `fine` (may be null / unusable): the same filter planned with R = 5.  A launch that is a single
@@ -374,7 +407,7 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
 namespace {
 hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
                               const StreamDesc *h_descs, const DescPack *pack,
-                              uint32_t n_streams, bool float_io, hipStream_t stream) {
+                              uint32_t n_streams, bool float_io, hipStream_t stream, PeriodShape *probe) {
   const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
   const uint32_t resident = 2 * device_compute_units();  // two workgroups fit per CU
@@ -495,7 +528,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   const bool isa_layout = false;  // (the A/B library without the ISA loop has no tap-range shares either)
 #else
-  const bool isa_layout = (t.ct == 1 && t.cgroups == 1) || (t.ct == 2 && t.cgroups <= 4);
+  const bool isa_layout = t.pp || (t.ct == 1 && t.cgroups == 1) || (t.ct == 2 && t.cgroups <= 4);
 #endif
   if (splits > 1 && env_ksplit != 0 && isa_layout && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
     uint32_t parts = env_ksplit > 0 ? static_cast<uint32_t>(env_ksplit) : max_waves / wave_groups;
@@ -515,6 +548,10 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   const uint32_t threads =
       (p.ksplit > 1 ? wave_groups * p.ksplit : helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
   p.threads = threads;
+  if (probe != nullptr) {
+    *probe = PeriodShape{tiles, splits, wave_groups, p.ksplit, threads};
+    return hipSuccess;
+  }
   // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8
   // when a tile is split: workgroups whose linear ids differ by a multiple of 8 share an XCD, so
   // the `splits` workgroups that stage the same input window hit in that XCD's L2 instead of

@@ -508,14 +508,14 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
   }
 }
 
-// Phase pairs (round 4; FirLoopAsmPP): single-channel lanes with one period and 2R phases -- acc[i] = phases 2i, 2i + 1
-// of group g.  rows: [group][trip][step][2R] floats; trips of 2 * steps_per_bank steps (2 for R = 10, 6 for R = 5).
+// Phase pairs (round 4; FirLoopAsmPP): a lane is (period, channel) -- one period, ONE channel of a frame of CF = 1, 2
+// or 3 -- with 2R phases: acc[i] = phases 2i, 2i + 1 of group g.  rows: [group][trip][step][2R] floats; trips of 2 * steps_per_bank steps (2 for R = 10, 6 for R = 5).
 // part / parts: tap-range shares (fir_tile_parts): this wave runs trips [total*part/parts, total*(part+1)/parts).
-template <int R, bool PADDED, bool W16>
+template <int R, int CF, bool PADDED, bool W16>
 __device__ __forceinline__ void fir_group_pp(const PeriodParams &p, const float *__restrict__ rows, const float *xs,
                                              const LaneCtx &c, uint32_t g, bool skip_all, uint32_t part, uint32_t parts,
                                              f32x2 (&acc)[R]) {
-  using Isa = FirLoopAsmPP<R, PADDED, W16>;
+  using Isa = FirLoopAsmPP<R, CF, PADDED, W16>;
   static_assert(Isa::available, "phase pairs run their ISA loop");
   constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
   constexpr uint32_t kPerIt = 4 / kStepsPerTrip;  // (the padded plan's boundary tables count 4-step iterations)
@@ -545,18 +545,24 @@ __device__ __forceinline__ void fir_group_pp(const PeriodParams &p, const float 
   }
   const float *rows_g = rows + (static_cast<size_t>(g) * p.l4 + t0) * (kStepsPerTrip * 2 * R);
   const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) +
-                        ((c.xlane + delta_g) + t0 * kStepsPerTrip + wraps * p.pad) * EB;
+                        ((c.xlane + delta_g * CF) + t0 * kStepsPerTrip * CF + wraps * p.pad) * EB;
   const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
   const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
                                                         static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
   Isa::run(acc, rows_s, addr, sgpr(overlap(0, head)), sgpr(overlap(head, main_end)), sgpr(overlap(main_end, total)), sgpr(to_wrap),
-           sgpr(wrap_step), sgpr((kStepsPerTrip + p.pad) * EB));
+           sgpr(wrap_step), sgpr((kStepsPerTrip * CF + p.pad) * EB));
 }
 
-// ... and its stores: the lane's 2R phases of group g are 2R consecutive samples of a mono stream -- whole dwords
-// around at most two odd samples (the run may start on the upper half of a dword: k_shift odd, an odd den), float
-// runs as 16-byte pieces; a run cut by the call's ends or the last group's padding phases goes sample by sample.
-template <int R, typename T>
+// ... and its stores.  The lane's 2R phases of group g are 2R consecutive FRAMES of its channel.  Mono: 2R consecutive
+// samples -- whole dwords around at most two odd samples (the run may start on the upper half of a dword: k_shift
+// odd, an odd den), float runs as 16-byte pieces.  Stereo: the two lanes of a frame (left, right: neighbours) swap
+// halves by DPP (quad_perm [1,0,3,2]) so that the left lane holds the first R frames whole and the right lane the
+// last R: R dwords (int16) or 2R floats each.  Three channels, and any run cut by the call's ends or the last group's
+// padding phases: sample by sample.
+__device__ __forceinline__ uint32_t pp_pair_swap(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0xB1, 0xF, 0xF, true));
+}
+template <int R, int CF, typename T>
 __device__ __forceinline__ void store_group_pp(const PeriodParams &p, const StreamDesc &d, const LaneCtx &c, uint32_t g,
                                                const f32x2 (&acc)[R]) {
   constexpr int N = 2 * R;
@@ -564,8 +570,54 @@ __device__ __forceinline__ void store_group_pp(const PeriodParams &p, const Stre
   const int64_t lo64 = k0 < 0 ? -k0 : 0;
   const int64_t hi64 = min(static_cast<int64_t>(N), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * N,
                                                        static_cast<int64_t>(d.n_out) - k0));
-  G<T> *o = out_ptr<T>(d) + k0;
-  if constexpr (sizeof(T) == 2) {
+  G<T> *o = out_ptr<T>(d) + k0 * CF + c.cg;
+  if constexpr (CF == 2) {
+    // (both lanes of a pair take this branch or neither: same period, same group, same call)
+    if (lo64 == 0 && hi64 == N && (reinterpret_cast<uintptr_t>(d.out) & 3u) == 0) {
+      const bool right = c.cg != 0;
+      if constexpr (sizeof(T) == 2) {
+        int mine[N];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+          asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(mine[2 * i]) : "v"(acc[i].x));
+          asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(mine[2 * i + 1]) : "v"(acc[i].y));
+        }
+        uint32_t w[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+          const int theirs = static_cast<int>(pp_pair_swap(static_cast<uint32_t>(right ? mine[q] : mine[R + q])));
+          typedef short short2_t __attribute__((ext_vector_type(2)));
+          const short2_t pk = right ? __builtin_amdgcn_cvt_pk_i16(theirs, mine[R + q]) : __builtin_amdgcn_cvt_pk_i16(mine[q], theirs);
+          w[q] = __builtin_bit_cast(uint32_t, pk);
+        }
+        g_u32 *od = (g_u32 *)(out_ptr<int16_t>(d) + (k0 + (right ? R : 0)) * 2);
+#pragma unroll
+        for (int j = 0; j + 4 <= R; j += 4) *(g_u32x4_a4 *)(od + j) = u32x4_a4{w[j], w[j + 1], w[j + 2], w[j + 3]};
+        if constexpr (R % 4 >= 2) *(g_u32x2_a4 *)(od + R / 4 * 4) = u32x2_a4{w[R / 4 * 4], w[R / 4 * 4 + 1]};
+        if constexpr (R % 2 != 0) od[R - 1] = w[R - 1];
+      } else {
+        float mine[N];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+          mine[2 * i] = acc[i].x;
+          mine[2 * i + 1] = acc[i].y;
+        }
+        G<float> *of = out_ptr<float>(d) + (k0 + (right ? R : 0)) * 2;
+#pragma unroll
+        for (int q = 0; q + 1 < R; q += 2) {
+          const float t0 = __uint_as_float(pp_pair_swap(__float_as_uint(right ? mine[q] : mine[R + q])));
+          const float t1 = __uint_as_float(pp_pair_swap(__float_as_uint(right ? mine[q + 1] : mine[R + q + 1])));
+          *(G<f32x4_a4> *)(of + 2 * q) = right ? f32x4_a4{t0, mine[R + q], t1, mine[R + q + 1]} : f32x4_a4{mine[q], t0, mine[q + 1], t1};
+        }
+        if constexpr (R % 2 != 0) {
+          const float t0 = __uint_as_float(pp_pair_swap(__float_as_uint(right ? mine[R - 1] : mine[N - 1])));
+          *(G<f32x2_a4> *)(of + 2 * (R - 1)) = right ? f32x2_a4{t0, mine[N - 1]} : f32x2_a4{mine[R - 1], t0};
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (CF == 1 && sizeof(T) == 2) {
     if (lo64 == 0 && hi64 == N && (reinterpret_cast<uintptr_t>(d.out) & 1u) == 0) {
       g_u32 *od;
       if ((reinterpret_cast<uintptr_t>(o) & 2u) == 0) {
@@ -592,7 +644,7 @@ __device__ __forceinline__ void store_group_pp(const PeriodParams &p, const Stre
       }
       return;
     }
-  } else {
+  } else if constexpr (CF == 1) {
     if (lo64 == 0 && hi64 == N) {
       G<float> *of = (G<float> *)o;
 #pragma unroll
@@ -610,9 +662,9 @@ __device__ __forceinline__ void store_group_pp(const PeriodParams &p, const Stre
     if (i < lo64 || i >= hi64) continue;
     const float v = (i & 1) ? acc[i / 2].y : acc[i / 2].x;
     if constexpr (sizeof(T) == 4)
-      o[i] = v;
+      o[i * CF] = v;
     else
-      o[i] = static_cast<int16_t>(round_pack_pcm(v, 0.f) & 0xffffu);
+      o[i * CF] = static_cast<int16_t>(round_pack_pcm(v, 0.f) & 0xffffu);
   }
 }
 
@@ -686,7 +738,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
     const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime(), fir_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (AM == 2) {
-      fir_group_pp<R, PADDED, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, 0u, 1u, acc);
+      fir_group_pp<R, ONE_GROUP ? 1 : CGF, PADDED, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, 0u, 1u, acc);
     } else if constexpr (AM == 1) {
       // fp64 sums, then the reference's store of its double sum into a float (resample.c:417, :544)
       double acc64[R][2];
@@ -721,7 +773,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
         d = d0;
       if (q.prio & 2u) __builtin_amdgcn_s_setprio(2);
       if constexpr (AM == 2)
-        store_group_pp<R, T>(q, d, c, g, acc);
+        store_group_pp<R, ONE_GROUP ? 1 : CGF, T>(q, d, c, g, acc);
       else
         store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
       if (q.prio & 2u) set_fir_priority(q);
@@ -811,7 +863,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
     g = zsplit * wg + gw;
     valid = g < p.groups;
     if constexpr (PP) {
-      if (valid) fir_group_pp<R, PADDED, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, part, parts, acc);
+      if (valid) fir_group_pp<R, ONE_GROUP ? 1 : CGF, PADDED, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, part, parts, acc);
     } else {
       if (valid) fir_group_part<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, part, parts, acc);
     }
@@ -835,7 +887,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
   if ((q.skip & 8u) || !c.live) return;
   const StreamDesc d = load_k(dp);
   if constexpr (PP)
-    store_group_pp<R, T>(q, d, c, g, acc);
+    store_group_pp<R, ONE_GROUP ? 1 : CGF, T>(q, d, c, g, acc);
   else
     store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
 }

@@ -1,7 +1,7 @@
-// kernels_period_pp.hip -- the period kernel's phase-pair instances (round 4): mono streams with ONE period per lane
-// and two PHASES per packed FMA (FirLoopAsmPP, csrc/gen_fir_loop.py) where the CT = 1 instances of kernels_period.hip
-// give a lane two periods.  Half the LDS window per tile for the same 64 lanes: what the wide windows of
-// down-sampling ratios need.  Same arithmetic per output as the fp32 chain (one FMA per tap, same order):
+// kernels_period_pp.hip -- the period kernel's phase-pair instances (round 4): lane = (period, channel) for mono, stereo
+// and three channels, two PHASES per packed FMA (FirLoopAsmPP, csrc/gen_fir_loop.py) where the other instances give
+// the halves of a packed FMA to two periods (odd channel counts) or to the two channels of a pair.  Half the LDS window
+// per tile for the same 64 lanes: what the wide windows of down-sampling ratios need.  Same arithmetic per output as the fp32 chain (one FMA per tap, same order):
 // deps/speex/resample.c:331-384 / :438-496 with the effective taps, +-1 LSB.
 #ifdef SPEEXHIP_STAMPS
 #undef SPEEXHIP_STAMPS  // (the diagnostics stamps belong to the fp32 translation unit)
@@ -10,21 +10,29 @@
 
 namespace speexhip {
 
-hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
-                              dim3 grid, uint32_t threads, bool float_io, hipStream_t stream) {
-  if (!t.pp || t.a64 || t.ct != 1 || t.cgroups != 1 || (t.pad != 0 && t.r != 10) || (t.w16 && float_io)) return hipErrorInvalidValue;
-#define SPEEXHIP_PP_KS(RV, PADV, TV, W)                                                                                       \
-  return p.ksplit > 1 ? launch_rc<RV, 1, true, PADV, TV, 0, W, true, 2>(p, pack, grid, threads, t.window_bytes, stream) \
-                      : launch_rc<RV, 1, true, PADV, TV, 0, W, false, 2>(p, pack, grid, threads, t.window_bytes, stream)
-#define SPEEXHIP_PP(RV, PADV)                          \
-  {                                                    \
-    if (float_io) SPEEXHIP_PP_KS(RV, PADV, float, false); \
-    if (t.w16) SPEEXHIP_PP_KS(RV, PADV, int16_t, true);   \
-    SPEEXHIP_PP_KS(RV, PADV, int16_t, false);             \
+hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack, dim3 grid, uint32_t threads,
+                              bool float_io, hipStream_t stream) {
+  if (!t.pp || t.a64 || t.ct != 1 || t.cgroups > 3 || (t.pad != 0 && t.r != 10) || (t.w16 && float_io)) return hipErrorInvalidValue;
+  // ONE / CGV: mono is the one-group layout, stereo and three channels carry their frame as a compile-time constant
+#define SPEEXHIP_PP_KS(RV, ONE, CGV, PADV, TV, W)                                                                               \
+  return p.ksplit > 1 ? launch_rc<RV, 1, ONE, PADV, TV, CGV, W, true, 2>(p, pack, grid, threads, t.window_bytes, stream)         \
+                      : launch_rc<RV, 1, ONE, PADV, TV, CGV, W, false, 2>(p, pack, grid, threads, t.window_bytes, stream)
+#define SPEEXHIP_PP(RV, ONE, CGV, PADV)                          \
+  {                                                              \
+    if (float_io) SPEEXHIP_PP_KS(RV, ONE, CGV, PADV, float, false); \
+    if (t.w16) SPEEXHIP_PP_KS(RV, ONE, CGV, PADV, int16_t, true);   \
+    SPEEXHIP_PP_KS(RV, ONE, CGV, PADV, int16_t, false);             \
   }
-  if (t.r == 5) SPEEXHIP_PP(5, false)
-  if (t.pad == 0) SPEEXHIP_PP(10, false)
-  SPEEXHIP_PP(10, true)
+#define SPEEXHIP_PP_FRAME(ONE, CGV)               \
+  {                                               \
+    if (t.r == 5) SPEEXHIP_PP(5, ONE, CGV, false)    \
+    if (t.pad == 0) SPEEXHIP_PP(10, ONE, CGV, false) \
+    SPEEXHIP_PP(10, ONE, CGV, true)                  \
+  }
+  if (t.cgroups == 1) SPEEXHIP_PP_FRAME(true, 0)
+  if (t.cgroups == 2) SPEEXHIP_PP_FRAME(false, 2)
+  SPEEXHIP_PP_FRAME(false, 3)
+#undef SPEEXHIP_PP_FRAME
 #undef SPEEXHIP_PP
 #undef SPEEXHIP_PP_KS
 }

@@ -482,7 +482,7 @@ def test_generated_fir_loop_is_in_step_with_its_generator():
         assert max(v.vgprs()) < (64 if v.R == 10 else 128) and min(v.vgprs()) % 2 == 0, v.name
     # the phase-pair variants (round 4, mono): one packed FMA per PAIR of phases, the tap pair in an aligned SGPR
     # pair, the sample broadcast from the low half of an aligned VGPR pair; one sample read per step
-    assert len(gen.variants_pp()) == 6
+    assert len(gen.variants_pp()) == 18 and sorted(set(v.CF for v in gen.variants_pp())) == [1, 2, 3]
     for v in gen.variants_pp():
         lines = v.lines()
         loops = 3 if v.R == 10 else 1
@@ -509,7 +509,7 @@ def test_round4_planners_fp64_accumulate_and_phase_pairs():
     seen = {0: 0, 4: 0, 5: 0, 6: 0}
     for i in rates:
         for o in rates:
-            for q, ch in ((10, 1), (9, 2), (10, 3), (9, 8), (7, 1), (5, 1)):
+            for q, ch in ((10, 1), (9, 2), (10, 3), (9, 8), (7, 1), (5, 2), (6, 3), (7, 4)):
                 try:
                     base = speexhip.debug_plan(i, o, q, ch)
                     t = speexhip.debug_plan64(i, o, q, ch)
@@ -533,14 +533,15 @@ def test_round4_planners_fp64_accumulate_and_phase_pairs():
                         assert t["fast_path"] == 0
                 else:
                     num = i // np.gcd(i, o)
-                    wide = base["fast_path"] == 2 and num >= 320
+                    wide = base["fast_path"] == 2 and num >= 320 and ch <= 3    # lane = (period, channel): up to 3 channels
                     assert (t["fast_path"] == 6) == wide, (i, o, q, ch, base, t)
                     if wide:
-                        assert 16 <= t["lane_periods"] <= 64 and t["lds_bytes"] <= 150 * 1024, (i, o, q, ch, t)
+                        assert 64 // ch // 4 <= t["lane_periods"] <= 64 // ch and t["lds_bytes"] <= 150 * 1024, (i, o, q, ch, t)
                         assert t["last"] in (0,) or t["last"] <= 64, (i, o, q, ch, t)
     assert min(seen.values()) > 0, seen
     p64 = speexhip.debug_plan64
     assert p64(24000, 48000, 10, 1)["fast_path"] == 4 and p64(24000, 48000, 10, 1)["r_or_p"] == 8    # BASELINE configs[2]
     assert p64(44100, 48000, 10, 2)["fast_path"] == 5 and p64(44100, 48000, 10, 3)["fast_path"] == 0
     assert p64(44100, 48000, 7, 1)["fast_path"] == 0 and p64(48000, 22050, 7, 1)["fast_path"] == 6
+    assert 28 <= p64(48000, 22050, 7, 2)["lane_periods"] <= 32 and p64(44100, 32000, 7, 3)["lane_periods"] <= 21
     assert p64(48000, 11025, 7, 1)["last"] >= 60      # its int16 window: two workgroups per CU instead of one

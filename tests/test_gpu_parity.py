@@ -1664,11 +1664,12 @@ def test_owned_block_calls_return_the_bytes_of_the_copying_calls():
 
 
 def test_phase_pair_plans_for_mono_on_every_launch():
-    """Round 4: mono filters with wide windows (num >= 320) also get PHASE-PAIR plans -- a lane owns one period and two
-    phases per packed FMA (FirLoopAsmPP) instead of two periods, so a tile is 64 periods and half the window -- and a
-    launch takes them by a rule (period_launch_prefers_pp: batches that two-period tiles leave at most one per CU).
-    SPEEXHIP_PP=1 (read once per process) plans them for EVERY mono filter and runs every mono launch over them: the
-    mono cases of the golden, layout, tap-range-share, int16-window, packed-store and control tests, +-1 LSB."""
+    """Round 4: filters of one, two and three channels with wide windows (num >= 320) also get PHASE-PAIR plans -- a
+    lane is (period, channel) with two phases per packed FMA (FirLoopAsmPP) instead of two periods or a channel pair, so
+    a tile holds half the periods and half the window -- and a launch takes them by a rule (period_launch_prefers_pp:
+    batches that the other tiles leave at most one per CU).  SPEEXHIP_PP=1 (read once per process) plans them for EVERY
+    such filter and runs every launch of up to three channels over them: the golden, layout, tap-range-share, int16-
+    window, packed-store and control tests (stereo frames leave through a DPP swap of lane pairs), +-1 LSB."""
     import subprocess
     import sys
     env = dict(os.environ, SPEEXHIP_PP="1")
@@ -1680,7 +1681,12 @@ def test_phase_pair_plans_for_mono_on_every_launch():
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     # ... and by the rule: a batch of a wide-window decimator runs over them, one big stream does not; both match
     import torch
-    ch, i, o, q, S, F = 1, 44100, 8000, 7, 8, 131072
+    for ch, i, o, q, S, F in ((1, 44100, 8000, 7, 8, 131072), (2, 48000, 22050, 7, 8, 131072), (3, 44100, 16000, 5, 6, 100000)):
+        _pp_batch_against_the_oracle(ch, i, o, q, S, F)
+
+
+def _pp_batch_against_the_oracle(ch, i, o, q, S, F):
+    import torch
     b = speexhip.Batch(S, ch, i, o, q)
     x = np.stack([orc.lcg_pcm(F * ch, 70 + s).reshape(F, ch) for s in range(S)])
     d_in = torch.from_numpy(x).cuda()
@@ -1690,10 +1696,10 @@ def test_phase_pair_plans_for_mono_on_every_launch():
         used, made = b.process_device(d_in.data_ptr(), F * ch, F, d_out.data_ptr(), cap * ch, cap, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     out = d_out.cpu().numpy()
-    for s in (0, 3, 7):
+    for s in (0, S // 2, S - 1):
         ref = orc.Oracle(ch, i, o, q)
         ref.process(x[s], cap)
         want, wu = ref.process(x[s], cap)
         assert used[s] == wu and made[s] == want.shape[0]
-        assert_close(out[s, : made[s]], want, "phase pairs by rule, stream %d" % s)
+        assert_close(out[s, : made[s]], want, "phase pairs by rule, %d ch stream %d" % (ch, s))
     b.close()
