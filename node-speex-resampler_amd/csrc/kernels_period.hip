@@ -481,8 +481,9 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   const uint32_t wave_groups = std::min<uint32_t>((t.groups + splits - 1) / splits, max_waves);
   PeriodParams p;
   p.rows = d_rows;
-  p.delta = t.a64 ? reinterpret_cast<const uint32_t *>(reinterpret_cast<const double *>(d_rows) + t.rows_floats)
-                  : reinterpret_cast<const uint32_t *>(d_rows + t.rows_floats);
+  p.delta = d_rows == nullptr ? nullptr  // (a probe of the launch shape: period_launch_prefers_pp)
+            : t.a64           ? reinterpret_cast<const uint32_t *>(reinterpret_cast<const double *>(d_rows) + t.rows_floats)
+                              : reinterpret_cast<const uint32_t *>(d_rows + t.rows_floats);
   p.l4 = t.l4;
   p.groups = t.groups;
   p.num = f.num;
