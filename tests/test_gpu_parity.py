@@ -171,6 +171,23 @@ def test_error_paths_through_the_c_abi():
     assert r.info()["filt_len"] == 8
     with pytest.raises(ValueError):
         r.set_mode(5)
+    r.set_mode(speexhip.MODE_FAST_F32)
+    assert r.info()["mode"] == speexhip.MODE_FAST_F32
+    # round 4: the owned-block calls, release_stream and the block release refuse / ignore null arguments
+    import ctypes as C
+    L = speexhip.lib()
+    n_in, n_out, blk = C.c_uint32(4), C.c_uint32(16), C.POINTER(C.c_int16)()
+    assert L.speexhip_resampler_process_interleaved_int_take(None, None, C.byref(n_in), C.byref(n_out), C.byref(blk)) == speexhip.ERR_INVALID_ARG
+    assert L.speexhip_resampler_process_interleaved_int_take(r._h, None, None, C.byref(n_out), C.byref(blk)) == speexhip.ERR_INVALID_ARG
+    assert L.speexhip_resampler_process_interleaved_int_take(r._h, None, C.byref(n_in), C.byref(n_out), None) == speexhip.ERR_INVALID_ARG
+    assert L.speexhip_resampler_release_stream(None) == speexhip.ERR_INVALID_ARG and L.speexhip_batch_release_stream(None) == speexhip.ERR_INVALID_ARG
+    L.speexhip_block_release(None)
+    assert r.release_stream() is None          # nothing to release: no device-pointer call so far
+    # a NULL input of n frames is n frames of silence (resample.c:1001-1005), through the owned-block call too
+    a, used = r.process_take(np.zeros((0, 1), np.int16), 64)
+    assert a.shape == (0, 1) and used == 0
+    assert speexhip.strerror(speexhip.ERR_NO_BLOCK).startswith("No pinned result block")
+    r.close()
 
 
 def test_python_mirror_of_processChunk_applies_the_capacity_rule(golden):
