@@ -116,18 +116,21 @@ def lib():
         L.speexhip_batch_destroy.argtypes = [p]
         L.speexhip_batch_set_mode.restype = i32
         L.speexhip_batch_set_mode.argtypes = [p, i32]
-        for fn, st in ((L.speexhip_resampler_process_interleaved_int_take, C.c_int16),
-                       (L.speexhip_resampler_process_interleaved_float_take, C.c_float)):
-            fn.restype = i32
-            fn.argtypes = [p, C.c_void_p, pu32, pu32, C.POINTER(C.POINTER(st))]
-        L.speexhip_block_release.restype = None
-        L.speexhip_block_release.argtypes = [C.c_void_p]
-        L.speexhip_debug_device_clock.restype = i32
-        L.speexhip_debug_device_clock.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        L.speexhip_resampler_release_stream.restype = i32
-        L.speexhip_resampler_release_stream.argtypes = [p]
-        L.speexhip_batch_release_stream.restype = i32
-        L.speexhip_batch_release_stream.argtypes = [p]
+        # (an older build of the library loaded through SPEEXHIP_LIB_PATH for a same-box A/B lacks the entry points
+        #  of later rounds: they stay unbound there)
+        if hasattr(L, "speexhip_block_release") or "SPEEXHIP_LIB_PATH" not in os.environ:
+            for fn, st in ((L.speexhip_resampler_process_interleaved_int_take, C.c_int16),
+                           (L.speexhip_resampler_process_interleaved_float_take, C.c_float)):
+                fn.restype = i32
+                fn.argtypes = [p, C.c_void_p, pu32, pu32, C.POINTER(C.POINTER(st))]
+            L.speexhip_block_release.restype = None
+            L.speexhip_block_release.argtypes = [C.c_void_p]
+            L.speexhip_debug_device_clock.restype = i32
+            L.speexhip_debug_device_clock.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+            L.speexhip_resampler_release_stream.restype = i32
+            L.speexhip_resampler_release_stream.argtypes = [p]
+            L.speexhip_batch_release_stream.restype = i32
+            L.speexhip_batch_release_stream.argtypes = [p]
         L.speexhip_batch_get_info.restype = i32
         L.speexhip_batch_get_info.argtypes = [p, u32, C.POINTER(Info)]
         L.speexhip_batch_process_interleaved_int_device.restype = i32
