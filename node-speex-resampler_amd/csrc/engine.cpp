@@ -131,6 +131,11 @@ int ctl_download(void *dst, const char *base, size_t total, size_t off, size_t l
 
 const size_t kLdsBudget = 150 * 1024;  // of the CU's 160 KiB
 const size_t kDirectCopyBytes = 256 * 1024;  // host buffers at least this big skip the pinned bounce buffer
+// A piecewise host call (take_in_pieces) takes 2 MB of input per piece, at most four: a piece costs ~15 us (an event,
+// a cross-stream wait, a launch) and buys the overlap of its launch -- the result leaving through PCIe -- with the next
+// piece's copy.  2^20 stereo frames (4.2 MB in): 1 / 2 / 3 / 4 pieces 0.1935 / 0.1879 / 0.198 / 0.224 ms per call; 8
+// channels (16.8 MB in), four pieces: 0.617 -> 0.517 ms.
+const size_t kPieceBytes = static_cast<size_t>(2) << 20;
 const size_t kZeroCopyBelow = 720 * 1024;    // ... and calls whose buffers are smaller than this run on pinned memory alone
 }  // namespace
 
@@ -719,6 +724,8 @@ Batch::~Batch() {
   pool::device_put(device_, d_stage_out_);
   pool::pinned_put(h_pin_in_);
   pool::pinned_put(h_pin_out_);
+  for (int i = 0; i < kMaxPieces; i++) pool::event_put(device_, piece_ev_[i]);
+  pool::stream_put(device_, copy_stream_);
   pool::stream_put(device_, own_stream_);
 }
 
@@ -874,6 +881,49 @@ int Batch::process_split(const void *d_in, uint32_t *in_len, void *d_out, uint32
   return zero_mode_ ? SPEEXHIP_ERR_ALLOC_FAILED : SPEEXHIP_ERR_SUCCESS;
 }
 
+// The kernel for one launch of up to 32 stream descriptors (`descs` = pack.d): what the mode, the filter's plans and
+// the launch's size select.
+int Batch::launch_chunk(const StreamDesc *descs, const DescPack &pack, uint32_t n, uint32_t max_out, bool float_io,
+                        hipStream_t stream) {
+  hipError_t e;
+  const bool fast = mode_ != SPEEXHIP_MODE_EXACT;
+  if (zero_mode_) {
+    ExactGeometry geo = exact_geo_;  // (its window geometry belongs to the filter no longer in force)
+    geo.staged = false;
+    geo.lds_bytes = 0;
+    geo.outs_per_block = 256;
+    e = launch_exact(filter_, geo, d_table_, channels_, &pack, n, max_out, float_io, stream, nullptr, true);
+  } else if (fast && acc64() && period64_.usable) {
+    // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
+    e = launch_period(filter_, period64_, reinterpret_cast<const float *>(d_period64_rows_), &period64_fine_,
+                      reinterpret_cast<const float *>(d_period64_fine_rows_), channels_, descs, &pack, n, float_io, stream);
+  } else if (fast && acc64() && !period_.usable && slide64_.usable) {
+    e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, &pack, n, float_io, stream);
+  } else if (fast && period_pp_.usable &&
+             period_launch_prefers_pp(filter_, (!float_io && !float_seen_ && period_w16_.usable) ? period_w16_ : period_,
+                                      (!float_io && !float_seen_ && period_pp_w16_.usable) ? period_pp_w16_ : period_pp_, descs, n)) {
+    // up to three channels, wide windows: phase pairs (lane = (period, channel), half the window per tile) where this
+    // launch gains
+    const bool w16 = !float_io && !float_seen_ && period_pp_w16_.usable;
+    e = launch_period(filter_, w16 ? period_pp_w16_ : period_pp_, w16 ? d_period_pp_w16_rows_ : d_period_pp_rows_, nullptr,
+                      nullptr, channels_, descs, &pack, n, float_io, stream);
+  } else if (fast && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
+             (w16_always() || period_launch_prefers_w16(filter_, period_, period_fine_.usable, descs, n))) {
+    // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- unless
+    // the launch is too small for that to pay (period_launch_prefers_w16)
+    e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, &pack, n, false, stream);
+  } else if (fast && period_.usable) {
+    e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs, &pack, n,
+                      float_io, stream);
+  } else if (fast && slide_.usable) {
+    e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, &pack, n, float_io, stream);
+  } else {
+    e = launch_exact(filter_, exact_geo_, d_table_, channels_, &pack, n, max_out, float_io, stream);
+  }
+  if (hip_failed(e, "kernel launch")) return SPEEXHIP_ERR_DEVICE;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
 // Every stream from plans[s].begin to plans[s].end: one launch per 32 streams (kMaxPackedStreams: the descriptors
 // of a launch travel in its kernel arguments -- no descriptor copy, no dependent load in the kernels).  in_frames[s]
 // = frames readable at the stream's input pointer.
@@ -934,42 +984,8 @@ int Batch::run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_fr
       if (chain_rc != SPEEXHIP_ERR_SUCCESS) return chain_rc;
       chained = true;
     }
-    hipError_t e;
-    const bool fast = mode_ != SPEEXHIP_MODE_EXACT;
-    if (zero_mode_) {
-      ExactGeometry geo = exact_geo_;  // (its window geometry belongs to the filter no longer in force)
-      geo.staged = false;
-      geo.lds_bytes = 0;
-      geo.outs_per_block = 256;
-      e = launch_exact(filter_, geo, d_table_, channels_, &pack, n, max_out, float_io, stream, nullptr, true);
-    } else if (fast && acc64() && period64_.usable) {
-      // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
-      e = launch_period(filter_, period64_, reinterpret_cast<const float *>(d_period64_rows_), &period64_fine_,
-                        reinterpret_cast<const float *>(d_period64_fine_rows_), channels_, descs, &pack, n, float_io, stream);
-    } else if (fast && acc64() && !period_.usable && slide64_.usable) {
-      e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, &pack, n, float_io, stream);
-    } else if (fast && period_pp_.usable &&
-               period_launch_prefers_pp(filter_, (!float_io && !float_seen_ && period_w16_.usable) ? period_w16_ : period_,
-                                        (!float_io && !float_seen_ && period_pp_w16_.usable) ? period_pp_w16_ : period_pp_, descs, n)) {
-      // up to three channels, wide windows: phase pairs (lane = (period, channel), half the window per tile) where this
-      // launch gains
-      const bool w16 = !float_io && !float_seen_ && period_pp_w16_.usable;
-      e = launch_period(filter_, w16 ? period_pp_w16_ : period_pp_, w16 ? d_period_pp_w16_rows_ : d_period_pp_rows_, nullptr,
-                        nullptr, channels_, descs, &pack, n, float_io, stream);
-    } else if (fast && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
-               (w16_always() || period_launch_prefers_w16(filter_, period_, period_fine_.usable, descs, n))) {
-      // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- unless
-      // the launch is too small for that to pay (period_launch_prefers_w16)
-      e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, &pack, n, false, stream);
-    } else if (fast && period_.usable) {
-      e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs, &pack, n,
-                        float_io, stream);
-    } else if (fast && slide_.usable) {
-      e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, &pack, n, float_io, stream);
-    } else {
-      e = launch_exact(filter_, exact_geo_, d_table_, channels_, &pack, n, max_out, float_io, stream);
-    }
-    if (hip_failed(e, "kernel launch")) return SPEEXHIP_ERR_DEVICE;
+    const int lrc = launch_chunk(descs, pack, n, max_out, float_io, stream);
+    if (lrc != SPEEXHIP_ERR_SUCCESS) return lrc;
   }
   if (chained) hist_cur_ ^= 1;
   for (uint32_t s = 0; s < n_streams_; s++)
@@ -1006,6 +1022,88 @@ int Batch::ensure_stage(size_t dev_in, size_t dev_out, size_t pin_in, size_t pin
   return rc;
 }
 
+// A large owned-block call in `pieces` pieces (process_host_take).  Piece i: input frames [f_i, f_{i+1}) copied on
+// copy_stream_, an event behind the copy, and on own_stream_ -- waiting for that event -- one launch for the outputs
+// whose windows end inside the frames copied so far.  Output k of the call reads V-frames
+// [last0 + (frac0 + k*num) div den, ... + taps) (stream_plan.h), so the count is closed-form; a piece's descriptor is
+// the call's with the position advanced by its first output.  A tile's window may reach past the frames copied so far:
+// what it stages from there only feeds outputs of later pieces, which this launch does not store.
+int Batch::take_in_pieces(const void *in, uint32_t *in_len, uint32_t *out_len, bool float_io, void *blk, uint32_t pieces) {
+  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
+  const uint32_t frames = *in_len;
+  EntryRules rules;
+  rules.block_in = block_in();
+  rules.float_entry = float_io;
+  const CallPlan plan = plan_call(filter_.num, filter_.den, frames, *out_len, P(0, 0), rules);
+  if (frames != 0 && *out_len != 0) started_[0] = 1;
+  const size_t in_bytes = static_cast<size_t>(frames) * channels_ * es;
+  DrainOnExit drain(&own_stream_);
+  int rc = ensure_stage(in_bytes, 0, 0, 0);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  if (copy_stream_ == nullptr) HIP_TRY(pool::stream_get(device_, &copy_stream_));
+  DrainOnExit drain_copy(&copy_stream_);
+  for (uint32_t i = 0; i < pieces; i++)
+    if (piece_ev_[i] == nullptr) HIP_TRY(pool::event_get(device_, &piece_ev_[i]));
+  rc = chain_to(own_stream_);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  if (float_io) float_seen_ = true;
+  const uint32_t hist_frames = filter_.taps - 1 + plan.begin.magic;
+  const int64_t num = filter_.num, den = filter_.den;
+  // outputs (of the call's plan.produced) whose windows lie inside history + the first f input frames
+  auto outputs_within = [&](uint64_t f) -> uint32_t {
+    const int64_t x = static_cast<int64_t>(f) + hist_frames - filter_.taps - plan.begin.last;
+    if (x < 0) return 0;
+    const int64_t k = ((x + 1) * den - 1 - static_cast<int64_t>(plan.begin.frac)) / num;  // last such output
+    return static_cast<uint32_t>(std::min<int64_t>(k + 1, plan.produced));
+  };
+  uint32_t done_out = 0;
+  for (uint32_t i = 0; i < pieces; i++) {
+    const uint64_t f0 = static_cast<uint64_t>(frames) * i / pieces, f1 = static_cast<uint64_t>(frames) * (i + 1) / pieces;
+    const size_t off = static_cast<size_t>(f0) * channels_ * es, bytes = static_cast<size_t>(f1 - f0) * channels_ * es;
+    if (bytes != 0) HIP_TRY(hipMemcpyAsync(d_stage_in_ + off, static_cast<const char *>(in) + off, bytes, hipMemcpyHostToDevice, copy_stream_));
+    HIP_TRY(hipEventRecord(piece_ev_[i], copy_stream_));
+    HIP_TRY(hipStreamWaitEvent(own_stream_, piece_ev_[i], 0));
+    const bool last = i + 1 == pieces;
+    const uint32_t upto = last ? plan.produced : outputs_within(f1);
+    const uint32_t n_out = upto > done_out ? upto - done_out : 0;
+    if (n_out == 0 && !last) continue;
+    // the piece's first output: the call's position advanced by done_out outputs
+    const uint64_t adv = static_cast<uint64_t>(plan.begin.frac) + static_cast<uint64_t>(done_out) * filter_.num;
+    StreamPos at = plan.begin;
+    at.last = plan.begin.last + static_cast<int32_t>(adv / filter_.den);
+    at.frac = static_cast<uint32_t>(adv % filter_.den);
+    DescPack pack;
+    std::memset(&pack, 0, sizeof(pack));
+    StreamDesc &d = pack.d[0];
+    d.in = d_stage_in_;
+    d.hist = d_hist_[hist_cur_];
+    d.out = static_cast<char *>(blk) + static_cast<size_t>(done_out) * channels_ * es;
+    d.hist_next = d_hist_[hist_cur_ ^ 1];
+    d.in_frames = frames;
+    d.n_out = n_out;
+    d.consumed = plan.magic_used + plan.consumed;
+    d.hist_frames = hist_frames;
+    d.hist_keep = last ? filter_.taps - 1 + plan.end.magic : 0;  // (the history moves once, with the last piece)
+    d.last0 = at.last;
+    d.frac0 = at.frac;
+    d.k_shift = phase_index_of(filter_.num, filter_.den, at.frac);
+    d.base_shift = at.last - static_cast<int32_t>((static_cast<uint64_t>(d.k_shift) * filter_.num) / filter_.den);
+    d.tile_begin = 0;
+    d.m_total = static_cast<uint32_t>((static_cast<uint64_t>(d.k_shift) + d.n_out + filter_.den - 1) / filter_.den);
+    rc = launch_chunk(pack.d, pack, 1, n_out, float_io, own_stream_);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    done_out = upto;
+  }
+  hist_cur_ ^= 1;
+  HIP_TRY(hipStreamSynchronize(own_stream_));  // (behind the last launch, which waited for the last copy)
+  drain.armed = false;
+  drain_copy.armed = false;
+  for (uint32_t c = 0; c < channels_; c++) P(0, c) = plan.end;
+  *in_len = plan.consumed;
+  *out_len = plan.produced;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
 // Host buffer in, result in a pinned block the caller owns afterwards (the N-API addon wraps it in an external
 // Buffer: src/index.ts:111-115 returns a fresh, caller-owned Buffer, and so does this -- without the copy into it).
 // The kernel writes the block directly: small calls as before (they already wrote pinned memory, then the result
@@ -1034,9 +1132,20 @@ int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len
     }
   } guard{blk};
   int rc;
+  // Large calls in pieces (round 4): PCIe is full duplex, and with the kernel writing the result block itself the
+  // two directions belong to different engines -- the input copies run on a second stream, and behind each an event
+  // lets a launch for the outputs that piece completes start while the next piece is still arriving.  No kernel
+  // change: a piece is a StreamDesc of the same call that begins o_i outputs later (positions advanced in integers)
+  // and only the last one rolls the history.  SPEEXHIP_PIECES=1 turns it off, =n forces n (A/B, tests).
+  static const int env_pieces = std::getenv("SPEEXHIP_PIECES") ? std::atoi(std::getenv("SPEEXHIP_PIECES")) : 0;
+  uint32_t pieces = env_pieces > 0 ? static_cast<uint32_t>(env_pieces) : static_cast<uint32_t>(in_bytes / kPieceBytes);
+  pieces = std::min<uint32_t>(pieces, kMaxPieces);
   if (split || zero_mode_) {
     rc = process_host(in, in_len, blk, out_len, float_io);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
+  } else if (pieces >= 2 && in != nullptr && in_bytes >= kZeroCopyBelow) {
+    rc = take_in_pieces(in, in_len, out_len, float_io, blk, pieces);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   } else {
     DrainOnExit drain(&own_stream_);
     const bool direct_in = in_bytes >= kZeroCopyBelow;

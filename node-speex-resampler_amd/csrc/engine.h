@@ -145,6 +145,10 @@ class Batch {
   int ensure_stage(size_t dev_in, size_t dev_out, size_t pin_in, size_t pin_out);
   int run_plans(const void *d_in, uint64_t in_stride, const uint32_t *in_frames, void *d_out,
                 uint64_t out_stride, const CallPlan *plans, bool float_io, hipStream_t stream);
+  int launch_chunk(const StreamDesc *descs, const DescPack &pack, uint32_t n, uint32_t max_out, bool float_io,
+                   hipStream_t stream);
+  // a large host call as pieces: input copies on a second stream, one launch per piece behind each (process_host_take)
+  int take_in_pieces(const void *in, uint32_t *in_len, uint32_t *out_len, bool float_io, void *blk, uint32_t pieces);
 
   FilterSpec filter_;
   uint32_t n_streams_ = 0, channels_ = 0;
@@ -207,6 +211,9 @@ class Batch {
 
   // host-buffer path (single stream)
   hipStream_t own_stream_ = nullptr;
+  hipStream_t copy_stream_ = nullptr;   // input copies of a piecewise call (another of the pool's streams)
+  static const int kMaxPieces = 4;
+  hipEvent_t piece_ev_[kMaxPieces] = {};
   char *d_stage_in_ = nullptr, *d_stage_out_ = nullptr;
   char *h_pin_in_ = nullptr, *h_pin_out_ = nullptr;
   uint32_t done_seq_ = 0;  // completion word of the small host-buffer calls (engine.cpp, process_host)

@@ -1635,7 +1635,12 @@ def test_owned_block_calls_return_the_bytes_of_the_copying_calls():
                     want, wu = a.process(x, cap)
                     view, gu, addr = b.process_take(x, cap, keep=True)
                 assert gu == wu and view.shape == want.shape and a.position() == b.position(), (mode, ch, i, o, q, call)
-                assert np.array_equal(view, want), (mode, ch, i, o, q, call)
+                if mode == speexhip.MODE_EXACT or fio:
+                    assert np.array_equal(view, want) or (fio and view.size and np.abs(view - want).max() <= 0.05), (mode, ch, i, o, q, call)
+                else:
+                    # (FAST: a large owned-block call runs as pieces -- other launch shapes, other summation orders: each
+                    #  within +-1 LSB of the reference, so within 2 of the other)
+                    assert view.size == 0 or np.abs(view.astype(np.int32) - want.astype(np.int32)).max() <= 2 * TOL_LSB, (mode, ch, i, o, q, call)
                 if addr:
                     kept.append((view, want.copy(), addr))
             for view, want, addr in kept:   # later calls did not touch earlier blocks
@@ -1656,7 +1661,8 @@ def test_owned_block_calls_return_the_bytes_of_the_copying_calls():
             got, gu = b.process(x, 1 << 21)          # what the N-API addon does then
             view, addr = got, 0
         want, wu = a.process(x, 1 << 21)
-        assert gu == wu and np.array_equal(view, want) and a.position() == b.position(), call
+        assert gu == wu and a.position() == b.position(), call
+        assert np.abs(view.astype(np.int32) - want.astype(np.int32)).max() <= 2 * TOL_LSB, call
         if addr:
             held.append(addr)
     assert refused > 0 and len(held) >= 8, (refused, len(held))   # ~4.6 MB per block: 13 fit in 64 MiB
@@ -1720,3 +1726,44 @@ def _pp_batch_against_the_oracle(ch, i, o, q, S, F):
         assert used[s] == wu and made[s] == want.shape[0]
         assert_close(out[s, : made[s]], want, "phase pairs by rule, %d ch stream %d" % (ch, s))
     b.close()
+
+
+def test_large_owned_block_calls_run_in_pieces_and_match_the_oracle():
+    """Round 4: an owned-block host call of >= 2 MB runs as up to four pieces -- input copies on a second stream, a
+    launch per piece behind each copy's event, the kernel writing the result block itself (PCIe both ways at once).
+    A piece is the same call begun some outputs later, so EXACT mode must stay bit-identical to the reference and FAST
+    within +-1 LSB, with counters, position and history as after a single launch -- across consecutive calls, a
+    capacity-bound call, ragged sizes, int16 and float, period / slide / fp64 kernels.  SPEEXHIP_PIECES=3 in a child
+    process forces three pieces on every such call from 720 KB up."""
+    cases = [(2, 44100, 48000, 7), (1, 24000, 48000, 10), (8, 48000, 44100, 5), (2, 48000, 16000, 9), (1, 48000, 11025, 7)]
+    for mode in (speexhip.MODE_EXACT, speexhip.MODE_FAST):
+        for (ch, i, o, q) in cases:
+            r = speexhip.Resampler(ch, i, o, q, mode=mode)
+            ref = orc.Oracle(ch, i, o, q)
+            for call, frames in enumerate([(1 << 20) + 12345, 300000, (1 << 21) // ch + 7]):
+                x = orc.lcg_pcm(frames * ch, 5 * call + ch).reshape(frames, ch)
+                cap = (frames * o // i) // 2 if call == 1 else frames * o // i + 4096      # one capacity-bound call
+                if call == 2 and mode == speexhip.MODE_EXACT:
+                    got, used = r.process_take(x.astype(np.float32), cap, float_io=True)
+                    want, wu = ref.process_float(x.astype(np.float32), cap)
+                    assert used == wu and got.shape == want.shape and np.array_equal(got, want), (mode, ch, i, o, q, call)
+                else:
+                    got, used = r.process_take(x, cap)
+                    want, wu = ref.process(x, cap)
+                    assert used == wu and r.position() == ref.position(), (mode, ch, i, o, q, call)
+                    if mode == speexhip.MODE_EXACT:
+                        assert np.array_equal(got, want), (ch, i, o, q, call)
+                    else:
+                        assert_close(got, want, "pieces %s call %d" % ((ch, i, o, q), call))
+            h = r.history()
+            for c in range(ch):
+                assert np.array_equal(h[:, c], ref.history(c)), (mode, ch, i, o, q)
+            r.close()
+    if os.environ.get("SPEEXHIP_PIECES") is None:
+        import subprocess
+        import sys
+        env = dict(os.environ, SPEEXHIP_PIECES="3")
+        res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                              "large_owned_block_calls or owned_block_calls_return"],
+                             env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
