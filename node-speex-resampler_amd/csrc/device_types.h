@@ -92,6 +92,7 @@ struct PeriodParams {
   uint32_t prio;          // bit 0: prologue + staging at raised wave priority; bit 1: the stores too
   uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP), 0 in normal operation
   uint32_t ksplit;        // > 1: tap-range shares, this many waves per phase group (fir_tile_parts)
+  uint32_t touch;         // != 0: every workgroup fetches the tap rows into L2 beside its window (touch_rows)
 };
 
 }  // namespace speexhip

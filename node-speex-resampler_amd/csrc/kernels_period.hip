@@ -129,7 +129,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   }
   static const bool no_pad = std::getenv("SPEEXHIP_NO_PAD") != nullptr;
   if (no_pad) t.pad = 0;
-  if (std::getenv("SPEEXHIP_PAD")) t.pad = static_cast<uint32_t>(std::atoi(std::getenv("SPEEXHIP_PAD"))) & (w16 ? ~7u : ~3u);  // diagnostics
+  if (std::getenv("SPEEXHIP_PAD")) t.pad = static_cast<uint32_t>(std::atoi(std::getenv("SPEEXHIP_PAD"))) & ((w16 || t.ct == 2) ? ~1u : ~0u);  // diagnostics
   if (t.pad != 0 && t.r != 10) return t;  // (the padded walk below is written for 4-step iterations)
   if (t.pad != 0) {
     // A padded window is only walked cheaply if every period boundary a group's window crosses
@@ -378,7 +378,10 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
     const uint64_t wgs = static_cast<uint64_t>(sh.tiles) * n_streams * sh.splits;
     const uint64_t per_cu = (wgs + cus - 1) / cus;
     const uint64_t fit = std::max<uint64_t>(1, std::min<uint64_t>((160 * 1024) / std::max<size_t>(t.window_bytes, 1), 32 / std::max<uint32_t>(sh.threads / 64, 1)));
-    return static_cast<double>(std::min(per_cu, fit)) * sh.wave_groups * sh.ksplit / 4.0;
+    // (the tap-range shares of an UNSPLIT launch count only against a plan that leaves lanes unused: two half-chains
+    //  are not two chains -- stereo 48k->11.025k in phase pairs with them: 90 us against 79 the other way, whose tiles
+    //  are full; three channels, 18 of 42 periods per tile the other way: 32 x 2^20 frames 870 -> 400 us)
+    return static_cast<double>(std::min(per_cu, fit)) * sh.wave_groups * ((sh.splits > 1 || unfilled) ? sh.ksplit : 1u) / 4.0;
   };
   const double wo = waves_per_simd(two, so), wp = waves_per_simd(pp, sp);
   if (wp < 3.5 || wp < wo) return false;
@@ -514,6 +517,18 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   p.prio = static_cast<uint32_t>(env_prio);
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
+  // touch_rows (kernels_period_impl.h): where a launch is more than a generation of workgroups and its rows are
+  // large, the samples streaming through L2 push the rows out between two workgroups of a CU -- three channels
+  // 48k->11.025k, 32 x 2^20 frames: 494 -> 400 us with every workgroup fetching them again beside its window; 32 x
+  // 131 072 frames 91.5 -> 80.7.  Launches of one generation lose to it (cfg2 one stream 11.5 -> 12.3 us, mono
+  // 48k->11.025k 42.2 -> 45.2: profiles/r04_touch_ab.txt), small tables gain nothing (cfg2 32 streams 192.9 / 193.0).
+  static const int env_touch = std::getenv("SPEEXHIP_TOUCH") ? std::atoi(std::getenv("SPEEXHIP_TOUCH")) : -1;  // A/B
+  {
+    const size_t rows_bytes = t.rows_floats * (t.a64 ? 8 : 4);
+    const bool wanted = env_touch >= 0 ? env_touch != 0
+                                       : rows_bytes >= 256 * 1024 && 4ull * tiles * n_streams * splits >= 5ull * device_compute_units();
+    p.touch = wanted ? 1u : 0u;
+  }
   // A workgroup that owns only a share of the groups still stages the whole window: lend it the
   // waves it has no groups for, they leave after the staging barrier.
   static const int env_helpers = std::getenv("SPEEXHIP_HELPERS") ? std::atoi(std::getenv("SPEEXHIP_HELPERS")) : 1;
@@ -531,7 +546,17 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 #else
   const bool isa_layout = t.pp || (t.ct == 1 && t.cgroups == 1) || (t.ct == 2 && t.cgroups <= 4);
 #endif
-  if (splits > 1 && env_ksplit != 0 && isa_layout && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
+  // (Round 4, late: an UNSPLIT launch whose workgroups have at most 8 waves takes the shares too.  The FIR loop waits
+  //  ~500 cycles for every bank of taps -- a scalar load that misses to L2 -- and only other waves cover that: stamps of
+  //  32 x 131 072 frames of 3-channel 48k -> 11.025k, 8 waves per workgroup, one or two workgroups per CU: every
+  //  wave spends 355 000 cycles on 6 480 packed FMAs, 55 cycles each, whether it shares its CU or not
+  //  (profiles/r04_stamps_3ch_pp.txt).  Two waves per group: 157 -> 92 us; mono 48k -> 22.05k 35.5 -> 26.2,
+  //  3 channels 44.1k -> 16k 89 -> 61: profiles/r04_ks_ab.txt.)
+  static const bool unsplit_ks_off = std::getenv("SPEEXHIP_KS_UNSPLIT") && std::atoi(std::getenv("SPEEXHIP_KS_UNSPLIT")) == 0;  // A/B
+  // (R = 10 only: the R = 5 instances with shares take 76 VGPRs -- one 16-wave workgroup per CU where two of 8 waves
+  //  ran: stereo 44.1k->8k in phase pairs 52.5 -> 57 us)
+  const bool unsplit_ks = splits == 1 && t.r == 10 && !unsplit_ks_off;
+  if ((splits > 1 || unsplit_ks || env_ksplit > 0) && env_ksplit != 0 && isa_layout && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
     uint32_t parts = env_ksplit > 0 ? static_cast<uint32_t>(env_ksplit) : max_waves / wave_groups;
     parts = std::min<uint32_t>(parts, max_waves / wave_groups);
     const uint32_t trips = t.l4;  // trips per group row
@@ -543,7 +568,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
     //  wave's latency -- 32 mono streams x 131 072 frames of 48k -> 22.05k in 2 shares: 44.8 us without, 48.7 with)
     const bool crowded = static_cast<uint64_t>(tiles) * n_streams * splits * 2 > device_compute_units();
     // (a wave's chain in vector instructions: one packed FMA per tap, two v_fma_f64 with an fp64 accumulator)
-    if (parts > 1 && (env_ksplit > 0 || (static_cast<uint64_t>(t.r) * t.row_len * (t.a64 ? 2 : 1) >= 1800 && !(crowded && parts < 3))))
+    if (parts > 1 && (env_ksplit > 0 || (static_cast<uint64_t>(t.r) * t.row_len * (t.a64 ? 2 : 1) >= 1800 && (unsplit_ks || !(crowded && parts < 3)))))
       p.ksplit = parts;
   }
   const uint32_t threads =

@@ -947,6 +947,24 @@ __device__ __forceinline__ void fir_tile_parts64(KParams pp, const double *__res
   store_group<R, CT, ONE_GROUP, T>(q, d, c, g, out);
 }
 
+// The tap rows on their way into L2 while the window is staged (round 4).  The FIR loop reads its taps with scalar loads,
+// one bank in flight per wave, and the waves of a launch walk their rows in step: a row line that is not in L2 costs
+// every wave that reads it the trip to HBM -- ~400 lines per wave x ~250 ns in a launch of one generation whose rows
+// the previous launch's samples pushed out (or that nobody has read yet: every first call).  32 streams x 131 072 frames
+// of stereo 48k -> 11.025k in phase pairs: FIR 155 us behind a staged window, 50 us with the window left unstaged and
+// the rows still in L2 from the launch before; rocprofv3, which runs every launch on cold caches, 137 us either way
+// (profiles/r04_skips_2ch_pp.txt, r04_pmc_skip.txt).  One dword per 128-byte line of ALL the rows (<= ~1 MB: a few loads
+// per lane, issued in front of the staging loads; workgroups of a later generation find the lines in L2 already).
+template <int R>
+__device__ __forceinline__ void touch_rows(const PeriodParams &p, const float *__restrict__ rows, uint32_t &sink) {
+  if (p.touch == 0) return;  // (the host's rule: launch_period_plan)
+  const uint32_t bytes = p.groups * p.l4 * static_cast<uint32_t>(2 * bank_taps(R) * 4);
+  // (one statement, its result tied to its input: the loads all land in the one register the caller keeps until they have)
+#pragma clang loop unroll(disable)
+  for (uint32_t off = threadIdx.x * 128u; off < bytes; off += p.threads * 128u)
+    asm volatile("global_load_dword %0, %1, %2" : "+v"(sink) : "v"(off), "s"(rows) : "memory");
+}
+
 // (Mono int16 left through an LDS image -- one row per period, whole rows written 16 bytes per lane -- from
 //  round 1 to round 3 for launches that fill the chip: 160 -> 138 us for 32 streams of 44.1k -> 48k when a lane's
 //  20-byte runs cost five stores.  With the runs packed into dwords at either alignment (store_group) the
@@ -1010,6 +1028,7 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
   }
   if (d.n_out == 0 || blockIdx.x > p.history_block || m_lo >= m_total) return;
   STAMP(1);
+  uint32_t row_sink = 0;
   if (!(p.skip & 2u)) {
     // 5 x 16 bytes per lane in flight: a 76 KB window staged by 1024 lanes in one round of loads
     // (the padded commit needs more registers per group: 3 there keeps the kernel at 8 waves per SIMD)
@@ -1019,6 +1038,12 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
     bool plain = false, plain_padded = false;
     if constexpr (!PADDED) plain = window_is_plain<UNR, T>(wg);  // (wave-uniform)
     if constexpr (PADDED && !W16) plain_padded = window_is_plain_padded<UNR, T>(wg);
+    // (in front of the window's loads: those return behind these.  Instances of the ISA loops only: in the ones that
+    //  run the C++ loop the statement alone -- never executed -- cost 20 VGPRs and 130-230 bytes of scratch, three
+    //  channels 44.1k->48k 64 -> 754 us; tests/test_gpu_perf_gate.py caught it)
+#ifndef SPEEXHIP_CXX_FIR_LOOP
+    if constexpr (AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available) touch_rows<R>(p, rows, row_sink);
+#endif
     if (plain_padded) {
       window_fetch_plain<UNR, T>(wg, w);
       STAMP(2);
@@ -1038,6 +1063,9 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
       else
         window_commit<UNR, T>(xs, d, wg, w);
     }
+    // (the loads of touch_rows land in row_sink: nothing reads it, the register stays reserved until they have)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(row_sink));
   }
   STAMP(3);
   __syncthreads();

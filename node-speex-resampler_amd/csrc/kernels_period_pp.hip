@@ -3,10 +3,8 @@
 // the halves of a packed FMA to two periods (odd channel counts) or to the two channels of a pair.  Half the LDS window
 // per tile for the same 64 lanes: what the wide windows of down-sampling ratios need.  Same arithmetic per output as the fp32 chain (one FMA per tap, same order):
 // deps/speex/resample.c:331-384 / :438-496 with the effective taps, +-1 LSB.
-#ifdef SPEEXHIP_STAMPS
-#undef SPEEXHIP_STAMPS  // (the diagnostics stamps belong to the fp32 translation unit)
-#endif
-#include "kernels_period_impl.h"
+#include "kernels_period_impl.h"  // (diagnostics build: this translation unit has stamps of its own, read by
+                                  //  speexhip_debug_stamps_pp below)
 
 namespace speexhip {
 
@@ -36,5 +34,18 @@ hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const 
 #undef SPEEXHIP_PP
 #undef SPEEXHIP_PP_KS
 }
+
+#ifdef SPEEXHIP_STAMPS
+extern "C" __attribute__((visibility("default"))) int speexhip_debug_stamps_pp(unsigned long long *dst, size_t n, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (dst && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long)) != hipSuccess) return 2;
+  if (clear) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess) return 3;
+    if (hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 16) != hipSuccess) return 4;
+  }
+  return 0;
+}
+#endif
 
 }  // namespace speexhip

@@ -39,6 +39,7 @@ if a.io == "float":
 sp = torch.cuda.current_stream().cuda_stream
 lib = speexhip.lib()
 lib.speexhip_debug_stamps.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+lib.speexhip_debug_stamps_pp.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
 N = 8192
 W = 16
 names = ["start", "desc+geometry", "loads issued", "LDS image written", "barrier passed", "FIR done", "stores issued"]
@@ -50,10 +51,12 @@ for launch in range(a.launches):
         for _ in range(32):
             b.process_device(xs[i % 3].data_ptr(), F * ch, F, y.data_ptr(), cap * ch, cap, sp, a.io == 'float'); i += 1
         torch.cuda.synchronize()
-    assert lib.speexhip_debug_stamps(None, 0, 1) == 0
+    assert lib.speexhip_debug_stamps(None, 0, 1) == 0 and lib.speexhip_debug_stamps_pp(None, 0, 1) == 0
     b.process_device(xs[launch % 3].data_ptr(), F * ch, F, y.data_ptr(), cap * ch, cap, sp, a.io == 'float')
     buf = np.zeros(N * W, np.uint64)
     assert lib.speexhip_debug_stamps(buf.ctypes.data, buf.size, 0) == 0
+    if not buf.any():  # a phase-pair launch: the stamps of its translation unit
+        assert lib.speexhip_debug_stamps_pp(buf.ctypes.data, buf.size, 0) == 0
     st = buf.reshape(N, W).astype(np.int64)
     live = st[:, 4] > 0          # workgroups that staged a window (not the history / padding blocks)
     w = st[live]
