@@ -517,16 +517,24 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   p.prio = static_cast<uint32_t>(env_prio);
   static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
   p.skip = skip_mask;
-  // touch_rows (kernels_period_impl.h): where a launch is more than a generation of workgroups and its rows are
-  // large, the samples streaming through L2 push the rows out between two workgroups of a CU -- three channels
-  // 48k->11.025k, 32 x 2^20 frames: 494 -> 400 us with every workgroup fetching them again beside its window; 32 x
-  // 131 072 frames 91.5 -> 80.7.  Launches of one generation lose to it (cfg2 one stream 11.5 -> 12.3 us, mono
-  // 48k->11.025k 42.2 -> 45.2: profiles/r04_touch_ab.txt), small tables gain nothing (cfg2 32 streams 192.9 / 193.0).
+  // touch_rows (kernels_period_impl.h): every workgroup fetches the tap rows into L2 once its window is in LDS.  Pays
+  // where the rows are NOT in L2 when the FIR loop starts -- a first call, or a launch whose own samples (and the
+  // launch before it) replace the L2s' 32 MB -- and the table is large; costs a trip to HBM per workgroup (~2 us,
+  // hidden where a second workgroup shares the CU) where they are.  On warm / cold caches (a 64 MB read between two
+  // launches), without -> with, profiles/r04_cold_touch.txt: stereo 48k->11.025k 32 x 131 072 frames 80.9 / 119.8 ->
+  // 82.8 / 82.8 us, mono 48k->22.05k 30.0 / 53.0 -> 31.0 / 31.6, 4 channels 145 / 148 -> 136 / 135, 3 channels 32 x 2^20
+  // frames 496 -> 393, stereo 327 -> 277; one stream of cfg2 14.0 / 16.6 -> 14.2 / 15.4, of 44.1k->48k q10 35.8 / 40.5
+  // -> 37.9 / 38.6.  So: launches that move >= 24 MB (their rows never survive to the next launch) with >= 128 KB of
+  // rows (6 channels 44.1k->8k, 250 KB: 111.8 -> 95.9 us; three channels 44.1k->16k, 150 KB: 60.7 -> 55.9; cfg2's 90 KB
+  // at 32 streams 190.5 / 189.0, cfg4's 546.8 / 551.1: profiles/r04_touch_ab3.txt); a caller whose launches are smaller
+  // but far apart can force it (SPEEXHIP_TOUCH=1).
   static const int env_touch = std::getenv("SPEEXHIP_TOUCH") ? std::atoi(std::getenv("SPEEXHIP_TOUCH")) : -1;  // A/B
   {
     const size_t rows_bytes = t.rows_floats * (t.a64 ? 8 : 4);
-    const bool wanted = env_touch >= 0 ? env_touch != 0
-                                       : rows_bytes >= 256 * 1024 && 4ull * tiles * n_streams * splits >= 5ull * device_compute_units();
+    uint64_t moved = 0;  // bytes in + out
+    for (uint32_t i = 0; i < n_streams; i++)
+      moved += (static_cast<uint64_t>(h_descs[i].in_frames) + h_descs[i].n_out) * channels * (float_io ? 4 : 2);
+    const bool wanted = env_touch >= 0 ? env_touch != 0 : rows_bytes >= 128 * 1024 && moved >= (24ull << 20);
     p.touch = wanted ? 1u : 0u;
   }
   // A workgroup that owns only a share of the groups still stages the whole window: lend it the
@@ -566,7 +574,8 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
       parts--;
     // (two parts on a chip already more than half full buy nothing: there the launch is throughput, not one
     //  wave's latency -- 32 mono streams x 131 072 frames of 48k -> 22.05k in 2 shares: 44.8 us without, 48.7 with)
-    const bool crowded = static_cast<uint64_t>(tiles) * n_streams * splits * 2 > device_compute_units();
+    static const bool crowded_off = std::getenv("SPEEXHIP_KS_CROWDED") && std::atoi(std::getenv("SPEEXHIP_KS_CROWDED")) == 0;  // A/B
+    const bool crowded = !crowded_off && static_cast<uint64_t>(tiles) * n_streams * splits * 2 > device_compute_units();
     // (a wave's chain in vector instructions: one packed FMA per tap, two v_fma_f64 with an fp64 accumulator)
     if (parts > 1 && (env_ksplit > 0 || (static_cast<uint64_t>(t.r) * t.row_len * (t.a64 ? 2 : 1) >= 1800 && (unsplit_ks || !(crowded && parts < 3)))))
       p.ksplit = parts;

@@ -953,8 +953,10 @@ __device__ __forceinline__ void fir_tile_parts64(KParams pp, const double *__res
 // the previous launch's samples pushed out (or that nobody has read yet: every first call).  32 streams x 131 072 frames
 // of stereo 48k -> 11.025k in phase pairs: FIR 155 us behind a staged window, 50 us with the window left unstaged and
 // the rows still in L2 from the launch before; rocprofv3, which runs every launch on cold caches, 137 us either way
-// (profiles/r04_skips_2ch_pp.txt, r04_pmc_skip.txt).  One dword per 128-byte line of ALL the rows (<= ~1 MB: a few loads
-// per lane, issued in front of the staging loads; workgroups of a later generation find the lines in L2 already).
+// (profiles/r04_skips_2ch_pp.txt, r04_pmc_skip.txt; a 32 MB read between two launches does the same, 24 MB does not: the
+// eight L2s hold 32 MB -- profiles/r04_cold_state.txt).  One dword per 128-byte line of ALL the rows (<= ~1 MB: a few
+// loads per lane, issued once the window is in LDS, waited for before the FIR loop starts: one trip to HBM, ~2 us, for
+// the ~400 in a row that the loop would make; workgroups of a later generation find the lines in L2 already).
 template <int R>
 __device__ __forceinline__ void touch_rows(const PeriodParams &p, const float *__restrict__ rows, uint32_t &sink) {
   if (p.touch == 0) return;  // (the host's rule: launch_period_plan)
@@ -1038,12 +1040,6 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
     bool plain = false, plain_padded = false;
     if constexpr (!PADDED) plain = window_is_plain<UNR, T>(wg);  // (wave-uniform)
     if constexpr (PADDED && !W16) plain_padded = window_is_plain_padded<UNR, T>(wg);
-    // (in front of the window's loads: those return behind these.  Instances of the ISA loops only: in the ones that
-    //  run the C++ loop the statement alone -- never executed -- cost 20 VGPRs and 130-230 bytes of scratch, three
-    //  channels 44.1k->48k 64 -> 754 us; tests/test_gpu_perf_gate.py caught it)
-#ifndef SPEEXHIP_CXX_FIR_LOOP
-    if constexpr (AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available) touch_rows<R>(p, rows, row_sink);
-#endif
     if (plain_padded) {
       window_fetch_plain<UNR, T>(wg, w);
       STAMP(2);
@@ -1063,6 +1059,14 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
       else
         window_commit<UNR, T>(xs, d, wg, w);
     }
+    // The tap rows into L2 BEHIND the window: fetched in front of the window's loads, or between those loads and
+    // their use, the lines are gone again when the FIR loop asks for them (the samples streaming in replace them);
+    // fetched once the window is in LDS they stay (profiles/r04_cold_state.txt).  Instances of the ISA loops only: in
+    // the ones that run the C++ loop the statement alone -- never executed -- cost 20 VGPRs and 130-230 bytes of
+    // scratch, three channels 44.1k->48k 64 -> 754 us; tests/test_gpu_perf_gate.py caught it.
+#ifndef SPEEXHIP_CXX_FIR_LOOP
+    if constexpr (AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available) touch_rows<R>(p, rows, row_sink);
+#endif
     // (the loads of touch_rows land in row_sink: nothing reads it, the register stays reserved until they have)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::"v"(row_sink));

@@ -12,6 +12,7 @@ HIP events, best of 3 repetitions) and fails above the ceiling.
   python tools/perf_floor.py --measure --merge    ... and fold them into profiles/perf_floor.json: a workload's
                                                   `slowest_us` only ever grows (run on several leases)
   python tools/perf_floor.py --measure --reset    ... start the file over from this box's numbers
+  ... --merge --forget a,b                        ... after dropping the records of workloads a and b (they got faster)
 """
 import argparse
 import json
@@ -57,6 +58,13 @@ WORKLOADS = [
     ("sw_1ch_48k_44k", (1, 48000, 44100, 7), 32, 131072, "fast", "int16"),
     ("sw_1ch_48k_8k", (1, 48000, 8000, 7), 32, 131072, "fast", "int16"),
     ("sw_2ch_48k_8k", (2, 48000, 8000, 7), 32, 131072, "fast", "int16"),
+    ("sw_6ch_44k_8k", (6, 44100, 8000, 7), 32, 131072, "fast", "int16"),
+    ("sw_3ch_48k_22k", (3, 48000, 22050, 7), 32, 131072, "fast", "int16"),
+    ("sw_2ch_48k_16k", (2, 48000, 16000, 7), 32, 131072, "fast", "int16"),
+    # several generations of wide windows: phase pairs with tap-range shares, rows fetched behind the window
+    ("big_3ch_48k_11k", (3, 48000, 11025, 7), 32, 1 << 20, "fast", "int16"),
+    ("big_2ch_48k_11k", (2, 48000, 11025, 7), 32, 1 << 20, "fast", "int16"),
+    ("big_3ch_44k_16k", (3, 44100, 16000, 7), 32, 1 << 20, "fast", "int16"),
     # launches of one generation with their own plans (tap-range shares, r = 5 shares)
     ("one_48k_11k_2ch", (2, 48000, 11025, 7), 1, 441000, "fast", "int16"),
     ("one_48k_8k_2ch", (2, 48000, 8000, 7), 1, 441000, "fast", "int16"),
@@ -116,6 +124,9 @@ def main():
     ap.add_argument("--merge", action="store_true")
     ap.add_argument("--reset", action="store_true")
     ap.add_argument("--only", default=None, help="substring of the workload names to run")
+    ap.add_argument("--forget", default=None,
+                    help="comma-separated workload names whose recorded numbers are dropped first (a kernel got faster: "
+                         "its old slowest time is no floor any more)")
     ap.add_argument("--out", default=FLOOR, help="where to write (gpurun brings back gpurun_out/ only)")
     args = ap.parse_args()
     if not args.measure:
@@ -126,6 +137,8 @@ def main():
     floor = {"margin": MARGIN, "boxes": [], "workloads": {}}
     if os.path.exists(FLOOR) and not args.reset:
         floor = json.load(open(FLOOR))
+    for name in (args.forget or "").split(","):
+        floor["workloads"].pop(name.strip(), None)
     rows = {}
     for w in WORKLOADS:
         if args.only and args.only not in w[0]:

@@ -1,9 +1,9 @@
 #!/bin/bash
 # tools/r04_ks_unsplit_ab.sh -- the sweep of tools/perf_sweep.sh with and without tap-range shares on unsplit launches
-# (SPEEXHIP_KS_UNSPLIT=0 SPEEXHIP_TOUCH=0: the rules before), same box; rows whose launch time moved by more than 3 %.
+# (SPEEXHIP_KS_UNSPLIT=0 SPEEXHIP_TOUCH=0: the rules before; OFF= / ON= set other pairs of environments), same box; rows whose launch time moved by more than 3 %.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r04${TAG:-}; mkdir -p $O
-SPEEXHIP_KS_UNSPLIT=0 SPEEXHIP_TOUCH=0 tools/perf_sweep.sh > $O/sweep_ks_off.txt 2>&1
-tools/perf_sweep.sh > $O/sweep_ks_on.txt 2>&1
+env ${OFF:-SPEEXHIP_KS_UNSPLIT=0 SPEEXHIP_TOUCH=0} tools/perf_sweep.sh > $O/sweep_ks_off.txt 2>&1
+env ${ON:-X=1} tools/perf_sweep.sh > $O/sweep_ks_on.txt 2>&1
 python3 - <<'PY'
 import re
 def rows(p):
