@@ -381,8 +381,16 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
     // (the tap-range shares of an UNSPLIT launch count only against a plan that leaves lanes unused: two half-chains
     //  are not two chains -- stereo 48k->11.025k in phase pairs with them: 90 us against 79 the other way, whose tiles
     //  are full; three channels, 18 of 42 periods per tile the other way: 32 x 2^20 frames 870 -> 400 us)
-    return static_cast<double>(std::min(per_cu, fit)) * sh.wave_groups * ((sh.splits > 1 || unfilled) ? sh.ksplit : 1u) / 4.0;
+    static const bool count_ks = std::getenv("SPEEXHIP_PP_COUNT_KS") && std::atoi(std::getenv("SPEEXHIP_PP_COUNT_KS")) != 0;  // A/B
+    return static_cast<double>(std::min(per_cu, fit)) * sh.wave_groups * ((sh.splits > 1 || unfilled || count_ks) ? sh.ksplit : 1u) / 4.0;
   };
+  // (Late in round 4: where the other plan has to SPLIT its tiles over two workgroups -- each stages the whole 150 KB window
+  //  -- and the phase-pair plan runs unsplit with tap-range shares and its rows fetched behind the window (launch_period_plan):
+  //  stereo 48k->11.025k, 32 x 131 072 frames: 76.6 us the other way, 89.6 in phase pairs without the fetch, 46.2 with;
+  //  profiles/r04_pp_touch_ab.txt.  Counting the shares in the rule below instead moved six more stereo rows to phase
+  //  pairs, +6 % each: profiles/r04_rule3_ab.txt.)
+  static const bool split_rule_off = std::getenv("SPEEXHIP_PP_SPLIT_RULE") && std::atoi(std::getenv("SPEEXHIP_PP_SPLIT_RULE")) == 0;  // A/B
+  if (!split_rule_off && so.splits > 1 && sp.splits == 1 && sp.ksplit > 1) return true;
   const double wo = waves_per_simd(two, so), wp = waves_per_simd(pp, sp);
   if (wp < 3.5 || wp < wo) return false;
   const uint64_t wgs_other = static_cast<uint64_t>(so.tiles) * n_streams * so.splits;
@@ -527,14 +535,26 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // -> 37.9 / 38.6.  So: launches that move >= 24 MB (their rows never survive to the next launch) with >= 128 KB of
   // rows (6 channels 44.1k->8k, 250 KB: 111.8 -> 95.9 us; three channels 44.1k->16k, 150 KB: 60.7 -> 55.9; cfg2's 90 KB
   // at 32 streams 190.5 / 189.0, cfg4's 546.8 / 551.1: profiles/r04_touch_ab3.txt); a caller whose launches are smaller
-  // but far apart can force it (SPEEXHIP_TOUCH=1).
+  // but far apart can force it (SPEEXHIP_TOUCH=1).  And: unsplit phase-pair launches with tap-range shares of about a
+  // generation or more whose rows are >= 256 KB -- those rows never survived from one launch to the next (stereo
+  // 48k->11.025k, 415 KB, 20.7 MB moved: 89.6 us without, 46.2 with; at 210 KB, stereo 48k->22.05k: 40.1 -> 42.3, so not
+  // there: profiles/r04_pp_touch_ab.txt, r04_rule4_ab.txt).
   static const int env_touch = std::getenv("SPEEXHIP_TOUCH") ? std::atoi(std::getenv("SPEEXHIP_TOUCH")) : -1;  // A/B
   {
     const size_t rows_bytes = t.rows_floats * (t.a64 ? 8 : 4);
     uint64_t moved = 0;  // bytes in + out
     for (uint32_t i = 0; i < n_streams; i++)
       moved += (static_cast<uint64_t>(h_descs[i].in_frames) + h_descs[i].n_out) * channels * (float_io ? 4 : 2);
-    const bool wanted = env_touch >= 0 ? env_touch != 0 : rows_bytes >= 128 * 1024 && moved >= (24ull << 20);
+    // (A/B: SPEEXHIP_TOUCH_RULE=2 fetches in every launch of half a generation or more -- stereo 48k->11.025k the same
+    //  46 us, ten more rows of the sweep +3...7 % on warm caches: profiles/r04_rule2_ab.txt)
+    static const bool wide_rule = std::getenv("SPEEXHIP_TOUCH_RULE") && std::atoi(std::getenv("SPEEXHIP_TOUCH_RULE")) == 2;
+    const bool half_generation = 2ull * tiles * n_streams * splits >= device_compute_units();
+    static const bool pp_rule = !(std::getenv("SPEEXHIP_TOUCH_RULE") && std::atoi(std::getenv("SPEEXHIP_TOUCH_RULE")) == 1);  // A/B: 1 = by bytes only
+    // (set below: the tap-range shares; an unsplit launch of 8-wave groups takes them whenever its chain is long)
+    const bool pp_shares = t.pp && splits == 1 && t.r == 10 && wave_groups * 2 <= max_waves;
+    const bool wanted = env_touch >= 0 ? env_touch != 0
+                                       : rows_bytes >= 128 * 1024 && (moved >= (24ull << 20) || (wide_rule && half_generation) ||
+                                                                     (pp_rule && pp_shares && half_generation && rows_bytes >= 256 * 1024));
     p.touch = wanted ? 1u : 0u;
   }
   // A workgroup that owns only a share of the groups still stages the whole window: lend it the
