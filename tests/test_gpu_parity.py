@@ -1728,6 +1728,30 @@ def _pp_batch_against_the_oracle(ch, i, o, q, S, F):
     b.close()
 
 
+def test_tap_rows_fetched_behind_the_window_and_shares_on_unsplit_launches():
+    """Round 4, last third: (1) launches whose workgroups have <= 8 waves give every phase group two waves (tap-range
+    shares on UNSPLIT launches, R = 10); (2) launches that move >= 24 MB with >= 128 KB of tap rows, and unsplit phase-pair
+    launches with shares, have every workgroup fetch the rows into L2 behind its window (touch_rows: loads whose
+    result nothing reads, into a register the kernel keeps until they have landed); (3) stereo takes phase pairs
+    where the other plan has to split its tiles.  None of it may change a sample.  SPEEXHIP_TOUCH=1 (read once per process)
+    fetches in EVERY period-kernel launch -- the golden, layout, share, window, store and control tests run under it
+    in a child process, and once more with the shares on unsplit launches off --, then batches that meet the rules."""
+    import subprocess
+    import sys
+    pick = ("(every_golden_case or many_rates or window_layout_variants or tap_range_shares or int16_window or mono_rows "
+            "or mono_packed or many_generation or eight_channel or fp64_accumulate_period or control_scripts_fast or "
+            "ragged or float_entry) and not phase_pair and not tap_rows_fetched")
+    for extra in ({"SPEEXHIP_TOUCH": "1"}, {"SPEEXHIP_TOUCH": "1", "SPEEXHIP_PP": "1"}, {"SPEEXHIP_KS_UNSPLIT": "0"}):
+        res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", pick],
+                             env=dict(os.environ, **extra), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+        assert res.returncode == 0, str(extra) + res.stdout[-3000:] + res.stderr[-2000:]
+    # by the rules: shares on an unsplit launch (three channels, 8 groups of 20 phases), the fetch by bytes moved
+    # (4 channels, 33 MB), stereo in phase pairs because the other plan splits -- all through the default environment
+    for ch, i, o, q, S, F in ((3, 48000, 11025, 7, 32, 131072), (4, 48000, 11025, 7, 32, 131072), (2, 48000, 11025, 7, 32, 131072),
+                              (1, 48000, 22050, 7, 32, 131072), (6, 44100, 8000, 7, 12, 131072)):
+        _pp_batch_against_the_oracle(ch, i, o, q, S, F)
+
+
 def test_large_owned_block_calls_run_in_pieces_and_match_the_oracle():
     """Round 4: an owned-block host call of >= 2 MB runs as up to four pieces -- input copies on a second stream, a
     launch per piece behind each copy's event, the kernel writing the result block itself (PCIe both ways at once).
