@@ -50,8 +50,15 @@ static __device__ unsigned long long g_stamps[8192 * 16];
     if ((threadIdx.x & 63u) == 0 && lin_ < 8192)                                                         \
       atomicMax(&g_stamps[lin_ * 16 + (k)], (unsigned long long)__builtin_amdgcn_s_memrealtime());        \
   } while (0)
+#define STAMP_FIRST(k)                                                                                   \
+  do {                                                                                                   \
+    const uint32_t lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                \
+    if ((threadIdx.x & 63u) == 0 && lin_ < 8192)                                                         \
+      atomicMax(&g_stamps[lin_ * 16 + (k)], ~(unsigned long long)__builtin_amdgcn_s_memrealtime());       \
+  } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define STAMP_FIRST(k) do { } while (0)
 #endif
 namespace {
 
@@ -868,7 +875,13 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
       if (valid) fir_group_part<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, part, parts, acc);
     }
   }
+#ifdef SPEEXHIP_STAMPS
+  asm volatile("" ::"v"(acc[0]));
+#endif
+  STAMP(5);    // (the last wave out of its FIR loop)
+  STAMP_FIRST(13);  // (the first wave out of its FIR loop: stored as ~time, so that atomicMax keeps the earliest)
   __syncthreads();  // every wave is done with the window
+  STAMP(11);
   // partial sums of part j >= 1, group-wave gw: block (j - 1) * wg + gw of R x 64 pairs, lanes side by side
   f32x2 *sums = reinterpret_cast<f32x2 *>(xs);
   if (valid && part != 0) {
@@ -883,6 +896,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
 #pragma unroll
     for (int i = 0; i < R; i++) acc[i] += theirs[i * 64];
   }
+  STAMP(12);  // (partial sums added)
   const PeriodParams q = load_k(pp);
   if ((q.skip & 8u) || !c.live) return;
   const StreamDesc d = load_k(dp);
@@ -890,6 +904,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
     store_group_pp<R, ONE_GROUP ? 1 : CGF, T>(q, d, c, g, acc);
   else
     store_group<R, CT, ONE_GROUP, T>(q, d, c, g, acc);
+  STAMP(6);
 }
 
 // ... with an fp64 accumulator: the partial sums meet in LDS as doubles (twice the room: launch_period_plan)

@@ -68,11 +68,22 @@ for launch in range(a.launches):
         col = rel[:, k]
         print("  %-18s min %7.2f  p10 %7.2f  median %7.2f  p90 %7.2f  max %7.2f" % (
             nm, col.min(), np.percentile(col, 10), np.median(col), np.percentile(col, 90), col.max()))
+    if (st[live][:, 11] > 0).any():  # tap-range shares: first / last wave out of the FIR loop, barrier, partial sums added
+        raw = buf.reshape(N, W)[live]
+        first = ((~raw[:, 13]).astype(np.int64) - origin) * 0.01
+        b1 = (w[:, 11] - origin) * 0.01
+        s2 = (w[:, 12] - origin) * 0.01
+        for nm, col in (("first wave out of FIR", first - rel[:, 4]), ("last wave out of FIR", rel[:, 5] - rel[:, 4]),
+                        ("barrier behind the FIR", b1 - rel[:, 5]), ("partial sums written + added", s2 - b1),
+                        ("stores", rel[:, 6] - s2)):
+            print("  shares: %-30s median %7.2f  p90 %7.2f  max %7.2f us" % (nm, np.median(col), np.percentile(col, 90), col.max()))
     d7 = w[:, 7].astype(np.float64)
     print("  longest FIR loop among a workgroup's waves, shader cycles (s_memtime): median %.0f p90 %.0f max %.0f" % (
         np.median(d7), np.percentile(d7, 90), d7.max()))
     ok = w[:, 10] > 0
     clk = w[ok, 9] / (w[ok, 10] * 10.0)  # cycles per ns = GHz (s_memtime over s_memrealtime, wave 0's FIR loop)
+    if not ok.any():  # (launches with tap-range shares record no loop clocks)
+        clk = np.array([float("nan")])
     print("  in-kernel clock over wave 0's FIR loop (s_memtime / s_memrealtime): median %.2f GHz  p10 %.2f  p90 %.2f" % (
         np.median(clk), np.percentile(clk, 10), np.percentile(clk, 90)))
     for k in range(1, 7):
