@@ -374,6 +374,15 @@ SPEEXHIP_API int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int
 SPEEXHIP_API int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
                                        uint32_t out[8]);
 
+/* Host only (tests): the shape of the period kernel's launch for a first call of `frames` frames on each of `streams`
+ * (<= 32) streams -- out[0] = 1 when the launch takes the phase-pair plan, out[1] = phases per wave (r), out[2] = 1 for
+ * the int16 window, out[3] = periods per tile, out[4] = tiles per stream, out[5] = phase-group splits, out[6] = waves
+ * with a group, out[7] = tap-range shares (1 = none), out[8] = lanes per workgroup, out[9] = 1 when every workgroup
+ * fetches the tap rows into L2 behind its window; all zero when the configuration does not run the fp32 period
+ * kernel.  The rules are fitted to a 256-CU device, which is what a process without a GPU assumes. */
+SPEEXHIP_API int speexhip_debug_launch_shape(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
+                                             uint32_t streams, uint32_t frames, int float_io, uint32_t out[10]);
+
 /* Which kind of box is this?  Runs ~0.3 ms of packed fp32 FMAs with LDS reads on every CU and reports the shader
  * clock (GHz) the chip held meanwhile (median / slowest workgroup): the pool's boxes differ by 4-6 %, so bench
  * lines and the perf gate (tests/test_gpu_perf_gate.py) quote it.  Diagnostics; blocks the calling thread. */

@@ -262,6 +262,49 @@ int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uin
     return static_cast<int>(SPEEXHIP_ERR_SUCCESS);
   });
 }
+int speexhip_debug_launch_shape(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels, uint32_t streams,
+                                uint32_t frames, int float_io, uint32_t out[10]) {
+  if (out == nullptr || channels == 0 || streams == 0 || streams > 32) return SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&]() -> int {
+    speexhip::FilterSpec f;
+    const int rc = speexhip::design_filter_frac(ratio_num, ratio_den, ratio_num, ratio_den, quality, &f, false);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+    std::memset(out, 0, 10 * sizeof(uint32_t));
+    if (f.kind == speexhip::kDirectDouble || f.kind == speexhip::kInterpolateDouble) return SPEEXHIP_ERR_SUCCESS;
+    // the plans a stream state holds (engine.cpp, build_tables) and the choice of launch_chunk among them, for a
+    // first call of `frames` frames on every stream (an r = 5 companion plan, where one exists, is not modelled)
+    const size_t lds = speexhip::lds_budget();
+    const speexhip::PeriodPlan base = speexhip::plan_period(f, channels, lds);
+    if (!base.usable) return SPEEXHIP_ERR_SUCCESS;
+    const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, lds, base);
+    speexhip::PeriodPlan pp, pp_w16;
+    if (speexhip::period_wants_pp_plans(f, channels)) {
+      pp = speexhip::plan_period(f, channels, lds, false, false, true);
+      pp_w16 = speexhip::plan_period_w16(f, channels, lds, pp);
+    }
+    std::vector<speexhip::StreamDesc> descs(streams);
+    for (auto &d : descs) {
+      std::memset(&d, 0, sizeof(d));
+      d.in_frames = frames;
+      d.n_out = static_cast<uint32_t>(static_cast<uint64_t>(frames) * f.den / f.num);
+    }
+    const bool i16 = !float_io;
+    const speexhip::PeriodPlan &two = (i16 && w16.usable) ? w16 : base;
+    const speexhip::PeriodPlan &pairs = (i16 && pp_w16.usable) ? pp_w16 : pp;
+    const speexhip::PeriodPlan *t = &base;
+    if (pp.usable && speexhip::period_launch_prefers_pp(f, two, pairs, descs.data(), streams)) {
+      t = &pairs;
+      out[0] = 1;
+    } else if (i16 && w16.usable && speexhip::period_launch_prefers_w16(f, base, false, descs.data(), streams)) {
+      t = &w16;
+    }
+    out[1] = t->r;
+    out[2] = t->w16 ? 1u : 0u;
+    out[3] = t->lane_periods;
+    if (!speexhip::debug_period_shape(f, *t, channels, descs.data(), streams, float_io != 0, out + 4)) return SPEEXHIP_ERR_BAD_STATE;
+    return SPEEXHIP_ERR_SUCCESS;
+  });
+}
 int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels, uint32_t out[8]) {
   if (out == nullptr || channels == 0) return SPEEXHIP_ERR_INVALID_ARG;
   return guarded([&] {

@@ -83,6 +83,10 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
 bool period_wants_pp_plans(const FilterSpec &f, uint32_t channels);
 bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const PeriodPlan &pp, const StreamDesc *h_descs,
                               uint32_t n_streams);
+// Host only: tiles, phase-group splits, waves with a group, tap-range shares, lanes and whether the workgroups fetch the
+// tap rows, as launch_period_plan would set them for this launch of `t` (speexhip_debug_launch_shape).
+bool debug_period_shape(const FilterSpec &f, const PeriodPlan &t, uint32_t channels, const StreamDesc *h_descs, uint32_t n_streams,
+                        bool float_io, uint32_t out[6]);
 // The int16-window plan of a filter whose float plan is `t`, .usable only where it pays: at least 5/4 of the
 // periods per tile (the loop converts every sample it reads: ~20 % more vector instructions per tile).
 PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_budget, const PeriodPlan &t);

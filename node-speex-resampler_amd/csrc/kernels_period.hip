@@ -303,7 +303,7 @@ uint32_t split_count(const PeriodPlan &t, uint32_t tiles, uint32_t n_streams, ui
 
 // probe != null: the launch's shape only (tiles, shares, waves), nothing is launched
 struct PeriodShape {
-  uint32_t tiles, splits, wave_groups, ksplit, threads;
+  uint32_t tiles, splits, wave_groups, ksplit, threads, touch;
 };
 hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
                               const StreamDesc *h_descs, const DescPack *pack,
@@ -395,6 +395,20 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
   if (wp < 3.5 || wp < wo) return false;
   const uint64_t wgs_other = static_cast<uint64_t>(so.tiles) * n_streams * so.splits;
   return wgs_other <= 2ull * cus || (unfilled && wp >= 6.0);
+}
+
+// Host only (speexhip_debug_launch_shape, tests): the shape launch_period_plan would give this launch.
+bool debug_period_shape(const FilterSpec &f, const PeriodPlan &t, uint32_t channels, const StreamDesc *h_descs, uint32_t n_streams,
+                        bool float_io, uint32_t out[6]) {
+  PeriodShape sh{};
+  if (launch_period_plan(f, t, nullptr, channels, h_descs, nullptr, n_streams, float_io, nullptr, &sh) != hipSuccess) return false;
+  out[0] = sh.tiles;
+  out[1] = sh.splits;
+  out[2] = sh.wave_groups;
+  out[3] = sh.ksplit;
+  out[4] = sh.threads;
+  out[5] = sh.touch;
+  return true;
 }
 
 // `fine` (may be null / unusable): the same filter planned with R = 5.  A launch that is a single
@@ -604,7 +618,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
       (p.ksplit > 1 ? wave_groups * p.ksplit : helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
   p.threads = threads;
   if (probe != nullptr) {
-    *probe = PeriodShape{tiles, splits, wave_groups, p.ksplit, threads};
+    *probe = PeriodShape{tiles, splits, wave_groups, p.ksplit, threads, p.touch};
     return hipSuccess;
   }
   // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8

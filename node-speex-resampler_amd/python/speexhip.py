@@ -50,7 +50,7 @@ EXPORTS = [
     "speexhip_release_cached_memory", "speexhip_debug_plan",
     "speexhip_resampler_release_stream", "speexhip_batch_release_stream", "speexhip_debug_device_clock",
     "speexhip_resampler_process_interleaved_int_take", "speexhip_resampler_process_interleaved_float_take",
-    "speexhip_block_release", "speexhip_debug_plan64",
+    "speexhip_block_release", "speexhip_debug_plan64", "speexhip_debug_launch_shape",
 ]
 
 
@@ -250,6 +250,17 @@ def debug_plan64(ratio_num, ratio_den, quality, channels):
     v = list(out)
     return {"fast_path": v[0], "r_or_p": v[1], "lane_periods": v[2], "row_len": v[3], "lds_bytes": v[4],
             "pad_or_stride": v[5], "trips": v[6], "last": v[7]}
+
+
+def debug_launch_shape(ratio_num, ratio_den, quality, channels, streams, frames, float_io=False):
+    """host-only: the period kernel's launch for a first call of `frames` frames on each of `streams` streams"""
+    out = (C.c_uint32 * 10)()
+    rc = lib().speexhip_debug_launch_shape(ratio_num, ratio_den, quality, channels, streams, frames, int(float_io), out)
+    if rc:
+        raise ValueError(strerror(rc))
+    v = list(out)
+    return {"phase_pairs": bool(v[0]), "r": v[1], "int16_window": bool(v[2]), "lane_periods": v[3], "tiles": v[4],
+            "splits": v[5], "wave_groups": v[6], "shares": v[7], "threads": v[8], "touch": bool(v[9])}
 
 
 def device_clock():

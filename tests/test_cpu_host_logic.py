@@ -545,3 +545,50 @@ def test_round4_planners_fp64_accumulate_and_phase_pairs():
     assert p64(44100, 48000, 7, 1)["fast_path"] == 0 and p64(48000, 22050, 7, 1)["fast_path"] == 6
     assert 28 <= p64(48000, 22050, 7, 2)["lane_periods"] <= 32 and p64(44100, 32000, 7, 3)["lane_periods"] <= 21
     assert p64(48000, 11025, 7, 1)["last"] >= 60      # its int16 window: two workgroups per CU instead of one
+
+
+def test_round4_launch_rules_shares_fetch_and_phase_pairs_by_launch():
+    """The per-launch rules of the period kernel that round 4 added, without a GPU (speexhip_debug_launch_shape; a process
+    without a device plans for 256 CUs): tap-range shares on UNSPLIT launches whose workgroups have <= 8 waves (R = 10
+    only), the tap rows fetched behind the window where the launch moves >= 24 MB with >= 128 KB of rows or runs
+    unsplit phase pairs with shares over >= 256 KB of rows, and phase pairs for stereo where the other plan has to
+    split its tiles.  The figures behind every threshold: DESIGN.md 3.3, profiles/r04_ks_unsplit_ab.txt,
+    r04_touch_ab3.txt, r04_rule4_ab.txt; tests/test_gpu_perf_gate.py holds the times."""
+    from math import gcd
+
+    def shape(ch, i, o, streams, frames, q=7, float_io=False):
+        g = gcd(i, o)
+        return speexhip.debug_launch_shape(i // g, o // g, q, ch, streams, frames, float_io)
+
+    # three channels 48k -> 11.025k: phase pairs, 8 groups of 20 phases on 8 waves -> two shares each, rows fetched
+    for frames in (131072, 1 << 20):
+        t = shape(3, 48000, 11025, 32, frames)
+        assert t["phase_pairs"] and t["r"] == 10 and t["splits"] == 1 and t["wave_groups"] == 8, t
+        assert t["shares"] == 2 and t["threads"] == 1024 and t["touch"], t
+    # stereo 48k -> 11.025k: the other plan would split its 150 KB tiles -> phase pairs, shares, rows (415 KB) fetched
+    t = shape(2, 48000, 11025, 32, 131072)
+    assert t["phase_pairs"] and t["splits"] == 1 and t["shares"] == 2 and t["touch"], t
+    # ... but one stream of it is a split launch of the other plan (phase pairs only in batches)
+    assert not shape(2, 48000, 11025, 1, 441000)["phase_pairs"]
+    # stereo 48k -> 22.05k: phase pairs with shares, 210 KB of rows and 21 MB moved -> no fetch
+    t = shape(2, 48000, 22050, 32, 131072)
+    assert t["phase_pairs"] and t["shares"] == 2 and not t["touch"], t
+    # R = 5 plans take no shares on unsplit launches (their instances with shares need 76 VGPRs)
+    t = shape(2, 44100, 8000, 32, 131072)
+    assert t["r"] == 5 and t["splits"] == 1 and t["shares"] == 1, t
+    # 4 and 6 channels: channel pairs; 33 / 50 MB moved -> rows fetched; 6 channels 44.1k -> 8k has 8 waves -> shares
+    t = shape(4, 48000, 11025, 32, 131072)
+    assert not t["phase_pairs"] and t["wave_groups"] == 15 and t["shares"] == 1 and t["touch"], t
+    t = shape(6, 44100, 8000, 32, 131072)
+    assert not t["phase_pairs"] and t["wave_groups"] == 8 and t["shares"] == 2 and t["touch"], t
+    # mono 48k -> 22.05k: unsplit, 8 waves -> shares; 10 MB moved -> no fetch
+    t = shape(1, 48000, 22050, 32, 131072)
+    assert t["splits"] == 1 and t["shares"] == 2 and not t["touch"], t
+    # the BASELINE launches are what they were: no shares on the 16-wave workgroups of cfg2, no fetch of 90 KB of rows
+    for streams in (1, 32):
+        t = shape(2, 44100, 48000, streams, 1 << 20)
+        assert not t["phase_pairs"] and t["shares"] == 1 and not t["touch"], t
+    t = shape(8, 48000, 44100, 32, 1 << 20, q=5)
+    assert t["shares"] == 1 and not t["touch"] and t["wave_groups"] == 15, t
+    # configurations that do not run the fp32 period kernel answer with zeros
+    assert shape(1, 24000, 48000, 1, 1 << 20, q=10)["r"] == 0 and shape(2, 44100, 48000, 1, 4096, q=10)["r"] == 0
