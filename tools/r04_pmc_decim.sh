@@ -11,7 +11,7 @@ G5="SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_IFETCH 
 G6="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_DCACHE_INPUT_VALID_READYB SQC_DCACHE_ATOMIC"
 for C in ${CASES:-1,48000,11025,7 2,48000,11025,7 3,48000,11025,7 2,48000,44100,7}; do
   T=$(echo $C | tr , _)
-  for G in 1 2 3 4 5 6; do
+  for G in ${GROUPS_TO_RUN:-1 2 3 4 5 6}; do
     eval "CS=\$G$G"
     timeout 300 rocprofv3 --pmc $CS --output-format csv -d $O/${T}_g$G -- python3 $R/bench.py --custom $C --streams 32 --frames 131072 --steps 6 --warmup 2 --reps 1 --preheat-ms 0 --no-cpu-baseline --no-parity > $O/${T}_g$G.log 2>&1 || echo "pass $G of $C failed"
   done
