@@ -2,7 +2,7 @@
 // phase-pair loops consume 8 bytes of taps per packed FMA through scalar loads; is that path a ceiling?)  Every wave
 // streams a 52 KB row with s_load_dwordx16, two loads (128 bytes) between waits, nothing else: bytes per second over the
 // chip for rows that are (a) every wave's own, (b) shared by wave w of every workgroup -- what a launch of the
-// period kernel does --, (c) shared by all waves of a workgroup.  Not part of the product.
+// period kernel does --, (c) shared by all waves of a workgroup, (d) by two or four of them.  Not part of the product.
 // build: hipcc --offload-arch=gfx950 -O3 tools/ubench_smem.hip -o tools/ubench_smem
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -13,7 +13,7 @@ template <int MODE, int INFLIGHT>
 __global__ __launch_bounds__(1024) void k(const char *rows, uint32_t row_bytes, int reps, uint32_t *out) {
   extern __shared__ float xs[];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), waves = blockDim.x >> 6;
-  const uint32_t stream = MODE == 0 ? blockIdx.x * waves + wave : MODE == 1 ? wave : 0;
+  const uint32_t stream = MODE == 0 ? blockIdx.x * waves + wave : MODE == 1 ? wave : MODE == 3 ? wave / 2 : MODE == 4 ? wave / 4 : 0;
   const char *p = rows + static_cast<size_t>(stream) * row_bytes;
   for (int r = 0; r < reps; r++)
     for (uint32_t off = 0; off < row_bytes; off += 64 * INFLIGHT) {
@@ -61,6 +61,11 @@ int main() {
     if (run<1, 2>("wave w of every workgroup shares", rows, blocks, 1024, row_bytes, 4, lds, out)) return 1;
     if (run<1, 1>("wave w of every workgroup shares", rows, blocks, 1024, row_bytes, 4, lds, out)) return 1;
     if (run<2, 2>("all waves of a workgroup share", rows, blocks, 1024, row_bytes, 4, lds, out)) return 1;
+  }
+  // what a workgroup of (phase group, period block) waves would see: two / four waves of a workgroup on every row
+  for (int blocks : {256, 512}) {
+    if (run<3, 2>("pairs of waves share a row", rows, blocks, 1024, row_bytes, 4, lds, out)) return 1;
+    if (run<4, 2>("four waves share a row", rows, blocks, 1024, row_bytes, 4, lds, out)) return 1;
   }
   if (run<1, 2>("wave w shares, 8 waves", rows, 256, 512, row_bytes, 4, lds, out)) return 1;
   if (run<1, 2>("wave w shares, 4 waves", rows, 256, 256, row_bytes, 4, lds, out)) return 1;
