@@ -188,6 +188,65 @@ def end_to_end(speexhip, cfg, frames, mode, float_io, base_stream, calls=30):
                     "then owns: what processChunk returns as an external Buffer); ms_per_chunk = the faster" % frames}
 
 
+def end_to_end_streams(speexhip, cfg, frames, mode, streams=32, calls=8):
+    """BASELINE configs[4]'s per-GPU share as a HOST caller reaches it (round 5): `streams` independent states -- what
+    `streams` SpeexResampler instances of one Node process hold -- fed pageable host buffers through ONE
+    speexhip_resampler_process_many_int call per step (per GPU one transfer in, one launch per <= 32 states, one
+    transfer out; index.js: SpeexResamplerBatch.processChunks and the same-tick coalescer of processChunkAsync).
+    PCIe-inclusive, reported beside `value`, never as it; a streaming-size point (16 384 frames per stream, the
+    64 KiB chunks of the reference's stream test) beside the full-size one."""
+    import ctypes as C
+    import numpy as np
+    ch, fi, fo, q = cfg
+    lib = speexhip.lib()
+    out = {"streams": streams,
+           "what": "%d single-stream states, pageable host buffers in and out, one speexhip_resampler_process_many_int "
+                   "call per step (PCIe-inclusive; not `value`); separate_calls = the same states through %d "
+                   "speexhip_resampler_process_interleaved_int calls" % (streams, streams)}
+    for label, F, n_calls in (("full", frames, calls), ("streaming", 16384, 4 * calls)):
+        states = [speexhip.Resampler(ch, fi, fo, q, mode=mode) for _ in range(streams)]
+        cap = wrapper_capacity(F * ch * 2, fi, fo, ch)
+        xs = [np.ascontiguousarray(lcg_pcm(F * ch, 12345 + s).reshape(F, ch)) for s in range(streams)]
+        ys = [np.zeros((cap, ch), np.int16) for _ in range(streams)]
+        n = streams
+        hs = (C.c_void_p * n)(*[st._h for st in states])
+        ins = (C.c_void_p * n)(*[x.ctypes.data for x in xs])
+        outs = (C.c_void_p * n)(*[y.ctypes.data for y in ys])
+        il, ol, codes = (C.c_uint32 * n)(), (C.c_uint32 * n)(), (C.c_int * n)()
+
+        def many():
+            for i in range(n):
+                il[i], ol[i] = F, cap
+            rc = lib.speexhip_resampler_process_many_int(n, hs, ins, il, outs, ol, codes)
+            assert rc == 0, rc
+
+        def apart():
+            fn = lib.speexhip_resampler_process_interleaved_int
+            for i in range(n):
+                a, b = C.c_uint32(F), C.c_uint32(cap)
+                rc = fn(states[i]._h, xs[i].ctypes.data_as(C.POINTER(C.c_int16)), C.byref(a),
+                        ys[i].ctypes.data_as(C.POINTER(C.c_int16)), C.byref(b))
+                assert rc == 0, rc
+
+        res = {}
+        for name, fn in (("many", many), ("separate_calls", apart)):
+            for _ in range(2):
+                fn()
+            ts = []
+            for _ in range(n_calls):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            res[name] = ts[len(ts) // 2]
+        for st in states:
+            st.close()
+        out[label] = {"frames_per_stream": F, "ms_per_step": round(res["many"] * 1e3, 4),
+                      "ms_per_step_separate_calls": round(res["separate_calls"] * 1e3, 4),
+                      "input_msamples_per_s": round(streams * F * ch / res["many"] / 1e6, 1)}
+    return out
+
+
 def cpu_baseline(cfg, frames, budget_s=12.0, max_chunks=32):
     """Time the CPU path on this box's host cores on a bounded sample of the same workload."""
     eng, kind = _oracle_engine(cfg)
@@ -492,6 +551,8 @@ def main():
                 rc = 3
         if world == 1 and not args.no_cpu_baseline:
             line["end_to_end"] = end_to_end(speexhip, cfg, F, mode, fio, base[0])
+            if not fio:
+                line["end_to_end_streams"] = end_to_end_streams(speexhip, cfg, F, mode)
             line["cpu_baseline"] = cpu_baseline(cfg, F)
         print(json.dumps(line), flush=True)
         if rc:

@@ -71,6 +71,22 @@ SPEEXHIP_API SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channel
                                                              uint32_t out_rate, int quality,
                                                              int *err);
 
+/* Which GPU a state lives on (round 5).  The reference's model is many SpeexResampler instances in one process
+ * (src/index.ts:18-45: one shared module, one state per instance); on a node with several MI355X the states of
+ * one process spread over them by a process-wide rule read from the environment when a state is made:
+ *   SPEEXHIP_DEVICE=k         every state on device k
+ *   SPEEXHIP_DEVICES=all      state number k of the process on device k mod speexhip_device_count()
+ *   SPEEXHIP_DEVICES=0,2,5    ... on the (k mod 3)-th listed device
+ *   neither                   the calling thread's current HIP device (the behaviour before round 5)
+ * speexhip_resampler_init / _init_frac / speexhip_batch_init follow the rule; the ..._init_on forms name the device
+ * (device < 0 = the rule).  A state's calls may come from any thread with any current device: every entry point
+ * switches to the state's device and back.  Init fails with SPEEXHIP_ERR_DEVICE for a device the node does not have.
+ * (SPEEXHIP_ALIAS_DEVICES=n, tests only: n logical devices, logical d on physical d mod the real count -- pools, table
+ * caches, streams and this rule key on the logical ordinal, so a 1-GPU box walks the multi-device paths.) */
+SPEEXHIP_API int speexhip_device_count(void);   /* usable logical devices; <= 0: none (no CPU fallback) */
+SPEEXHIP_API SpeexHipResamplerState *speexhip_resampler_init_on(int device, uint32_t nb_channels, uint32_t in_rate,
+                                                                uint32_t out_rate, int quality, int *err);
+
 /* Replaces speex_resampler_destroy (speex_resampler.h:157, resample.c:868). */
 SPEEXHIP_API void speexhip_resampler_destroy(SpeexHipResamplerState *st);
 
@@ -231,6 +247,24 @@ SPEEXHIP_API int speexhip_resampler_process_chunks_float(SpeexHipResamplerState 
                                                          const float *const *in, uint32_t *in_len,
                                                          float *out, uint32_t *out_len);
 
+/* Many states, one call (round 5; SURVEY 8b: "a batched entry (array of states/buffers) for multi-stream launches").
+ * st[i] is an independent single-stream state -- what one `new SpeexResampler(...)` of the reference holds -- and
+ * (in[i], in_len[i], out[i], out_len[i]) are the arguments its own speexhip_resampler_process_interleaved_int call
+ * would get: HOST pointers, frames per channel, in = available / capacity, out = consumed / written.  Samples and
+ * counters of every state are exactly those of the n separate calls; codes[i] (may be NULL) receives call i's return
+ * code and the function returns the first one that is not SUCCESS.  What changes is the shape on the GPU: per device
+ * ONE transfer in, ONE launch per <= 32 states that share (rates, quality, channels, mode), ONE transfer out -- the
+ * shape BASELINE configs[4] is quoted on -- and states that live on different GPUs (SPEEXHIP_DEVICES=all) run side by
+ * side, each over its own PCIe link.  States whose channels the per-channel calls moved apart, states in the zero
+ * fallback and a state named twice take their own single call, in order.  Synchronous; a state must not be used
+ * by another thread meanwhile. */
+SPEEXHIP_API int speexhip_resampler_process_many_int(uint32_t n, SpeexHipResamplerState *const *st,
+                                                     const int16_t *const *in, uint32_t *in_len,
+                                                     int16_t *const *out, uint32_t *out_len, int *codes);
+SPEEXHIP_API int speexhip_resampler_process_many_float(uint32_t n, SpeexHipResamplerState *const *st,
+                                                       const float *const *in, uint32_t *in_len,
+                                                       float *const *out, uint32_t *out_len, int *codes);
+
 /* What the next processing call WOULD consume and produce for (in_len, out_capacity), without
  * touching the state: the counters are integer functions of the stream position alone, so a
  * binding can size its output buffer exactly before the call: the processing calls write
@@ -271,6 +305,10 @@ typedef struct SpeexHipInfo {
 } SpeexHipInfo;
 
 SPEEXHIP_API int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info);
+/* The same with the caller's sizeof(SpeexHipInfo): at most `struct_size` bytes are written, so a caller compiled
+ * against an older header (the struct grows at its end: accumulate_bits came in 0.2) is not overrun.  ABI note:
+ * 0.2 -> 0.3 adds entry points and SPEEXHIP_MODE_FAST_FIXED; SpeexHipInfo and the error codes are unchanged. */
+SPEEXHIP_API int speexhip_resampler_get_info2(SpeexHipResamplerState *st, SpeexHipInfo *info, uint32_t struct_size);
 
 /* Copies the last filt_len-1 consumed frames (interleaved float, the reference's `mem`: what
  * the next call's first outputs are computed from; resample.c:898-899) followed by the
@@ -285,6 +323,8 @@ SPEEXHIP_API int speexhip_resampler_get_history(SpeexHipResamplerState *st, floa
 SPEEXHIP_API SpeexHipBatch *speexhip_batch_init(uint32_t n_streams, uint32_t nb_channels,
                                                 uint32_t in_rate, uint32_t out_rate, int quality,
                                                 int *err);
+SPEEXHIP_API SpeexHipBatch *speexhip_batch_init_on(int device, uint32_t n_streams, uint32_t nb_channels,
+                                                   uint32_t in_rate, uint32_t out_rate, int quality, int *err);
 SPEEXHIP_API void speexhip_batch_destroy(SpeexHipBatch *b);
 SPEEXHIP_API int speexhip_batch_set_mode(SpeexHipBatch *b, int mode);
 SPEEXHIP_API int speexhip_batch_get_info(SpeexHipBatch *b, uint32_t stream, SpeexHipInfo *info);
@@ -382,6 +422,13 @@ SPEEXHIP_API int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, i
  * kernel.  The rules are fitted to a 256-CU device, which is what a process without a GPU assumes. */
 SPEEXHIP_API int speexhip_debug_launch_shape(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
                                              uint32_t streams, uint32_t frames, int float_io, uint32_t out[10]);
+
+/* Host only (tests): the placement rule above as a pure function -- the device of state number k on a node with
+ * `device_count` devices, env_device / env_devices = the values of SPEEXHIP_DEVICE / SPEEXHIP_DEVICES (NULL = unset),
+ * current_device = the calling thread's HIP device.  Returns the device, or -1 when the environment names a device
+ * the node does not have or cannot be parsed. */
+SPEEXHIP_API int speexhip_debug_placement(int device_count, const char *env_device, const char *env_devices,
+                                          uint64_t k, int current_device);
 
 /* Which kind of box is this?  Runs ~0.3 ms of packed fp32 FMAs with LDS reads on every CU and reports the shader
  * clock (GHz) the chip held meanwhile (median / slowest workgroup): the pool's boxes differ by 4-6 %, so bench

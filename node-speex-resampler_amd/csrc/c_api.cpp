@@ -3,8 +3,10 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/speexhip_resampler.h"
+#include "devices.h"
 #include "engine.h"
 #include "pool.h"
 
@@ -39,12 +41,23 @@ struct SpeexHipBatch_ {
 
 extern "C" {
 
+int speexhip_device_count(void) { return speexhip::devices::count(); }
+int speexhip_debug_placement(int device_count, const char *env_device, const char *env_devices, uint64_t k,
+                             int current_device) {
+  return speexhip::devices::placement_rule(device_count, env_device, env_devices, k, current_device);
+}
+
 SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channels, uint32_t in_rate,
                                                 uint32_t out_rate, int quality, int *err) {
+  return speexhip_resampler_init_on(-1, nb_channels, in_rate, out_rate, quality, err);
+}
+
+SpeexHipResamplerState *speexhip_resampler_init_on(int device, uint32_t nb_channels, uint32_t in_rate,
+                                                   uint32_t out_rate, int quality, int *err) {
   Batch *b = nullptr;
   int code = SPEEXHIP_ERR_SUCCESS;
   const int rc = guarded([&] {
-    b = Batch::create(1, nb_channels, in_rate, out_rate, quality, &code);
+    b = Batch::create(1, nb_channels, in_rate, out_rate, quality, &code, device < 0 ? -1 : device);
     return code;
   });
   if (err) *err = rc;
@@ -401,6 +414,39 @@ int speexhip_resampler_get_info(SpeexHipResamplerState *st, SpeexHipInfo *info) 
   return SPEEXHIP_ERR_SUCCESS;
 }
 
+int speexhip_resampler_get_info2(SpeexHipResamplerState *st, SpeexHipInfo *info, uint32_t struct_size) {
+  if (st == nullptr || info == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
+  SpeexHipInfo full;
+  st->batch->info(0, &full);
+  std::memcpy(info, &full, struct_size < sizeof(full) ? struct_size : sizeof(full));
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+namespace {
+int process_many(uint32_t n, SpeexHipResamplerState *const *st, const void *const *in, uint32_t *in_len,
+                 void *const *out, uint32_t *out_len, int *codes, bool float_io) {
+  if (n == 0) return SPEEXHIP_ERR_SUCCESS;
+  if (st == nullptr || in == nullptr || in_len == nullptr || out == nullptr || out_len == nullptr)
+    return SPEEXHIP_ERR_INVALID_ARG;
+  return guarded([&] {
+    std::vector<Batch *> b(n);
+    for (uint32_t i = 0; i < n; i++) b[i] = st[i] != nullptr ? st[i]->batch : nullptr;
+    return Batch::process_host_many(n, b.data(), in, in_len, out, out_len, float_io, codes);
+  });
+}
+}  // namespace
+
+int speexhip_resampler_process_many_int(uint32_t n, SpeexHipResamplerState *const *st, const int16_t *const *in,
+                                        uint32_t *in_len, int16_t *const *out, uint32_t *out_len, int *codes) {
+  return process_many(n, st, reinterpret_cast<const void *const *>(in), in_len, reinterpret_cast<void *const *>(out),
+                      out_len, codes, false);
+}
+int speexhip_resampler_process_many_float(uint32_t n, SpeexHipResamplerState *const *st, const float *const *in,
+                                          uint32_t *in_len, float *const *out, uint32_t *out_len, int *codes) {
+  return process_many(n, st, reinterpret_cast<const void *const *>(in), in_len, reinterpret_cast<void *const *>(out),
+                      out_len, codes, true);
+}
+
 int speexhip_resampler_get_history(SpeexHipResamplerState *st, float *dst) {
   if (st == nullptr || dst == nullptr) return SPEEXHIP_ERR_INVALID_ARG;
   return guarded([&] { return st->batch->history(0, dst); });
@@ -408,10 +454,15 @@ int speexhip_resampler_get_history(SpeexHipResamplerState *st, float *dst) {
 
 SpeexHipBatch *speexhip_batch_init(uint32_t n_streams, uint32_t nb_channels, uint32_t in_rate,
                                    uint32_t out_rate, int quality, int *err) {
+  return speexhip_batch_init_on(-1, n_streams, nb_channels, in_rate, out_rate, quality, err);
+}
+
+SpeexHipBatch *speexhip_batch_init_on(int device, uint32_t n_streams, uint32_t nb_channels, uint32_t in_rate,
+                                      uint32_t out_rate, int quality, int *err) {
   Batch *b = nullptr;
   int code = SPEEXHIP_ERR_SUCCESS;
   const int rc = guarded([&] {
-    b = Batch::create(n_streams, nb_channels, in_rate, out_rate, quality, &code);
+    b = Batch::create(n_streams, nb_channels, in_rate, out_rate, quality, &code, device < 0 ? -1 : device);
     return code;
   });
   if (err) *err = rc;
@@ -541,6 +592,6 @@ int speexhip_plan_filter_change(uint32_t old_filt_len, uint32_t new_filt_len, ui
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-const char *speexhip_version(void) { return "speexhip 0.2.0 gfx950"; }
+const char *speexhip_version(void) { return "speexhip 0.3.0 gfx950"; }
 
 }  // extern "C"

@@ -1,0 +1,108 @@
+// devices.cpp -- see devices.h.
+#include "devices.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace speexhip {
+namespace devices {
+namespace {
+
+int real_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return n;
+}
+
+int alias_count() {  // SPEEXHIP_ALIAS_DEVICES (diagnostics / tests), 0 = off
+  static const int n = [] {
+    const char *e = std::getenv("SPEEXHIP_ALIAS_DEVICES");
+    const int v = e != nullptr ? std::atoi(e) : 0;
+    return v > 0 && v <= 64 ? v : 0;
+  }();
+  return n;
+}
+
+// "3" -> 3; anything else (empty, signs, trailing text) -> -1
+int parse_ordinal(const std::string &s) {
+  if (s.empty() || s.size() > 4) return -1;
+  int v = 0;
+  for (char c : s) {
+    if (c < '0' || c > '9') return -1;
+    v = v * 10 + (c - '0');
+  }
+  return v;
+}
+
+std::atomic<uint64_t> g_states{0};
+
+}  // namespace
+
+int count() {
+  const int real = real_count();
+  if (real <= 0) return real;
+  const int alias = alias_count();
+  return alias != 0 ? alias : real;
+}
+
+int physical(int logical) {
+  if (alias_count() == 0) return logical;
+  const int real = real_count();
+  return real > 0 ? logical % real : logical;
+}
+
+int current() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return d;  // (with aliases: physical d is logical d, its lowest alias)
+}
+
+int placement_rule(int device_count, const char *env_device, const char *env_devices, uint64_t k, int current_device) {
+  if (device_count <= 0) return -1;
+  if (env_device != nullptr && env_device[0] != '\0') {
+    const int d = parse_ordinal(env_device);
+    return d >= 0 && d < device_count ? d : -1;
+  }
+  if (env_devices != nullptr && env_devices[0] != '\0') {
+    if (std::strcmp(env_devices, "all") == 0) return static_cast<int>(k % static_cast<uint64_t>(device_count));
+    std::vector<int> list;
+    std::string item;
+    for (const char *p = env_devices;; p++) {
+      if (*p == ',' || *p == '\0') {
+        const int d = parse_ordinal(item);
+        if (d < 0 || d >= device_count) return -1;
+        list.push_back(d);
+        item.clear();
+        if (*p == '\0') break;
+      } else if (*p != ' ') {
+        item.push_back(*p);
+      }
+    }
+    return list[k % list.size()];
+  }
+  return current_device >= 0 && current_device < device_count ? current_device : -1;
+}
+
+int place_next_state() {
+  const int n = count();
+  if (n <= 0) return -1;
+  const char *one = std::getenv("SPEEXHIP_DEVICE"), *many = std::getenv("SPEEXHIP_DEVICES");
+  const bool spread = (one == nullptr || one[0] == '\0') && many != nullptr && many[0] != '\0';
+  // (the counter only moves when the rule uses it: a process that never sets SPEEXHIP_DEVICES keeps no history)
+  const uint64_t k = spread ? g_states.fetch_add(1) : 0;
+  return placement_rule(n, one, many, k, current());
+}
+
+}  // namespace devices
+}  // namespace speexhip

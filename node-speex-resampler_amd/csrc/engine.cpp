@@ -1,6 +1,7 @@
 // engine.cpp -- see engine.h.
 #include "engine.h"
 
+#include "devices.h"
 #include "pool.h"
 
 #include <algorithm>
@@ -9,7 +10,10 @@
 #include <chrono>
 #include <cstring>
 #include <list>
+#include <map>
 #include <mutex>
+#include <thread>
+#include <tuple>
 
 namespace speexhip {
 namespace {
@@ -29,7 +33,8 @@ bool hip_failed(hipError_t e, const char *what) {
 // and leaves the thread's current device as it found it.
 class DeviceScope {
  public:
-  explicit DeviceScope(int device) {
+  explicit DeviceScope(int logical_device) {  // (devices.h: logical ordinals; physical = logical unless aliased)
+    const int device = devices::physical(logical_device);
     if (hipGetDevice(&prev_) != hipSuccess) prev_ = device;
     if (prev_ != device) err_ = hipSetDevice(device);
   }
@@ -166,12 +171,12 @@ uint32_t Batch::max_magic(uint32_t s) const {
 }
 
 Batch *Batch::create(uint32_t n_streams, uint32_t channels, uint32_t in_rate, uint32_t out_rate,
-                     int quality, int *err) {
-  return create_frac(n_streams, channels, in_rate, out_rate, in_rate, out_rate, quality, err);
+                     int quality, int *err, int device) {
+  return create_frac(n_streams, channels, in_rate, out_rate, in_rate, out_rate, quality, err, device);
 }
 
 Batch *Batch::create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_num, uint32_t ratio_den,
-                          uint32_t in_rate, uint32_t out_rate, int quality, int *err) {
+                          uint32_t in_rate, uint32_t out_rate, int quality, int *err, int device) {
   int e = SPEEXHIP_ERR_SUCCESS;
   // (owned until it is handed out: an exception below -- a bad_alloc in a position vector, in the design
   //  or in the tap rows; c_api.cpp maps it to a code -- must not leak the batch and what it already took)
@@ -187,6 +192,7 @@ Batch *Batch::create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_
     } else {
       b->n_streams_ = n_streams;
       b->channels_ = channels;
+      b->device_ = device;  // (< 0: the placement rule decides, setup())
       e = design_filter_frac(ratio_num, ratio_den, in_rate, out_rate, quality, &b->filter_, /*fill_table=*/false);
       if (e == SPEEXHIP_ERR_SUCCESS) e = b->setup();
       if (e != SPEEXHIP_ERR_SUCCESS) b.reset();
@@ -197,14 +203,27 @@ Batch *Batch::create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_
 }
 
 int Batch::setup() {
-  int count = 0;
-  if (hip_failed(hipGetDeviceCount(&count), "hipGetDeviceCount") || count <= 0) {
-    if (count <= 0) g_last_error = "HIP device error: no GPU visible (libspeexhip has no CPU fallback)";
+  const int count = devices::count();
+  if (count <= 0) {
+    g_last_error = count < 0 ? "HIP device error: hipGetDeviceCount failed (libspeexhip has no CPU fallback)"
+                             : "HIP device error: no GPU visible (libspeexhip has no CPU fallback)";
     return SPEEXHIP_ERR_DEVICE;
   }
-  HIP_TRY(hipGetDevice(&device_));
+  // Which GPU: the caller's choice (..._init_on), else the process-wide rule (devices.h: SPEEXHIP_DEVICE,
+  // SPEEXHIP_DEVICES=all -> state k on device k mod count, default = the thread's current device).
+  if (device_ < 0) {
+    device_ = devices::place_next_state();
+    if (device_ < 0) {
+      g_last_error = "HIP device error: SPEEXHIP_DEVICE / SPEEXHIP_DEVICES names a device this node does not have";
+      return SPEEXHIP_ERR_DEVICE;
+    }
+  } else if (device_ >= count) {
+    g_last_error = "HIP device error: device " + std::to_string(device_) + " requested, the node has " + std::to_string(count);
+    return SPEEXHIP_ERR_DEVICE;
+  }
+  ON_DEVICE();  // (everything below -- pool, tables, uploads -- runs on the state's device)
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device_));
+  HIP_TRY(hipGetDeviceProperties(&prop, devices::physical(device_)));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     g_last_error = std::string("HIP device error: built for gfx950 (MI355X), found ") + prop.gcnArchName;
     return SPEEXHIP_ERR_DEVICE;
@@ -1022,6 +1041,25 @@ int Batch::ensure_stage(size_t dev_in, size_t dev_out, size_t pin_in, size_t pin
   return rc;
 }
 
+// The second stream of a piecewise call: one of the pool's shared streams that is NOT this state's own one (on the
+// same stream the copies and the launches would simply take turns: correct, but nothing overlaps).
+bool Batch::have_copy_stream() {
+  if (copy_stream_ != nullptr) return copy_stream_ != own_stream_;
+  if (own_stream_ == nullptr && pool::stream_get(device_, &own_stream_) != hipSuccess) return false;
+  for (int tries = 0; tries < 4; tries++) {
+    hipStream_t s = nullptr;
+    if (pool::stream_get(device_, &s) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    if (s != own_stream_) {
+      copy_stream_ = s;
+      return true;
+    }
+  }
+  return false;
+}
+
 // A large owned-block call in `pieces` pieces (process_host_take).  Piece i: input frames [f_i, f_{i+1}) copied on
 // copy_stream_, an event behind the copy, and on own_stream_ -- waiting for that event -- one launch for the outputs
 // whose windows end inside the frames copied so far.  Output k of the call reads V-frames
@@ -1040,7 +1078,6 @@ int Batch::take_in_pieces(const void *in, uint32_t *in_len, uint32_t *out_len, b
   DrainOnExit drain(&own_stream_);
   int rc = ensure_stage(in_bytes, 0, 0, 0);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-  if (copy_stream_ == nullptr) HIP_TRY(pool::stream_get(device_, &copy_stream_));
   DrainOnExit drain_copy(&copy_stream_);
   for (uint32_t i = 0; i < pieces; i++)
     if (piece_ev_[i] == nullptr) HIP_TRY(pool::event_get(device_, &piece_ev_[i]));
@@ -1056,6 +1093,18 @@ int Batch::take_in_pieces(const void *in, uint32_t *in_len, uint32_t *out_len, b
     const int64_t k = ((x + 1) * den - 1 - static_cast<int64_t>(plan.begin.frac)) / num;  // last such output
     return static_cast<uint32_t>(std::min<int64_t>(k + 1, plan.produced));
   };
+  // A fast kernel runs every phase of a group over the group's whole zero-padded row (row_len >= taps steps), so an
+  // output's accumulator also meets samples up to row_len - taps frames BEHIND its own window -- times zero taps.
+  // Behind the frames copied so far the staging buffer holds stale pool memory (or the next piece arriving): as float
+  // samples that may be Inf / NaN, and 0 * NaN = NaN.  A piece therefore only stores the outputs whose
+  // whole ROW lies inside the frames copied so far: the bound moves back by the longest row any plan of this filter
+  // may run (+ one loop iteration of prefetch).
+  uint32_t guard = 0;
+  for (const PeriodPlan *t : {&period_, &period_fine_, &period_w16_, &period_pp_, &period_pp_w16_, &period64_, &period64_fine_})
+    if (t->usable && t->row_len > filter_.taps) guard = std::max(guard, t->row_len - filter_.taps);
+  for (const SlidePlan *t : {&slide_, &slide64_})
+    if (t->usable && t->row_len > filter_.taps) guard = std::max(guard, t->row_len - filter_.taps + t->p * t->num);
+  guard += 16;
   uint32_t done_out = 0;
   for (uint32_t i = 0; i < pieces; i++) {
     const uint64_t f0 = static_cast<uint64_t>(frames) * i / pieces, f1 = static_cast<uint64_t>(frames) * (i + 1) / pieces;
@@ -1064,7 +1113,7 @@ int Batch::take_in_pieces(const void *in, uint32_t *in_len, uint32_t *out_len, b
     HIP_TRY(hipEventRecord(piece_ev_[i], copy_stream_));
     HIP_TRY(hipStreamWaitEvent(own_stream_, piece_ev_[i], 0));
     const bool last = i + 1 == pieces;
-    const uint32_t upto = last ? plan.produced : outputs_within(f1);
+    const uint32_t upto = last ? plan.produced : std::max(done_out, outputs_within(f1 > guard ? f1 - guard : 0));
     const uint32_t n_out = upto > done_out ? upto - done_out : 0;
     if (n_out == 0 && !last) continue;
     // the piece's first output: the call's position advanced by done_out outputs
@@ -1143,7 +1192,7 @@ int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len
   if (split || zero_mode_) {
     rc = process_host(in, in_len, blk, out_len, float_io);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
-  } else if (pieces >= 2 && in != nullptr && in_bytes >= kZeroCopyBelow) {
+  } else if (pieces >= 2 && in != nullptr && in_bytes >= kZeroCopyBelow && frames < 0x40000000u && have_copy_stream()) {
     rc = take_in_pieces(in, in_len, out_len, float_io, blk, pieces);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   } else {
@@ -1444,6 +1493,260 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
     out_len[i] = plans[i].produced;
   }
   return SPEEXHIP_ERR_SUCCESS;
+}
+
+// ---- host-buffer calls of many single-stream states at once (engine.h) ---------------------------------------------
+namespace {
+// Staging of the many-states call: one per logical device, grow-only, taken from the pool and kept for the life of the
+// process like the shared streams.  A call holds the lock of every device it touches from its first copy to its last.
+struct ManyStage {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+  size_t d_in_cap = 0, d_out_cap = 0, h_in_cap = 0, h_out_cap = 0;
+  uint32_t seq = 0;
+};
+ManyStage &many_stage(int device) {
+  static std::mutex mu;
+  static std::map<int, ManyStage *> *all = new std::map<int, ManyStage *>();  // never destroyed, like the pool
+  std::lock_guard<std::mutex> lock(mu);
+  ManyStage *&m = (*all)[device];
+  if (m == nullptr) m = new ManyStage();
+  return *m;
+}
+int grow_stage(int device, char **buf, size_t *cap_now, size_t want, bool pinned) {
+  if (want <= *cap_now) return SPEEXHIP_ERR_SUCCESS;
+  if (pinned)
+    pool::pinned_put(*buf);
+  else
+    pool::device_put(device, *buf);
+  *buf = nullptr;
+  *cap_now = 0;
+  const size_t cap = pool::size_class(std::max<size_t>(want, 8192));
+  if (pinned)
+    HIP_TRY(pool::pinned_get(reinterpret_cast<void **>(buf), cap));
+  else
+    HIP_TRY(pool::device_get(device, reinterpret_cast<void **>(buf), cap));
+  *cap_now = cap;
+  return SPEEXHIP_ERR_SUCCESS;
+}
+inline size_t align64(size_t v) { return (v + 63) & ~static_cast<size_t>(63); }
+}  // namespace
+
+// The fused states of ONE device: idx = their positions in the caller's arrays.
+int Batch::many_on_device(int device, const std::vector<uint32_t> &idx, Batch *const *st, const void *const *in,
+                          uint32_t *in_len, void *const *out, uint32_t *out_len, bool float_io, int *rcs) {
+  ManyStage &ms = many_stage(device);
+  std::lock_guard<std::mutex> lock(ms.mu);
+  DeviceScope device_scope(device);
+  HIP_TRY(device_scope.error());
+  if (ms.stream == nullptr) HIP_TRY(pool::stream_get(device, &ms.stream));
+  DrainOnExit drain(&ms.stream);
+  const size_t es = float_io ? sizeof(float) : sizeof(int16_t);
+  struct Item {
+    uint32_t i;
+    Batch *b;
+    CallPlan plan;
+    size_t in_bytes, out_bytes, in_off, out_off;
+  };
+  std::vector<Item> items(idx.size());
+  size_t total_in = 0, total_out = 0;
+  for (size_t k = 0; k < idx.size(); k++) {
+    Item &it = items[k];
+    it.i = idx[k];
+    it.b = st[it.i];
+    EntryRules rules;
+    rules.block_in = it.b->block_in();
+    rules.float_entry = float_io;
+    it.plan = plan_call(it.b->filter_.num, it.b->filter_.den, in_len[it.i], out_len[it.i], it.b->P(0, 0), rules);
+    it.in_bytes = in[it.i] != nullptr ? static_cast<size_t>(in_len[it.i]) * it.b->channels_ * es : 0;
+    it.out_bytes = static_cast<size_t>(it.plan.produced) * it.b->channels_ * es;
+    total_in += align64(it.in_bytes);
+    total_out += align64(it.out_bytes);
+  }
+  // Small calls (a server's 10-20 ms frames, a Transform's 64 KiB chunks) are all latency: the kernels read and write
+  // pinned memory straight through PCIe, one wait (process_host's small-call path).  Larger ones: inputs of >= 256 KB
+  // go from the caller's pageable memory by the runtime's own staged copies, smaller ones are gathered in the pinned
+  // buffer and travel as ONE copy; the same on the way out.
+  const bool zero_copy = total_in < kZeroCopyBelow && total_out < kZeroCopyBelow;
+  // layout: the small buffers first (one contiguous range = one copy), then the large ones
+  size_t small_in = 0, small_out = 0, off_in = 0, off_out = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (Item &it : items) {
+      const bool big_in = !zero_copy && it.in_bytes >= kDirectCopyBytes, big_out = !zero_copy && it.out_bytes >= kDirectCopyBytes;
+      if (big_in == (pass == 1)) {
+        it.in_off = off_in;
+        off_in += align64(it.in_bytes);
+        if (pass == 0) small_in = off_in;
+      }
+      if (big_out == (pass == 1)) {
+        it.out_off = off_out;
+        off_out += align64(it.out_bytes);
+        if (pass == 0) small_out = off_out;
+      }
+    }
+  int rc = grow_stage(device, &ms.h_in, &ms.h_in_cap, zero_copy ? total_in : small_in, true);
+  if (rc == SPEEXHIP_ERR_SUCCESS) rc = grow_stage(device, &ms.h_out, &ms.h_out_cap, (zero_copy ? total_out : small_out) + 128, true);
+  if (rc == SPEEXHIP_ERR_SUCCESS && !zero_copy) rc = grow_stage(device, &ms.d_in, &ms.d_in_cap, total_in, false);
+  if (rc == SPEEXHIP_ERR_SUCCESS && !zero_copy) rc = grow_stage(device, &ms.d_out, &ms.d_out_cap, total_out, false);
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  char *src_base = zero_copy ? ms.h_in : ms.d_in, *dst_base = zero_copy ? ms.h_out : ms.d_out;
+  for (const Item &it : items) {
+    if (it.in_bytes == 0) continue;
+    if (zero_copy || it.in_bytes < kDirectCopyBytes)
+      std::memcpy(ms.h_in + it.in_off, in[it.i], it.in_bytes);
+    else
+      HIP_TRY(hipMemcpyAsync(ms.d_in + it.in_off, in[it.i], it.in_bytes, hipMemcpyHostToDevice, ms.stream));
+  }
+  if (!zero_copy && small_in != 0) HIP_TRY(hipMemcpyAsync(ms.d_in, ms.h_in, small_in, hipMemcpyHostToDevice, ms.stream));
+  // launches: the states that share (tables, mode, window format) go together, 32 per launch
+  std::map<std::tuple<const void *, int, bool>, std::vector<Item *>> groups;
+  for (Item &it : items) {
+    if (float_io) it.b->float_seen_ = true;
+    if (in_len[it.i] != 0 && out_len[it.i] != 0) it.b->started_[0] = 1;  // resample.c:886
+    if (it.plan.produced == 0 && it.plan.magic_used + it.plan.consumed == 0) continue;  // nothing to run: the state stays
+    groups[std::make_tuple(static_cast<const void *>(it.b->tables_.get()), it.b->mode_, it.b->float_seen_)].push_back(&it);
+  }
+  for (auto &kv : groups) {
+    std::vector<Item *> &g = kv.second;
+    for (size_t g0 = 0; g0 < g.size(); g0 += kMaxPackedStreams) {
+      const uint32_t cnt = static_cast<uint32_t>(std::min<size_t>(kMaxPackedStreams, g.size() - g0));
+      DescPack pack;
+      std::memset(&pack, 0, sizeof(pack));
+      uint32_t max_out = 0;
+      for (uint32_t j = 0; j < cnt; j++) {
+        Item &it = *g[g0 + j];
+        Batch *b = it.b;
+        rc = b->chain_to(ms.stream);  // (each state's calls stay ordered, whatever stream its last one ran on)
+        if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+        StreamDesc &d = pack.d[j];
+        const FilterSpec &f = b->filter_;
+        d.in = in[it.i] != nullptr ? src_base + it.in_off : nullptr;
+        d.hist = b->d_hist_[b->hist_cur_];
+        d.out = dst_base + it.out_off;
+        d.hist_next = b->d_hist_[b->hist_cur_ ^ 1];
+        d.in_frames = in_len[it.i];
+        d.n_out = it.plan.produced;
+        d.consumed = it.plan.magic_used + it.plan.consumed;
+        d.hist_frames = f.taps - 1 + it.plan.begin.magic;
+        d.hist_keep = f.taps - 1 + it.plan.end.magic;
+        d.last0 = it.plan.begin.last;
+        d.frac0 = it.plan.begin.frac;
+        d.k_shift = phase_index_of(f.num, f.den, it.plan.begin.frac);
+        d.base_shift = it.plan.begin.last - static_cast<int32_t>((static_cast<uint64_t>(d.k_shift) * f.num) / f.den);
+        d.tile_begin = 0;
+        d.m_total = static_cast<uint32_t>((static_cast<uint64_t>(d.k_shift) + d.n_out + f.den - 1) / f.den);
+        max_out = std::max(max_out, it.plan.produced);
+      }
+      rc = g[g0]->b->launch_chunk(pack.d, pack, cnt, max_out, float_io, ms.stream);
+      if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+      for (uint32_t j = 0; j < cnt; j++) g[g0 + j]->b->hist_cur_ ^= 1;
+    }
+  }
+  for (Item &it : items) {
+    for (uint32_t c = 0; c < it.b->channels_; c++) it.b->P(0, c) = it.plan.end;
+    in_len[it.i] = it.plan.consumed;
+    out_len[it.i] = it.plan.produced;
+    rcs[it.i] = SPEEXHIP_ERR_SUCCESS;
+  }
+  // results back
+  if (zero_copy) {
+    volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(ms.h_out + ((ms.h_out_cap - 64) & ~static_cast<size_t>(63)));
+    const uint32_t seq = ++ms.seq;
+    *done = seq - 1;
+    bool signalled = false;
+    if (!groups.empty() && hipStreamWriteValue32(ms.stream, const_cast<uint32_t *>(done), seq, 0) == hipSuccess) {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+      for (uint32_t spins = 0; !signalled; spins++) {
+        signalled = __atomic_load_n(const_cast<const uint32_t *>(done), __ATOMIC_ACQUIRE) == seq;
+        if (signalled) break;
+        __builtin_ia32_pause();
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
+    if (!signalled) HIP_TRY(hipStreamSynchronize(ms.stream));
+    drain.armed = false;
+    for (const Item &it : items)
+      if (it.out_bytes != 0) std::memcpy(out[it.i], ms.h_out + it.out_off, it.out_bytes);
+    return SPEEXHIP_ERR_SUCCESS;
+  }
+  if (small_out != 0) HIP_TRY(hipMemcpyAsync(ms.h_out, ms.d_out, small_out, hipMemcpyDeviceToHost, ms.stream));
+  for (const Item &it : items)
+    if (it.out_bytes >= kDirectCopyBytes)
+      HIP_TRY(hipMemcpyAsync(out[it.i], ms.d_out + it.out_off, it.out_bytes, hipMemcpyDeviceToHost, ms.stream));
+  HIP_TRY(hipStreamSynchronize(ms.stream));
+  drain.armed = false;
+  for (const Item &it : items)
+    if (it.out_bytes != 0 && it.out_bytes < kDirectCopyBytes) std::memcpy(out[it.i], ms.h_out + it.out_off, it.out_bytes);
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in, uint32_t *in_len, void *const *out,
+                             uint32_t *out_len, bool float_io, int *codes) {
+  std::vector<int> rcs(n, SPEEXHIP_ERR_SUCCESS);
+  std::map<int, std::vector<uint32_t>> by_device;  // (ordered: two concurrent calls lock their devices in one order)
+  std::vector<uint32_t> apart;                     // states that take the single call (in the caller's order)
+  for (uint32_t i = 0; i < n; i++) {
+    Batch *b = st[i];
+    if (b == nullptr || (out[i] == nullptr && out_len[i] != 0)) {
+      rcs[i] = SPEEXHIP_ERR_INVALID_ARG;
+      continue;
+    }
+    bool earlier = false;  // a state named twice: its second call must see the first one's end state
+    for (uint32_t j = 0; j < i && !earlier; j++) earlier = st[j] == b;
+    // (rare states -- channels moved apart by the per-channel calls, the zero fallback, batches of several streams --
+    //  keep their own call's rules)
+    if (earlier || b->n_streams_ != 1 || !b->uniform(0) || b->zero_mode_)
+      apart.push_back(i);
+    else
+      by_device[b->device_].push_back(i);
+  }
+  std::vector<int> dev_rc(by_device.size(), SPEEXHIP_ERR_SUCCESS);
+  std::vector<std::string> dev_err(by_device.size());
+  auto run_device = [&](size_t slot, int device, const std::vector<uint32_t> *idx) {
+    try {
+      dev_rc[slot] = many_on_device(device, *idx, st, in, in_len, out, out_len, float_io, rcs.data());
+    } catch (const std::bad_alloc &) {
+      dev_rc[slot] = SPEEXHIP_ERR_ALLOC_FAILED;
+    }
+    if (dev_rc[slot] != SPEEXHIP_ERR_SUCCESS) {
+      dev_err[slot] = g_last_error;  // (the text lives per thread)
+      for (uint32_t i : *idx) rcs[i] = dev_rc[slot];
+    }
+  };
+  {
+    // GPUs side by side: every further device of the call gets a thread of its own (a GPU is a PCIe link of its own,
+    // and the runtime's pageable copies keep the calling thread busy while they run)
+    std::vector<std::thread> workers;
+    size_t slot = 0;
+    const std::vector<uint32_t> *first_idx = nullptr;
+    int first_device = 0;
+    for (auto &kv : by_device) {
+      if (slot == 0) {
+        first_idx = &kv.second;
+        first_device = kv.first;
+      } else {
+        workers.emplace_back(run_device, slot, kv.first, &kv.second);
+      }
+      slot++;
+    }
+    if (first_idx != nullptr) run_device(0, first_device, first_idx);
+    for (std::thread &w : workers) w.join();
+    for (size_t k = 0; k < dev_rc.size(); k++)
+      if (dev_rc[k] != SPEEXHIP_ERR_SUCCESS) {
+        g_last_error = dev_err[k];
+        break;
+      }
+  }
+  for (uint32_t i : apart) rcs[i] = st[i]->process_host(in[i], &in_len[i], out[i], &out_len[i], float_io);
+  int first = SPEEXHIP_ERR_SUCCESS;
+  for (uint32_t i = 0; i < n; i++) {
+    if (codes != nullptr) codes[i] = rcs[i];
+    if (first == SPEEXHIP_ERR_SUCCESS && rcs[i] != SPEEXHIP_ERR_SUCCESS) first = rcs[i];
+  }
+  return first;
 }
 
 }  // namespace speexhip

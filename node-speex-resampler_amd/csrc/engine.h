@@ -51,12 +51,13 @@ size_t release_cached_tables();
 
 class Batch {
  public:
-  // Returns nullptr and sets *err on failure.  Uses the calling thread's current HIP device.
+  // Returns nullptr and sets *err on failure.  device: logical ordinal (devices.h), or < 0 for the process-wide
+  // placement rule (SPEEXHIP_DEVICE / SPEEXHIP_DEVICES, default = the calling thread's current HIP device).
   static Batch *create(uint32_t n_streams, uint32_t channels, uint32_t in_rate, uint32_t out_rate,
-                       int quality, int *err);
+                       int quality, int *err, int device = -1);
   // speex_resampler_init_frac (resample.c:799): ratio given separately from the nominal rates.
   static Batch *create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_num, uint32_t ratio_den,
-                            uint32_t in_rate, uint32_t out_rate, int quality, int *err);
+                            uint32_t in_rate, uint32_t out_rate, int quality, int *err, int device = -1);
   ~Batch();
 
   // Device-resident call for all streams; asynchronous on `stream`.
@@ -71,6 +72,14 @@ class Batch {
   // of twice (device or pinned buffer -> copy -> the caller's buffer).  *block = nullptr when nothing was written.
   int process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len, bool float_io, void **block);
   static void release_block(void *block);
+  // Host-buffer calls of n single-stream states at once (SURVEY 8b "array of states/buffers"; the reference's model
+  // is many instances in one process, src/index.ts:18-45): per GPU one transfer in, one launch per <= 32 states that
+  // share a filter, one transfer out; states on different GPUs run side by side (a GPU is a PCIe link of its own).
+  // Samples and counters of state i are exactly those of process_host(in[i], &in_len[i], out[i], &out_len[i]);
+  // codes[i] (may be null) = that call's return code; returns the first code that is not SUCCESS.
+  static int process_host_many(uint32_t n, Batch *const *states, const void *const *in, uint32_t *in_len,
+                               void *const *out, uint32_t *out_len, bool float_io, int *codes);
+  int device() const { return device_; }
   // n_chunks consecutive host-buffer calls of a single-stream batch as one launch; outputs are
   // written back to back into `out` (room for the sum of the capacities).
   int process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_t *in_len, void *out,
@@ -149,6 +158,9 @@ class Batch {
                    hipStream_t stream);
   // a large host call as pieces: input copies on a second stream, one launch per piece behind each (process_host_take)
   int take_in_pieces(const void *in, uint32_t *in_len, uint32_t *out_len, bool float_io, void *blk, uint32_t pieces);
+  static int many_on_device(int device, const std::vector<uint32_t> &idx, Batch *const *st, const void *const *in,
+                            uint32_t *in_len, void *const *out, uint32_t *out_len, bool float_io, int *rcs);
+  bool have_copy_stream();  // copy_stream_ = a pool stream other than own_stream_ (false: none -> no piecewise call)
 
   FilterSpec filter_;
   uint32_t n_streams_ = 0, channels_ = 0;

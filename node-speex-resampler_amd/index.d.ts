@@ -45,7 +45,17 @@ declare class SpeexResampler {
     /** grow-only byte size that caps the frames one call may return */
     _outBufferSize: number;
 
-    constructor(channels: number, inRate: number, outRate: number, quality?: number);
+    /**
+     * The reference's four arguments.  `options.device` (extension) pins the instance to one GPU; without it the
+     * library places it when its native state is made: the process's current GPU, or -- environment
+     * SPEEXHIP_DEVICES=all -- instance number k of the process on GPU k mod the GPU count (SPEEXHIP_DEVICE=k: all on k).
+     */
+    constructor(channels: number, inRate: number, outRate: number, quality?: number, options?: { device?: number });
+
+    /** GPU the instance lives on (-1 until the first call made its native state) */
+    readonly device: number;
+    /** GPUs the library can place instances on */
+    static deviceCount(): number;
 
     /**
      * interleaved s16le PCM in, resampled s16le PCM out: a fresh Buffer the caller owns, like the reference's.
@@ -58,7 +68,9 @@ declare class SpeexResampler {
     /** consecutive chunks in one GPU launch; result[i] equals processChunk(chunks[i]) */
     processChunks(chunks: Buffer[]): Buffer[];
     /**
-     * processChunk off the event loop; calls on one instance stay in order.  While one is pending the
+     * processChunk off the event loop; calls on one instance stay in order.  Calls of DIFFERENT instances that become
+     * ready in the same tick leave as one native call: one transfer in, one GPU launch per <= 32 instances of equal
+     * (channels, rates, quality) and GPU, one transfer out (a server's connections, each with a small chunk per tick).  While one is pending the
      * synchronous methods of the same instance (processChunk, processChunks, processChunkFloat, setRate,
      * setQuality, skipZeros, resetMem, flush, destroy) throw: await the promise first.
      */
@@ -100,6 +112,28 @@ export declare class SpeexResamplerTransform extends Transform {
     constructor(channels: number, inRate: number, outRate: number, quality?: number,
                 options?: SpeexResamplerTransformOptions);
     _transform(chunk: Buffer, encoding: string, callback: TransformCallback): void;
+}
+
+/**
+ * Extension: n independent streams of one (channels, rates, quality), each a SpeexResampler with its own capacity
+ * rule, whose chunks of one step run together -- per GPU one transfer in, one launch per <= 32 streams, one transfer
+ * out; with SPEEXHIP_DEVICES=all or `options.devices` the streams spread over the node's GPUs (stream k on the k-th
+ * listed GPU modulo their number).  Entry k of a result equals `streams[k].processChunk(chunks[k])`.
+ */
+export declare class SpeexResamplerBatch {
+    channels: number;
+    inRate: number;
+    outRate: number;
+    quality: number;
+    streams: SpeexResampler[];
+    readonly length: number;
+    constructor(nStreams: number, channels: number, inRate: number, outRate: number, quality?: number,
+                options?: { devices?: number[] });
+    /** one chunk per stream (null: the stream sits the step out) -> one fresh Buffer per stream (null likewise) */
+    processChunks(chunks: Array<Buffer | null>): Array<Buffer | null>;
+    processChunksAsync(chunks: Array<Buffer | null>): Promise<Array<Buffer | null>>;
+    setMode(mode: 'fast' | 'exact' | 'fast_f32' | 'fast_fixed'): void;
+    destroy(): void;
 }
 
 export default SpeexResampler;

@@ -26,11 +26,15 @@ class SpeexResampler {
    * Same four arguments as the reference class: channel count (>= 1), input and output sample
    * rates in Hz, Speex quality 0..10 (default 7; higher = longer filter).
    */
-  constructor(channels, inRate, outRate, quality = 7) {
+  constructor(channels, inRate, outRate, quality = 7, options = undefined) {
     this.channels = channels;
     this.inRate = inRate;
     this.outRate = outRate;
     this.quality = quality;
+    // Extension (ignored by reference-style callers): { device: k } pins this instance to GPU k.  Without it the
+    // library's process-wide rule places the instance when its native state is made (first call): the calling
+    // thread's current GPU, or -- SPEEXHIP_DEVICES=all -- instance number k of the process on GPU k mod the GPU count.
+    this._device = options && Number.isInteger(options.device) ? options.device : -1;
     this._resamplerPtr = undefined; // native handle (the reference keeps a WASM pointer here)
     this._outBufferSize = -1;       // bytes; grow-only, drives the capacity rule below
     this._inFlight = 0;             // processChunkAsync calls not yet settled (extension)
@@ -62,7 +66,7 @@ class SpeexResampler {
       // throws Error(strerror(code)) and leaves _resamplerPtr unset, so a bad configuration
       // fails again on every call (reference src/index.ts:59-66)
       this._resamplerPtr = speexModule.init(this.channels >>> 0, this.inRate >>> 0,
-        this.outRate >>> 0, this.quality | 0);
+        this.outRate >>> 0, this.quality | 0, this._device);
     }
     // reference src/index.ts:80-87: the output buffer only ever grows ...
     const outBufferLengthTarget = Math.ceil(chunk.length * this.outRate / this.inRate);
@@ -104,7 +108,7 @@ class SpeexResampler {
     }
     if (!this._resamplerPtr) {
       this._resamplerPtr = speexModule.init(this.channels >>> 0, this.inRate >>> 0,
-        this.outRate >>> 0, this.quality | 0);
+        this.outRate >>> 0, this.quality | 0, this._device);
     }
     return this._resamplerPtr;
   }
@@ -138,7 +142,19 @@ class SpeexResampler {
     } catch (e) {
       return Promise.reject(e);
     }
-    const run = () => speexModule.processAsync(this._resamplerPtr, chunk, args[0], args[1]);
+    // Calls of DIFFERENT instances that become ready in the same tick leave as ONE native call
+    // (speexhip_resampler_process_many_int: per GPU one transfer in, one launch per <= 32 instances with the same
+    // rates / quality / channels, one transfer out) -- a server's many connections are many instances
+    // (reference src/index.ts:18-45), each with a small chunk per tick.  A lone call takes the single-state path.
+    const run = () => new Promise((resolve, reject) => {
+      tickQueue.push({ handle: this._resamplerPtr, chunk, inFrames: args[0], cap: args[1], resolve, reject });
+      if (!tickScheduled) {
+        tickScheduled = true;
+        // (process.nextTick from inside a promise continuation runs once the continuations that are ready now have
+        //  run: the calls of one tick are all in the queue by then)
+        process.nextTick(flushTick);
+      }
+    });
     this._inFlight++;
     const settle = () => { this._inFlight--; };
     const p = (this._pending || Promise.resolve()).then(run, run);
@@ -219,8 +235,123 @@ class SpeexResampler {
     this._resamplerPtr = undefined;
     this._outBufferSize = -1;
   }
+
+  /** GPU this instance lives on (-1 until its native state exists). */
+  get device() { return this._resamplerPtr ? speexModule.getInfo(this._resamplerPtr).device : this._device; }
 }
 SpeexResampler.initPromise = globalModulePromise;
+/** Extension: GPUs the library can place instances on (<= 0: none -- there is no CPU fallback). */
+SpeexResampler.deviceCount = () => {
+  if (!speexModule) {
+    throw new Error('You need to wait for SpeexResampler.initPromise before calling this method');
+  }
+  return speexModule.deviceCount();
+};
+
+// processChunkAsync calls that became ready in this tick (see there)
+const tickQueue = [];
+let tickScheduled = false;
+function flushTick() {
+  tickScheduled = false;
+  const jobs = tickQueue.splice(0, tickQueue.length);
+  if (jobs.length === 0) return;
+  if (jobs.length === 1) {
+    const j = jobs[0];
+    speexModule.processAsync(j.handle, j.chunk, j.inFrames, j.cap).then(j.resolve, j.reject);
+    return;
+  }
+  let promise;
+  try {
+    promise = speexModule.processManyAsync(jobs.map((j) => j.handle), jobs.map((j) => j.chunk),
+      jobs.map((j) => j.inFrames), jobs.map((j) => j.cap));
+  } catch (e) {
+    for (const j of jobs) j.reject(e);
+    return;
+  }
+  promise.then((outs) => { jobs.forEach((j, i) => j.resolve(outs[i])); },
+    (e) => { for (const j of jobs) j.reject(e); });
+}
+
+/**
+ * Extension: n independent streams with one (channels, rates, quality) -- n SpeexResampler instances, each with its
+ * own grow-only capacity rule (reference src/index.ts:80-95 per instance) -- whose chunks of one step travel and run
+ * together: per GPU one transfer in, ONE launch per <= 32 streams, one transfer out.  With SPEEXHIP_DEVICES=all (or
+ * options.devices = [0, 1, ...]) the streams spread over the node's GPUs, stream k on the k-th of them modulo their
+ * number, and the GPUs work side by side.  Results are byte-identical (mode 'exact') / within +-1 LSB (default) to
+ * calling processChunk on n separate instances.
+ */
+class SpeexResamplerBatch {
+  constructor(nStreams, channels, inRate, outRate, quality = 7, options = undefined) {
+    if (!Number.isInteger(nStreams) || nStreams < 1) throw new Error('nStreams must be a positive integer');
+    this.channels = channels;
+    this.inRate = inRate;
+    this.outRate = outRate;
+    this.quality = quality;
+    const devices = options && Array.isArray(options.devices) && options.devices.length > 0 ? options.devices : null;
+    this.streams = [];
+    for (let k = 0; k < nStreams; k++) {
+      this.streams.push(new SpeexResampler(channels, inRate, outRate, quality,
+        devices ? { device: devices[k % devices.length] } : undefined));
+    }
+  }
+
+  get length() { return this.streams.length; }
+
+  _gather(chunks) {
+    if (!Array.isArray(chunks) || chunks.length !== this.streams.length) {
+      throw new Error('processChunks expects one chunk (or null) per stream: ' + this.streams.length);
+    }
+    const picked = { index: [], handles: [], chunks: [], inFrames: [], caps: [] };
+    for (let k = 0; k < chunks.length; k++) {
+      if (chunks[k] === null || chunks[k] === undefined) continue; // this stream sits the step out
+      const [f, cap] = this.streams[k]._prepare(chunks[k], Uint16Array.BYTES_PER_ELEMENT);
+      picked.index.push(k);
+      picked.handles.push(this.streams[k]._resamplerPtr);
+      picked.chunks.push(chunks[k]);
+      picked.inFrames.push(f);
+      picked.caps.push(cap);
+    }
+    return picked;
+  }
+
+  /**
+   * One chunk of interleaved s16le PCM per stream (null / undefined: the stream sits this step out) in, one fresh
+   * Buffer per stream out (null for streams that sat out): entry k is what streams[k].processChunk(chunks[k]) returns.
+   */
+  processChunks(chunks) {
+    for (const r of this.streams) r._refuseWhileAsyncPending('SpeexResamplerBatch.processChunks');
+    const g = this._gather(chunks);
+    const outs = g.handles.length > 0 ? speexModule.processMany(g.handles, g.chunks, g.inFrames, g.caps) : [];
+    const result = new Array(this.streams.length).fill(null);
+    g.index.forEach((k, i) => { result[k] = outs[i]; });
+    return result;
+  }
+
+  /** processChunks off the event loop; steps are chained, so the streams advance in the order of the calls. */
+  processChunksAsync(chunks) {
+    let g;
+    try {
+      for (const r of this.streams) r._refuseWhileAsyncPending('SpeexResamplerBatch.processChunksAsync');
+      g = this._gather(chunks);
+    } catch (e) {
+      return Promise.reject(e);
+    }
+    const run = () => (g.handles.length > 0
+      ? speexModule.processManyAsync(g.handles, g.chunks, g.inFrames, g.caps) : Promise.resolve([]))
+      .then((outs) => {
+        const result = new Array(this.streams.length).fill(null);
+        g.index.forEach((k, i) => { result[k] = outs[i]; });
+        return result;
+      });
+    const p = (this._pending || Promise.resolve()).then(run, run);
+    this._pending = p.then(() => undefined, () => undefined);
+    return p;
+  }
+
+  setMode(mode) { for (const r of this.streams) r.setMode(mode); }
+
+  destroy() { for (const r of this.streams) r.destroy(); }
+}
 /**
  * Extension.  Destroyed (or collected) states leave their device buffers, pinned staging buffers and
  * filter tables in a process-wide pool for the next `new SpeexResampler` (DESIGN 3.5); this hands
@@ -327,4 +458,5 @@ class SpeexResamplerTransform extends Transform {
 }
 
 exports.SpeexResamplerTransform = SpeexResamplerTransform;
+exports.SpeexResamplerBatch = SpeexResamplerBatch;
 exports.default = SpeexResampler;

@@ -84,8 +84,8 @@ static SpeexHipResamplerState *lock_state(napi_env env, napi_value v, Handle **h
 /* init(channels, inRate, outRate, quality) -> handle; throws Error(strerror(code)) like
  * src/index.ts:63-65 */
 static napi_value Init(napi_env env, napi_callback_info info) {
-  size_t argc = 4;
-  napi_value argv[4];
+  size_t argc = 5;
+  napi_value argv[5];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   uint32_t ch = 0, in_rate = 0, out_rate = 0;
   int32_t quality = 0;
@@ -93,8 +93,15 @@ static napi_value Init(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_get_value_uint32(env, argv[1], &in_rate));
   NAPI_OK(napi_get_value_uint32(env, argv[2], &out_rate));
   NAPI_OK(napi_get_value_int32(env, argv[3], &quality));
+  /* optional fifth argument: the GPU (speexhip_resampler_init_on); absent / negative = the library's placement rule
+   * (SPEEXHIP_DEVICE, SPEEXHIP_DEVICES=all: instance k of the process on GPU k mod the device count) */
+  int32_t device = -1;
+  if (argc >= 5) {
+    napi_valuetype t;
+    if (napi_typeof(env, argv[4], &t) == napi_ok && t == napi_number) NAPI_OK(napi_get_value_int32(env, argv[4], &device));
+  }
   int err = 0;
-  SpeexHipResamplerState *st = speexhip_resampler_init(ch, in_rate, out_rate, quality, &err);
+  SpeexHipResamplerState *st = speexhip_resampler_init_on(device, ch, in_rate, out_rate, quality, &err);
   if (st == NULL) {
     napi_throw_error(env, NULL, speexhip_resampler_strerror(err));
     return NULL;
@@ -139,7 +146,10 @@ static int buffer_or_null(napi_env env, napi_value v, void **data, size_t *bytes
 
 /* external Buffers over pinned blocks of the library (process_common) */
 static const size_t kExternalMin = 4096;            /* below this a copy is cheaper than a finalizer */
+/* (process-wide: the addon may be loaded by several environments -- the main thread and worker_threads -- and
+ *  finalizers run on whichever thread owns the Buffer: every access is an atomic builtin) */
 static size_t g_external_bytes = 0;
+static size_t g_take_calls = 0, g_take_no_block = 0; /* stats(): results left in pinned blocks / slab full, copied instead */
 static int g_no_external = 0; /* SPEEXHIP_NAPI_COPY=1: always copy (A/B, tests) */
 static void finalize_block(napi_env env, void *data, void *hint) {
   const size_t bytes = (size_t)hint;
@@ -194,6 +204,8 @@ static napi_value process_common(napi_env env, napi_callback_info info, size_t s
     take_rc = sample_bytes == 2
                   ? speexhip_resampler_process_interleaved_int_take(st, (const int16_t *)in_data, &take_in, &take_out, (int16_t **)&block)
                   : speexhip_resampler_process_interleaved_float_take(st, (const float *)in_data, &take_in, &take_out, (float **)&block);
+  if (take_rc == SPEEXHIP_ERR_NO_BLOCK && made_bytes >= kExternalMin && !g_no_external)
+    __atomic_fetch_add(&g_take_no_block, 1, __ATOMIC_RELAXED);
   if (take_rc != SPEEXHIP_ERR_NO_BLOCK) { /* (NO_BLOCK: the state is untouched -> the copying path below) */
     int rc = take_rc;
     uint32_t cap_len = take_out;
@@ -205,11 +217,24 @@ static napi_value process_common(napi_env env, napi_callback_info info, size_t s
     }
     napi_value ext;
     __atomic_fetch_add(&g_external_bytes, made_bytes, __ATOMIC_RELAXED);
-    if (napi_create_external_buffer(env, made_bytes, block, finalize_block, (void *)made_bytes, &ext) != napi_ok) {
+    __atomic_fetch_add(&g_take_calls, 1, __ATOMIC_RELAXED);
+    const napi_status ext_status = napi_create_external_buffer(env, made_bytes, block, finalize_block, (void *)made_bytes, &ext);
+    if (ext_status != napi_ok) {
+      /* The state has already advanced and the audio exists only in the block: a runtime that refuses external
+       * Buffers (napi_no_external_buffers_allowed: Electron, V8 sandbox) or is out of memory for the wrapper must not
+       * cost the caller its samples.  Copy them into an ordinary Buffer, hand the block back, and stop asking for
+       * external Buffers for good when the runtime does not allow them. */
       __atomic_fetch_sub(&g_external_bytes, made_bytes, __ATOMIC_RELAXED);
+      if ((int)ext_status == 22 /* napi_no_external_buffers_allowed (Node >= 18.?; not in this header) */) g_no_external = 1;
+      napi_value copy;
+      void *copied = NULL;
+      const napi_status copy_status = napi_create_buffer_copy(env, made_bytes, block, &copied, &copy);
       speexhip_block_release(block);
-      napi_throw_error(env, NULL, "speexhip N-API failure: napi_create_external_buffer");
-      return NULL;
+      if (copy_status != napi_ok) {
+        napi_throw_error(env, NULL, "speexhip N-API failure: napi_create_external_buffer and napi_create_buffer_copy");
+        return NULL;
+      }
+      return copy;
     }
     int64_t adjusted = 0;
     (void)napi_adjust_external_memory(env, (int64_t)made_bytes, &adjusted); /* the collector sees what the Buffer holds */
@@ -569,7 +594,276 @@ static napi_value ReleaseCachedMemory(napi_env env, napi_callback_info info) {
   return v;
 }
 
-static napi_value ModuleInit(napi_env env, napi_value exports) {
+/* ---- many states, one call (speexhip_resampler_process_many_int): SpeexResamplerBatch.processChunks and the
+ * coalescer of processChunkAsync calls issued in one tick (index.js) ---- */
+typedef struct {
+  uint32_t n;
+  Handle **h;               /* per entry */
+  Handle **locked;          /* the distinct handles, sorted by address (lock order) */
+  uint32_t n_locked;
+  SpeexHipResamplerState **st;
+  const int16_t **in;
+  int16_t **out;
+  uint32_t *in_len, *out_len, *will_make, *channels;
+  int *codes;
+  /* asynchronous form */
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref *refs;           /* handles, chunks, result Buffers: 3 per entry (chunk ref may be NULL) */
+  napi_ref result_ref;      /* the result array */
+  int rc;
+  char errmsg[256];
+} ManyJob;
+
+static void many_free(napi_env env, ManyJob *j) {
+  if (j == NULL) return;
+  if (j->refs != NULL) {
+    for (uint32_t i = 0; i < 3 * j->n; i++)
+      if (j->refs[i] != NULL) napi_delete_reference(env, j->refs[i]);
+  }
+  if (j->result_ref != NULL) napi_delete_reference(env, j->result_ref);
+  free(j->h);
+  free(j->locked);
+  free(j->st);
+  free(j->in);
+  free(j->out);
+  free(j->in_len);
+  free(j->out_len);
+  free(j->will_make);
+  free(j->channels);
+  free(j->codes);
+  free(j->refs);
+  free(j);
+}
+
+static int cmp_handle(const void *a, const void *b) {
+  const uintptr_t x = (uintptr_t)*(Handle *const *)a, y = (uintptr_t)*(Handle *const *)b;
+  return x < y ? -1 : x > y;
+}
+static void many_lock(ManyJob *j) {
+  for (uint32_t k = 0; k < j->n_locked; k++) pthread_mutex_lock(&j->locked[k]->lock);
+}
+static void many_unlock(ManyJob *j) {
+  for (uint32_t k = j->n_locked; k-- > 0;) pthread_mutex_unlock(&j->locked[k]->lock);
+}
+/* the call itself, locks held; 0 or a code with its text in errmsg */
+static void many_run(ManyJob *j) {
+  for (uint32_t i = 0; i < j->n; i++) {
+    j->st[i] = j->h[i]->st;
+    if (j->st[i] == NULL) {
+      j->rc = SPEEXHIP_ERR_BAD_STATE;
+      snprintf(j->errmsg, sizeof(j->errmsg), "%s", speexhip_resampler_strerror(j->rc));
+      return;
+    }
+  }
+  j->rc = speexhip_resampler_process_many_int(j->n, j->st, j->in, j->in_len, j->out, j->out_len, j->codes);
+  if (j->rc == 0)
+    for (uint32_t i = 0; i < j->n; i++)
+      if (j->out_len[i] != j->will_make[i]) j->rc = SPEEXHIP_ERR_BAD_STATE;
+  if (j->rc != 0) snprintf(j->errmsg, sizeof(j->errmsg), "%s", speexhip_resampler_strerror(j->rc));
+}
+
+/* Parses (handles[], chunks[], inFrames[], caps[]), sizes the results from the states' counters and creates the
+ * result Buffers; returns the job with *result = the array of Buffers, or NULL with an exception pending. */
+static ManyJob *many_prepare(napi_env env, napi_callback_info info, napi_value *result, int keep_refs) {
+  size_t argc = 4;
+  napi_value argv[4];
+  if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < 4) {
+    napi_throw_type_error(env, NULL, "processMany expects (handle[], Buffer[], number[], number[])");
+    return NULL;
+  }
+  uint32_t n = 0;
+  if (napi_get_array_length(env, argv[0], &n) != napi_ok) {
+    napi_throw_type_error(env, NULL, "processMany expects (handle[], Buffer[], number[], number[])");
+    return NULL;
+  }
+  ManyJob *j = (ManyJob *)calloc(1, sizeof(ManyJob));
+  const size_t m = n ? n : 1;
+  if (j != NULL) {
+    j->n = n;
+    j->h = (Handle **)calloc(m, sizeof(Handle *));
+    j->locked = (Handle **)calloc(m, sizeof(Handle *));
+    j->st = (SpeexHipResamplerState **)calloc(m, sizeof(*j->st));
+    j->in = (const int16_t **)calloc(m, sizeof(*j->in));
+    j->out = (int16_t **)calloc(m, sizeof(*j->out));
+    j->in_len = (uint32_t *)calloc(m, sizeof(uint32_t));
+    j->out_len = (uint32_t *)calloc(m, sizeof(uint32_t));
+    j->will_make = (uint32_t *)calloc(m, sizeof(uint32_t));
+    j->channels = (uint32_t *)calloc(m, sizeof(uint32_t));
+    j->codes = (int *)calloc(m, sizeof(int));
+    if (keep_refs) j->refs = (napi_ref *)calloc(3 * m, sizeof(napi_ref));
+  }
+  if (j == NULL || !j->h || !j->locked || !j->st || !j->in || !j->out || !j->in_len || !j->out_len || !j->will_make ||
+      !j->channels || !j->codes || (keep_refs && !j->refs)) {
+    many_free(env, j);
+    napi_throw_error(env, NULL, speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED));
+    return NULL;
+  }
+  const char *fail = NULL;
+  int type_error = 0;
+  for (uint32_t i = 0; fail == NULL && i < n; i++) {
+    napi_value hv, c, a, b;
+    void *p = NULL, *data = NULL;
+    size_t bytes = 0;
+    if (napi_get_element(env, argv[0], i, &hv) != napi_ok || napi_get_value_external(env, hv, &p) != napi_ok || p == NULL ||
+        napi_get_element(env, argv[1], i, &c) != napi_ok || !buffer_or_null(env, c, &data, &bytes) ||
+        napi_get_element(env, argv[2], i, &a) != napi_ok || napi_get_value_uint32(env, a, &j->in_len[i]) != napi_ok ||
+        napi_get_element(env, argv[3], i, &b) != napi_ok || napi_get_value_uint32(env, b, &j->out_len[i]) != napi_ok) {
+      fail = "processMany expects (handle[], Buffer[], number[], number[])";
+      type_error = 1;
+      break;
+    }
+    j->h[i] = (Handle *)p;
+    j->in[i] = (const int16_t *)data;
+    /* (the chunk's byte count is checked against its frames below, once the channel count is known) */
+    j->channels[i] = (uint32_t)bytes;  /* borrowed until then */
+    if (keep_refs) {
+      if (napi_create_reference(env, hv, 1, &j->refs[3 * i]) != napi_ok ||
+          (data != NULL && napi_create_reference(env, c, 1, &j->refs[3 * i + 1]) != napi_ok))
+        fail = "speexhip N-API failure: napi_create_reference";
+    }
+  }
+  if (fail == NULL) {
+    memcpy(j->locked, j->h, n * sizeof(Handle *));
+    qsort(j->locked, n, sizeof(Handle *), cmp_handle);
+    for (uint32_t k = 0; k < n; k++) {
+      if (k > 0 && j->locked[k] == j->locked[k - 1]) {
+        fail = "processMany: a state may appear once per call";
+        break;
+      }
+    }
+    j->n_locked = n;
+  }
+  if (fail == NULL && napi_create_array_with_length(env, n, result) != napi_ok) fail = "speexhip N-API failure: napi_create_array";
+  if (fail == NULL) {
+    many_lock(j);
+    for (uint32_t i = 0; fail == NULL && i < n; i++) {
+      SpeexHipResamplerState *st = j->h[i]->st;
+      if (st == NULL) {
+        fail = speexhip_resampler_strerror(SPEEXHIP_ERR_BAD_STATE);
+        break;
+      }
+      SpeexHipInfo si;
+      speexhip_resampler_get_info(st, &si);
+      const size_t bytes = j->channels[i], frame_bytes = (size_t)si.nb_channels * 2;
+      j->channels[i] = si.nb_channels;
+      if (j->in[i] != NULL && (size_t)j->in_len[i] * frame_bytes > bytes) {
+        fail = "input frame count exceeds the chunk";
+        break;
+      }
+      uint32_t will_use = 0;
+      speexhip_resampler_peek(st, j->in_len[i], j->out_len[i], 0, &will_use, &j->will_make[i]);
+      napi_value buf;
+      void *dst = NULL;
+      if (napi_create_buffer(env, (size_t)j->will_make[i] * frame_bytes, &dst, &buf) != napi_ok ||
+          napi_set_element(env, *result, i, buf) != napi_ok ||
+          (keep_refs && napi_create_reference(env, buf, 1, &j->refs[3 * i + 2]) != napi_ok)) {
+        fail = "speexhip N-API failure: building the result array";
+        break;
+      }
+      static uint64_t nowhere = 0;
+      j->out[i] = (int16_t *)(dst != NULL ? dst : (void *)&nowhere);
+    }
+    if (fail != NULL || keep_refs) many_unlock(j); /* (the synchronous form keeps the locks until the call is done) */
+  }
+  if (fail != NULL) {
+    many_free(env, j);
+    if (type_error)
+      napi_throw_type_error(env, NULL, fail);
+    else
+      napi_throw_error(env, NULL, fail);
+    return NULL;
+  }
+  return j;
+}
+
+/* processMany(handles[], chunks[], inFrames[], outCapacities[]) -> Buffer[]: entry i is what
+ * process(handles[i], chunks[i], inFrames[i], outCapacities[i]) returns. */
+static napi_value ProcessMany(napi_env env, napi_callback_info info) {
+  napi_value result = NULL;
+  ManyJob *j = many_prepare(env, info, &result, 0);
+  if (j == NULL) return NULL;
+  many_run(j); /* (locks held since many_prepare) */
+  many_unlock(j);
+  const int rc = j->rc;
+  char msg[256];
+  snprintf(msg, sizeof(msg), "%s", j->errmsg);
+  many_free(env, j);
+  if (rc != 0) {
+    napi_throw_error(env, NULL, msg);
+    return NULL;
+  }
+  return result;
+}
+
+static void many_execute(napi_env env, void *data) {
+  (void)env;
+  ManyJob *j = (ManyJob *)data;
+  many_lock(j);
+  many_run(j);
+  many_unlock(j);
+}
+static void many_complete(napi_env env, napi_status status, void *data) {
+  ManyJob *j = (ManyJob *)data;
+  napi_value v;
+  if (status == napi_ok && j->rc == 0 && napi_get_reference_value(env, j->result_ref, &v) == napi_ok) {
+    napi_resolve_deferred(env, j->deferred, v);
+  } else {
+    napi_value msg;
+    napi_create_string_utf8(env, j->rc != 0 ? j->errmsg : "speexhip: asynchronous call failed", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &v);
+    napi_reject_deferred(env, j->deferred, v);
+  }
+  napi_delete_async_work(env, j->work);
+  many_free(env, j);
+}
+/* processManyAsync(...) -> Promise<Buffer[]>: the same call on a libuv pool thread.  The results are sized on the
+ * calling thread from the states' counters, so no state of the call may be used until the promise settles (index.js
+ * keeps one call per instance in flight). */
+static napi_value ProcessManyAsync(napi_env env, napi_callback_info info) {
+  napi_value result = NULL, promise, name;
+  ManyJob *j = many_prepare(env, info, &result, 1);
+  if (j == NULL) return NULL;
+  if (napi_create_reference(env, result, 1, &j->result_ref) != napi_ok ||
+      napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+      napi_create_string_utf8(env, "speexhip.processManyAsync", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+      napi_create_async_work(env, NULL, name, many_execute, many_complete, j, &j->work) != napi_ok ||
+      napi_queue_async_work(env, j->work) != napi_ok) {
+    many_free(env, j);
+    napi_throw_error(env, NULL, "speexhip N-API failure: queueing processManyAsync");
+    return NULL;
+  }
+  return promise;
+}
+
+/* deviceCount() -> GPUs the library can place states on (speexhip_device_count) */
+static napi_value DeviceCount(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value v;
+  NAPI_OK(napi_create_int32(env, speexhip_device_count(), &v));
+  return v;
+}
+
+/* stats() -> { externalBytes, takeCalls, takeNoBlock }: bytes of pinned result blocks JavaScript holds as external
+ * Buffers, results delivered that way, and calls that found the slab full and copied instead (diagnostics) */
+static napi_value Stats(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value obj, v;
+  NAPI_OK(napi_create_object(env, &obj));
+  NAPI_OK(napi_create_double(env, (double)__atomic_load_n(&g_external_bytes, __ATOMIC_RELAXED), &v));
+  NAPI_OK(napi_set_named_property(env, obj, "externalBytes", v));
+  NAPI_OK(napi_create_double(env, (double)__atomic_load_n(&g_take_calls, __ATOMIC_RELAXED), &v));
+  NAPI_OK(napi_set_named_property(env, obj, "takeCalls", v));
+  NAPI_OK(napi_create_double(env, (double)__atomic_load_n(&g_take_no_block, __ATOMIC_RELAXED), &v));
+  NAPI_OK(napi_set_named_property(env, obj, "takeNoBlock", v));
+  return obj;
+}
+
+/* NAPI_MODULE_INIT: the well-known symbol napi_register_module_v1, so that every environment of the process -- the main
+ * thread and each worker_threads Worker -- can load the addon (a module that registers itself from a static constructor
+ * loads once per process).  The addon keeps no per-environment state: handles are externals, the counters above are
+ * atomics, the library underneath is thread-safe per state. */
+NAPI_MODULE_INIT() {
   const char *copy_env = getenv("SPEEXHIP_NAPI_COPY");
   g_no_external = copy_env != NULL && copy_env[0] != '\0' && copy_env[0] != '0';
   napi_property_descriptor props[] = {
@@ -590,10 +884,13 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
       {"strerror", NULL, StrError, NULL, NULL, NULL, napi_default, NULL},
       {"version", NULL, Version, NULL, NULL, NULL, napi_default, NULL},
       {"releaseCachedMemory", NULL, ReleaseCachedMemory, NULL, NULL, NULL, napi_default, NULL},
+      {"processMany", NULL, ProcessMany, NULL, NULL, NULL, napi_default, NULL},
+      {"processManyAsync", NULL, ProcessManyAsync, NULL, NULL, NULL, napi_default, NULL},
+      {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
+      {"stats", NULL, Stats, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props) != napi_ok)
     napi_throw_error(env, NULL, "speexhip: cannot define exports");
   return exports;
 }
 
-NAPI_MODULE(NODE_GYP_MODULE_NAME, ModuleInit)

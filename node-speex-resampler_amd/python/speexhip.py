@@ -51,6 +51,10 @@ EXPORTS = [
     "speexhip_resampler_release_stream", "speexhip_batch_release_stream", "speexhip_debug_device_clock",
     "speexhip_resampler_process_interleaved_int_take", "speexhip_resampler_process_interleaved_float_take",
     "speexhip_block_release", "speexhip_debug_plan64", "speexhip_debug_launch_shape",
+    # round 5: device placement, many states per call
+    "speexhip_device_count", "speexhip_resampler_init_on", "speexhip_batch_init_on",
+    "speexhip_resampler_process_many_int", "speexhip_resampler_process_many_float",
+    "speexhip_resampler_get_info2", "speexhip_debug_placement",
 ]
 
 
@@ -187,6 +191,21 @@ def lib():
         L.speexhip_debug_plan.argtypes = [u32, u32, i32, u32, C.POINTER(u32)]
         L.speexhip_release_cached_memory.restype = C.c_uint64
         L.speexhip_release_cached_memory.argtypes = []
+        if hasattr(L, "speexhip_resampler_process_many_int") or "SPEEXHIP_LIB_PATH" not in os.environ:
+            L.speexhip_device_count.restype = i32
+            L.speexhip_device_count.argtypes = []
+            L.speexhip_resampler_init_on.restype = p
+            L.speexhip_resampler_init_on.argtypes = [i32, u32, u32, u32, i32, C.POINTER(C.c_int)]
+            L.speexhip_batch_init_on.restype = p
+            L.speexhip_batch_init_on.argtypes = [i32, u32, u32, u32, u32, i32, C.POINTER(C.c_int)]
+            for f in (L.speexhip_resampler_process_many_int, L.speexhip_resampler_process_many_float):
+                f.restype = i32
+                f.argtypes = [u32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), pu32, C.POINTER(C.c_void_p), pu32,
+                              C.POINTER(C.c_int)]
+            L.speexhip_resampler_get_info2.restype = i32
+            L.speexhip_resampler_get_info2.argtypes = [p, C.c_void_p, u32]
+            L.speexhip_debug_placement.restype = i32
+            L.speexhip_debug_placement.argtypes = [i32, C.c_char_p, C.c_char_p, C.c_uint64, i32]
         _lib = L
     return _lib
 
@@ -263,6 +282,42 @@ def debug_launch_shape(ratio_num, ratio_den, quality, channels, streams, frames,
             "splits": v[5], "wave_groups": v[6], "shares": v[7], "threads": v[8], "touch": bool(v[9])}
 
 
+def device_count():
+    """logical devices the library can place states on (speexhip_device_count)"""
+    return lib().speexhip_device_count()
+
+
+def placement(device_count_, env_device, env_devices, k, current=0):
+    """host-only: the placement rule (speexhip_debug_placement); None = unset environment variable"""
+    enc = lambda v: None if v is None else str(v).encode()
+    return lib().speexhip_debug_placement(device_count_, enc(env_device), enc(env_devices), k, current)
+
+
+def process_many(states, chunks, capacities, dtype=np.int16):
+    """speexhip_resampler_process_many_int / _float: chunks[i] (frames x channels, or None with capacities[i] =
+    (null_frames, capacity)) through states[i], all in one call.  Returns (outputs, consumed, codes)."""
+    n = len(states)
+    hs, ins, outs = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    il, ol, codes = (C.c_uint32 * n)(), (C.c_uint32 * n)(), (C.c_int * n)()
+    keep, bufs = [], []
+    for i, (st, ch_) in enumerate(zip(states, chunks)):
+        hs[i] = st._h
+        if ch_ is None:
+            ins[i], il[i], ol[i] = None, capacities[i][0], capacities[i][1]
+        else:
+            a = np.ascontiguousarray(ch_, dtype=dtype).reshape(-1, st.channels)
+            keep.append(a)
+            ins[i], il[i], ol[i] = a.ctypes.data, a.shape[0], capacities[i]
+        b = np.zeros((max(int(ol[i]), 1), st.channels), dtype)
+        bufs.append(b)
+        outs[i] = b.ctypes.data
+    fn = lib().speexhip_resampler_process_many_int if dtype == np.int16 else lib().speexhip_resampler_process_many_float
+    rc = fn(n, hs, ins, il, outs, ol, codes)
+    if rc not in (0, ERR_ALLOC_FAILED):
+        raise RuntimeError(strerror(rc))
+    return [bufs[i][: ol[i]].copy() for i in range(n)], list(il), list(codes)
+
+
 def device_clock():
     """(median GHz, slowest workgroup's GHz) the chip holds under an FIR-like load: the kind of box this is"""
     a, b = C.c_double(), C.c_double()
@@ -300,9 +355,11 @@ class Resampler:
     """Thin object over the C ABI state: host-buffer ``process`` and device-pointer
     ``process_device`` (same signature as oracle.Oracle.process for the shared test driver)."""
 
-    def __init__(self, channels, in_rate, out_rate, quality=7, mode=None, ratio=None):
+    def __init__(self, channels, in_rate, out_rate, quality=7, mode=None, ratio=None, device=None):
         err = C.c_int(0)
-        if ratio is None:
+        if device is not None:
+            self._h = lib().speexhip_resampler_init_on(device, channels, in_rate, out_rate, quality, C.byref(err))
+        elif ratio is None:
             self._h = lib().speexhip_resampler_init(channels, in_rate, out_rate, quality, C.byref(err))
         else:
             self._h = lib().speexhip_resampler_init_frac(channels, ratio[0], ratio[1], in_rate, out_rate,

@@ -11,7 +11,7 @@ const crypto = require('crypto');
 const { Readable } = require('stream');
 const mod = require('../index.js');
 const SpeexResampler = mod.default;
-const { SpeexResamplerTransform } = mod;
+const { SpeexResamplerTransform, SpeexResamplerBatch } = mod;
 
 const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '../../tests/golden/golden.json')));
 const assert = (c, m) => { if (!c) throw new Error(m); };
@@ -351,6 +351,150 @@ function externalBufferTest() {
   console.log('external Buffers: caller-owned, stable, recycled');
 }
 
+// Round 5: many streams through ONE native call -- SpeexResamplerBatch.processChunks and the coalescer of
+// processChunkAsync calls issued in one tick -- against the same streams as separate SpeexResampler instances
+// (the reference's model, src/index.ts:18-45): byte-identical in 'exact' mode, +-1 LSB in the default mode,
+// counters and positions equal, including 160-frame (640-byte) chunks where the capacity rule drops input (F5),
+// ragged lengths, empty chunks and streams that sit a step out.
+async function batchTest() {
+  const addon = require('../speex_hip_napi.node');
+  const N = 32;
+  const close = (got, want, what) => {
+    assert(got.length === want.length, `${what}: ${got.length} bytes, want ${want.length}`);
+    for (let i = 0; i < want.length; i += 2) {
+      assert(Math.abs(got.readInt16LE(i) - want.readInt16LE(i)) <= 1, `${what}: sample ${i / 2} off by more than 1 LSB`);
+    }
+  };
+  for (const mode of ['exact', 'fast']) {
+    const batch = new SpeexResamplerBatch(N, 2, 44100, 48000, 7);
+    const apart = [];
+    for (let k = 0; k < N; k++) apart.push(new SpeexResampler(2, 44100, 48000, 7));
+    batch.processChunks(new Array(N).fill(Buffer.alloc(0)));   // lazy init, then the mode
+    batch.setMode(mode);
+    for (const r of apart) { r.processChunk(Buffer.alloc(0)); r.setMode(mode); }
+    // frames per step; k = stream: 640-byte chunks (160 stereo frames) after a long one are the F5 case
+    const steps = [(k) => 4410 + k, () => 160, () => 160, (k) => (k % 3 === 0 ? null : 7), () => 0, () => 16384,
+      (k) => 160 + (k % 2), (k) => 100000 + 13 * k, () => 160, (k) => (k === 5 ? null : 2000)];
+    steps.forEach((frames, step) => {
+      const chunks = [];
+      for (let k = 0; k < N; k++) {
+        const f = frames(k);
+        chunks.push(f === null ? null : lcg(f, 2, 1000 * step + k));
+      }
+      const got = batch.processChunks(chunks);
+      for (let k = 0; k < N; k++) {
+        if (chunks[k] === null) { assert(got[k] === null, 'a stream that sat out returns null'); continue; }
+        const want = apart[k].processChunk(chunks[k]);
+        if (mode === 'exact') assert(got[k].equals(want), `batch step ${step} stream ${k}: bytes differ (exact)`);
+        else close(got[k], want, `batch step ${step} stream ${k}`);
+        const a = addon.getInfo(batch.streams[k]._resamplerPtr), b = addon.getInfo(apart[k]._resamplerPtr);
+        assert(a.last_sample === b.last_sample && a.samp_frac_num === b.samp_frac_num, `batch step ${step} stream ${k}: position`);
+      }
+    });
+    // the asynchronous form, two steps queued at once: chained, same bytes
+    const c1 = [], c2 = [];
+    for (let k = 0; k < N; k++) { c1.push(lcg(3000 + k, 2, 70000 + k)); c2.push(lcg(160, 2, 80000 + k)); }
+    const [o1, o2] = await Promise.all([batch.processChunksAsync(c1), batch.processChunksAsync(c2)]);
+    for (let k = 0; k < N; k++) {
+      const w1 = apart[k].processChunk(c1[k]), w2 = apart[k].processChunk(c2[k]);
+      if (mode === 'exact') assert(o1[k].equals(w1) && o2[k].equals(w2), `async batch stream ${k}: bytes differ`);
+      else { close(o1[k], w1, `async batch stream ${k}`); close(o2[k], w2, `async batch stream ${k} (2)`); }
+    }
+    batch.destroy();
+    for (const r of apart) r.destroy();
+  }
+  // the coalescer: instances of THREE different filters call processChunkAsync in the same tick -- one native call,
+  // one launch per filter -- and again with a second call per instance queued behind the first
+  {
+    const kinds = [[2, 44100, 48000, 7], [1, 24000, 48000, 10], [2, 48000, 44100, 5]];
+    const mk = () => kinds.map((a) => [0, 1, 2, 3, 4].map(() => {
+      const r = new SpeexResampler(a[0], a[1], a[2], a[3]);
+      r.processChunk(Buffer.alloc(0));
+      r.setMode('exact');
+      return r;
+    })).reduce((x, y) => x.concat(y), []);
+    const fused = mk(), apart = mk();
+    const before = addon.stats ? addon.stats() : null;
+    const jobs = [], want = [];
+    fused.forEach((r, i) => {
+      const a = lcg(2000 + 17 * i, r.channels, 500 + i), b = lcg(160, r.channels, 600 + i);
+      jobs.push(r.processChunkAsync(a), r.processChunkAsync(b));
+      want.push(apart[i].processChunk(a), apart[i].processChunk(b));
+    });
+    const got = await Promise.all(jobs);
+    got.forEach((g, i) => assert(g.equals(want[i]), `coalesced processChunkAsync ${i}: bytes differ`));
+    fused.concat(apart).forEach((r) => r.destroy());
+    void before;
+  }
+  // misuse through the addon itself: a state twice in one call, a destroyed state, lengths that do not fit
+  {
+    const r = new SpeexResampler(2, 44100, 48000, 7);
+    r.processChunk(Buffer.alloc(0));
+    const h = r._resamplerPtr, c = lcg(100, 2, 1);
+    const msg = (f) => { try { f(); return null; } catch (e) { return e.message; } };
+    assert(/once per call/.test(msg(() => addon.processMany([h, h], [c, c], [100, 100], [200, 200]))), 'a state twice');
+    assert(/exceeds the chunk/.test(msg(() => addon.processMany([h], [c], [101], [200]))), 'frames beyond the chunk');
+    assert(addon.processMany([], [], [], []).length === 0, 'empty call');
+    r.destroy();
+    assert(msg(() => addon.processMany([h], [c], [100], [200])) === 'Bad resampler state.', 'destroyed state in a many-call');
+  }
+  // placement: an explicit device, a device the node does not have
+  {
+    const n = SpeexResampler.deviceCount();
+    assert(n >= 1, 'deviceCount');
+    const r = new SpeexResampler(2, 44100, 48000, 7, { device: n - 1 });
+    assert(r.device === n - 1 && r.processChunk(lcg(1000, 2, 3)).length > 0 && r.device === n - 1, 'explicit device');
+    r.destroy();
+    let m = null;
+    try { new SpeexResampler(2, 44100, 48000, 7, { device: n }).processChunk(lcg(10, 2, 3)); } catch (e) { m = e.message; }
+    assert(m !== null && /device/.test(m), `a device the node does not have must fail loudly (${m})`);
+    if (process.env.SPEEXHIP_DEVICES === 'all' && n > 1) {
+      const b = new SpeexResamplerBatch(2 * n, 2, 44100, 48000, 7);
+      b.processChunks(new Array(2 * n).fill(Buffer.alloc(0)));
+      const seen = b.streams.map((s) => s.device);
+      for (let k = 1; k < seen.length; k++) assert(seen[k] === (seen[0] + k) % n, `SPEEXHIP_DEVICES=all: devices ${seen}`);
+      b.destroy();
+      console.log(`placement: ${2 * n} streams on devices ${seen.join(',')}`);
+    }
+  }
+  console.log('batch / coalescer / placement: many streams per native call, bytes of the separate instances');
+}
+
+// The addon under worker_threads: every Worker loads it (NAPI_MODULE_INIT), has a state of its own and gets the
+// reference's bytes ('exact' mode, sha1 of the main thread's result).
+async function workerTest() {
+  let wt;
+  try { wt = require('worker_threads'); } catch (e) { console.log('worker_threads not available: skipped'); return; }
+  const pcm = lcg(50000, 2, 4321);
+  const main = new SpeexResampler(2, 44100, 48000, 7);
+  main.setMode('exact');
+  const want = sha1(main.processChunk(pcm));
+  main.destroy();
+  const src = `
+    const { parentPort, workerData } = require('worker_threads');
+    const crypto = require('crypto');
+    const R = require(workerData.index).default;
+    R.initPromise.then(() => {
+      const out = [];
+      for (let k = 0; k < 3; k++) {
+        const r = new R(2, 44100, 48000, 7);
+        r.setMode('exact');
+        out.push(crypto.createHash('sha1').update(r.processChunk(Buffer.from(workerData.pcm))).digest('hex'));
+        if (k % 2) r.destroy();
+      }
+      parentPort.postMessage(out);
+    }).catch((e) => parentPort.postMessage(['error: ' + e.message]));`;
+  const runs = [0, 1].map(() => new Promise((res, rej) => {
+    const w = new wt.Worker(src, { eval: true, workerData: { index: path.join(__dirname, '../index.js'), pcm } });
+    w.on('message', res);
+    w.on('error', rej);
+  }));
+  for (const hashes of await Promise.all(runs)) {
+    assert(hashes.length === 3 && hashes.every((h) => h === want), `a Worker's bytes differ: ${hashes}`);
+  }
+  console.log('worker_threads: two Workers, states of their own, the main thread\'s bytes');
+}
+
 (async () => {
   const early = (() => { try { new SpeexResampler(1, 8000, 8000).processChunk(Buffer.alloc(2)); return null; } catch (e) { return e.message; } })();
   assert(early === 'You need to wait for SpeexResampler.initPromise before calling this method', 'initPromise guard');
@@ -363,5 +507,7 @@ function externalBufferTest() {
   poolTest();
   externalBufferTest();
   modeTest();
+  await batchTest();
+  await workerTest();
   console.log('ALL NODE TESTS PASSED');
 })().catch((e) => { console.error(e); process.exit(1); });

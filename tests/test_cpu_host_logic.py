@@ -592,3 +592,25 @@ def test_round4_launch_rules_shares_fetch_and_phase_pairs_by_launch():
     assert t["shares"] == 1 and not t["touch"] and t["wave_groups"] == 15, t
     # configurations that do not run the fp32 period kernel answer with zeros
     assert shape(1, 24000, 48000, 1, 1 << 20, q=10)["r"] == 0 and shape(2, 44100, 48000, 1, 4096, q=10)["r"] == 0
+
+
+def test_device_placement_rule():
+    """Round 5: which GPU a new state lives on (csrc/devices.cpp) as a pure function of the device count, the two
+    environment variables and the state's number in its process -- SPEEXHIP_DEVICES=all is BASELINE configs[4]'s
+    "stream s on GPU s mod 8" inside ONE process (the reference's model: many instances, one module)."""
+    P = speexhip.placement
+    assert [P(8, None, "all", k) for k in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+    assert [P(8, None, "0,2,5", k) for k in range(7)] == [0, 2, 5, 0, 2, 5, 0]
+    assert [P(8, None, " 1, 0", k) for k in range(3)] == [1, 0, 1]
+    assert [P(8, "3", "all", k) for k in range(4)] == [3, 3, 3, 3]        # SPEEXHIP_DEVICE wins
+    assert [P(8, None, None, k, current=6) for k in range(3)] == [6, 6, 6]  # neither: the thread's current device
+    assert P(8, "", "", 4, current=2) == 2                                  # empty = unset
+    # what the node does not have, or cannot be read: -1 (init then fails with SPEEXHIP_ERR_DEVICE)
+    for bad in [(8, "8", None), (8, "-1", None), (8, "x", None), (8, None, "0,8"), (8, None, "0,,1"), (8, None, "all,1"),
+                (0, None, "all"), (-1, None, None)]:
+        assert P(bad[0], bad[1], bad[2], 0) == -1, bad
+    # 256 streams over 8 GPUs: 32 each
+    counts = [0] * 8
+    for k in range(256):
+        counts[P(8, None, "all", k)] += 1
+    assert counts == [32] * 8

@@ -1791,3 +1791,170 @@ def test_large_owned_block_calls_run_in_pieces_and_match_the_oracle():
                               "large_owned_block_calls or owned_block_calls_return"],
                              env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+# ---- round 5: many states per call, device placement, piecewise float calls on stale staging memory ----------------
+
+def _many_states_scenario(modes=(speexhip.MODE_EXACT, speexhip.MODE_FAST)):
+    """40 single-stream states of three filters through speexhip_resampler_process_many_int, step after step, each
+    against an oracle state of its own: bytes (EXACT: identical; FAST: +-1 LSB), counters, positions, histories.  The
+    steps cover the wrapper's capacity rule on 160-frame chunks (F5: input dropped), ragged lengths, empty and NULL
+    inputs, a state named twice in one call, and sizes on both sides of the pinned / staged transport."""
+    kinds = [(2, 44100, 48000, 7)] * 34 + [(1, 24000, 48000, 10)] * 3 + [(8, 48000, 44100, 5)] * 3
+    for mode in modes:
+        states = [speexhip.Resampler(*k, mode=mode) for k in kinds]
+        refs = [orc.Oracle(*k) for k in kinds]
+        caps = [-1] * len(kinds)           # the wrapper's grow-only byte size, per instance (src/index.ts:80-87)
+        steps = [lambda s: 4410 + s, lambda s: 160, lambda s: 160 + s % 2, lambda s: 0, lambda s: 70000 + 31 * s,
+                 lambda s: 160, lambda s: 300000 if s % 8 == 0 else 500, lambda s: 7]
+        for step, frames_of in enumerate(steps):
+            chunks, cap_frames = [], []
+            for s, (ch, i, o, q) in enumerate(kinds):
+                f = frames_of(s)
+                x = orc.lcg_pcm(f * ch, 977 * step + s).reshape(f, ch)
+                caps[s] = max(caps[s], -(-x.size * 2 * o // i))
+                chunks.append(x)
+                cap_frames.append(caps[s] // ch // 2)
+            outs, used, codes = speexhip.process_many(states, chunks, cap_frames)
+            assert codes == [0] * len(kinds)
+            for s, (ch, i, o, q) in enumerate(kinds):
+                want, wu = refs[s].process(chunks[s], cap_frames[s])
+                assert used[s] == wu and outs[s].shape == want.shape, (mode, step, s, used[s], wu)
+                if mode == speexhip.MODE_EXACT:
+                    assert np.array_equal(outs[s], want), (step, s)
+                else:
+                    assert_close(outs[s], want, "many-call step %d state %d" % (step, s))
+                assert states[s].position() == refs[s].position(), (mode, step, s)
+        # NULL input (silence) for some states, and one state twice in a call: its second call sees the first's end state
+        sel = [0, 0, 35, 39]
+        chunks = [orc.lcg_pcm(2000, 5).reshape(1000, 2), None, None, orc.lcg_pcm(800, 6).reshape(100, 8)]
+        capl = [2000, (300, 400), (64, 200), 400]
+        outs, used, codes = speexhip.process_many([states[s] for s in sel], chunks, capl)
+        assert codes == [0, 0, 0, 0]
+        for j, s in enumerate(sel):
+            if chunks[j] is None:
+                want, wu = refs[s].process(None, capl[j][1], null_frames=capl[j][0])
+            else:
+                want, wu = refs[s].process(chunks[j], capl[j])
+            assert used[j] == wu and outs[j].shape == want.shape, (mode, j)
+            if mode == speexhip.MODE_EXACT:
+                assert np.array_equal(outs[j], want), j
+            else:
+                assert_close(outs[j], want, "many-call tail %d" % j)
+        for s in (0, 20, 35, 39):
+            h = states[s].history()
+            for c in range(kinds[s][0]):
+                assert np.array_equal(h[:, c], refs[s].history(c)), (mode, s, c)
+        for st in states:
+            st.close()
+
+
+def test_many_states_in_one_call_equal_the_separate_calls():
+    _many_states_scenario()
+    # the float entry point through the same call
+    kinds = [(2, 44100, 48000, 7)] * 5 + [(1, 48000, 16000, 5)] * 2
+    states = [speexhip.Resampler(*k, mode=speexhip.MODE_EXACT) for k in kinds]
+    refs = [orc.Oracle(*k) for k in kinds]
+    for step, f in enumerate([3000, 160, 90000]):
+        chunks = [(orc.lcg_pcm(f * k[0], 50 * step + s).reshape(f, k[0]).astype(np.float32) / np.float32(32768.0))
+                  for s, k in enumerate(kinds)]
+        caps = [f * k[2] // k[1] + 64 for k in kinds]
+        outs, used, codes = speexhip.process_many(states, chunks, caps, dtype=np.float32)
+        for s in range(len(kinds)):
+            want, wu = refs[s].process_float(chunks[s], caps[s])
+            assert codes[s] == 0 and used[s] == wu and np.array_equal(outs[s], want), (step, s)
+    for st in states:
+        st.close()
+
+
+_PLACEMENT_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "node-speex-resampler_amd", "python"))
+sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import speexhip, oracle as orc
+assert speexhip.device_count() == 2, speexhip.device_count()
+# SPEEXHIP_DEVICES=all: state k of the process on device k mod 2 -- through the library's own rule
+states = [speexhip.Resampler(2, 44100, 48000, 7, mode=speexhip.MODE_EXACT) for _ in range(6)]
+assert [s.info()["device"] for s in states] == [0, 1, 0, 1, 0, 1], [s.info()["device"] for s in states]
+on1 = speexhip.Resampler(2, 44100, 48000, 7, mode=speexhip.MODE_EXACT, device=1)
+assert on1.info()["device"] == 1
+try:
+    speexhip.Resampler(2, 44100, 48000, 7, device=2)
+    raise SystemExit("device 2 of 2 must be refused")
+except RuntimeError as e:
+    assert "device 2 requested" in str(e), str(e)
+b = speexhip.Batch(3, 2, 44100, 48000, 7)         # the 8th state of the process: device 7 mod 2... counted: 6 + 0 (init_on does not count)
+assert b.info()["device"] == 0, b.info()["device"]
+b.close()
+states.append(on1)
+refs = [orc.Oracle(2, 44100, 48000, 7) for _ in states]
+for step, f in enumerate([5000, 160, 400000, 160]):
+    chunks = [orc.lcg_pcm(f * 2, 31 * step + s).reshape(f, 2) for s in range(len(states))]
+    caps = [f * 48000 // 44100 + 64] * len(states)
+    outs, used, codes = speexhip.process_many(states, chunks, caps)    # both devices in one call, side by side
+    for s in range(len(states)):
+        want, wu = refs[s].process(chunks[s], caps[s])
+        assert codes[s] == 0 and used[s] == wu and np.array_equal(outs[s], want), (step, s)
+    # ... and the single-state calls of states on either device, from this one thread
+    for s in (0, 1):
+        x = orc.lcg_pcm(2000, 7 * step + s).reshape(1000, 2)
+        got, used1 = states[s].process(x, 1200)
+        want, wu = refs[s].process(x, 1200)
+        assert used1 == wu and np.array_equal(got, want), (step, s)
+for s in states:
+    s.close()
+print("PLACEMENT OK")
+"""
+
+
+def test_placement_rule_and_many_call_across_two_logical_devices():
+    """SPEEXHIP_ALIAS_DEVICES=2 makes this box's one GPU two LOGICAL devices (pools, table caches, streams and the
+    placement rule key on the logical ordinal): SPEEXHIP_DEVICES=all then spreads the states of a process over them
+    by the library's rule, init_on names one, and one many-states call drives both -- each from a thread of its own --
+    with EXACT bytes.  What an 8-GPU node runs, walked on one."""
+    import sys
+    env = dict(os.environ, SPEEXHIP_ALIAS_DEVICES="2", SPEEXHIP_DEVICES="all")
+    res = subprocess.run([sys.executable, "-c", _PLACEMENT_CHILD, ROOT], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0 and "PLACEMENT OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+    if shutil.which("node") is not None:
+        script = os.path.join(ROOT, "node-speex-resampler_amd", "test", "test.js")
+        res = subprocess.run(["node", "--expose-gc", script], capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0 and "placement: 4 streams on devices" in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def test_fast_float_pieces_never_meet_stale_staging_memory():
+    """a piece of a piecewise owned-block call stored outputs whose zero-padded rows reached past the frames
+    copied so far -- stale pool memory, as float samples possibly NaN / Inf, and 0 * NaN = NaN.  Poison the staging
+    buffer (an int16 call of -1 samples: 0xFFFFFFFF as a float is a NaN), then run FAST float calls in three pieces:
+    every sample finite and within tolerance of the oracle."""
+    import sys
+    child = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "node-speex-resampler_amd", "python"))
+sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import speexhip, oracle as orc
+for (ch, i, o, q) in [(2, 44100, 48000, 7), (1, 24000, 48000, 5), (2, 48000, 11025, 7), (8, 48000, 44100, 5)]:
+    frames = (3 << 20) // ch
+    r = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_FAST)
+    ref = orc.Oracle(ch, i, o, q)
+    poison = np.full((frames * 2 + 4096, ch), -1, np.int16)       # same staging buffer (grow-only), all 0xFFFF
+    r.process_take(poison, poison.shape[0] * o // i + 64)
+    ref.process(poison, poison.shape[0] * o // i + 64)
+    for call in range(2):
+        x = (orc.lcg_pcm(frames * ch, 3 + call).reshape(frames, ch).astype(np.float32) / np.float32(32768.0))
+        cap = frames * o // i + 64
+        got, used = r.process_take(x, cap, float_io=True)
+        want, wu = ref.process_float(x, cap)
+        assert used == wu and got.shape == want.shape, (ch, i, o, q, call)
+        assert np.isfinite(got).all(), "non-finite samples in a piecewise FAST float call %s" % ((ch, i, o, q),)
+        assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 4e-6, (ch, i, o, q, call)
+    r.close()
+print("PIECES OK")
+"""
+    env = dict(os.environ, SPEEXHIP_PIECES="3")
+    res = subprocess.run([sys.executable, "-c", child, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "PIECES OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
