@@ -284,7 +284,7 @@ def parse_args(argv=None):
                     help="independent streams in the WHOLE JOB, stream s on rank s %% N (strong scaling; "
                          "256 = BASELINE configs[4]); overrides --streams")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
-    ap.add_argument("--mode", default="fast", choices=["fast", "exact", "fast_f32"],
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact", "fast_f32", "fast_fixed"],
                     help="fast: +-1 LSB, fp64 accumulator where the reference has one (q9, q10); fast_f32: one fp32 "
                          "FMA chain for every filter (rounds 1-3); exact: the reference's arithmetic order")
     ap.add_argument("--io", default="int16", choices=["int16", "float"],
@@ -386,7 +386,8 @@ def main():
         sys.exit("bench.py: rank %d owns no stream (--total-streams %d over %d ranks)" % (rank, args.total_streams, world))
     streams_total = args.total_streams if strong else args.streams * world
     cap = wrapper_capacity(F * ch * 2, fi, fo, ch)
-    mode = {"exact": speexhip.MODE_EXACT, "fast": speexhip.MODE_FAST, "fast_f32": speexhip.MODE_FAST_F32}[args.mode]
+    mode = {"exact": speexhip.MODE_EXACT, "fast": speexhip.MODE_FAST, "fast_f32": speexhip.MODE_FAST_F32,
+            "fast_fixed": speexhip.MODE_FAST_FIXED}[args.mode]
     batch = speexhip.Batch(S, ch, fi, fo, q, mode=mode)
     info = batch.info()
 

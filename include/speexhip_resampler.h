@@ -44,8 +44,14 @@ enum {
 enum {
   SPEEXHIP_MODE_FAST = 0,      /* +-1 LSB; the filters the reference sums in fp64 (quality 9, 10) in fp64 */
   SPEEXHIP_MODE_EXACT = 1,     /* bit-identical arithmetic order */
-  SPEEXHIP_MODE_FAST_F32 = 2   /* FAST with one fp32 FMA chain for every filter (the fast path of rounds 1-3):
+  SPEEXHIP_MODE_FAST_F32 = 2,  /* FAST with one fp32 FMA chain for every filter (the fast path of rounds 1-3):
                                   narrower than the reference's accumulator at quality 9 and 10, still +-1 LSB */
+  SPEEXHIP_MODE_FAST_FIXED = 3 /* FAST with a pinned summation order (round 5): no tap-range shares, the one launch-time
+                                  choice that re-associates an output's sum.  Like the reference -- and unlike FAST -- the
+                                  bytes of a stream then do not depend on how it is cut into chunks, on how many
+                                  streams share a launch or on the GPU's size; still +-1 LSB.  Costs nothing on
+                                  launches that fill the chip (the BASELINE configs); small launches of long filters
+                                  (one-stream decimators) lose the 1.5-2x the shares bought */
 };
 
 /* Which of the reference's inner kernels the (rates, quality) pair selects
@@ -276,8 +282,8 @@ SPEEXHIP_API int speexhip_resampler_peek(SpeexHipResamplerState *st, uint32_t in
                                          int float_entry, uint32_t *consumed, uint32_t *produced);
 
 /* SPEEXHIP_MODE_FAST (default; +-1 LSB), SPEEXHIP_MODE_EXACT (bit-identical arithmetic order,
- * slower) or SPEEXHIP_MODE_FAST_F32.  The environment variable SPEEXHIP_MODE=exact|fast|fast_f32
- * sets the initial mode. */
+ * slower), SPEEXHIP_MODE_FAST_F32 or SPEEXHIP_MODE_FAST_FIXED.  The environment variable
+ * SPEEXHIP_MODE=exact|fast|fast_f32|fast_fixed sets the initial mode. */
 SPEEXHIP_API int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode);
 
 typedef struct SpeexHipInfo {

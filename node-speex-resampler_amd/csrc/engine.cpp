@@ -37,6 +37,9 @@ class DeviceScope {
     const int device = devices::physical(logical_device);
     if (hipGetDevice(&prev_) != hipSuccess) prev_ = device;
     if (prev_ != device) err_ = hipSetDevice(device);
+    // (a failed call leaves its code behind as the thread's "last error", and the launchers read that after their
+    //  next launch: hipLaunchKernelGGL + hipGetLastError would report THIS failure for a launch that worked)
+    if (err_ != hipSuccess) (void)hipGetLastError();
   }
   ~DeviceScope() {
     if (prev_ != device_now()) (void)hipSetDevice(prev_);
@@ -219,6 +222,7 @@ int Batch::setup() {
     }
   } else if (device_ >= count) {
     g_last_error = "HIP device error: device " + std::to_string(device_) + " requested, the node has " + std::to_string(count);
+    device_ = -1;  // (nothing lives anywhere yet: the destructor has no device to visit)
     return SPEEXHIP_ERR_DEVICE;
   }
   ON_DEVICE();  // (everything below -- pool, tables, uploads -- runs on the state's device)
@@ -231,6 +235,7 @@ int Batch::setup() {
   const char *m = std::getenv("SPEEXHIP_MODE");
   if (m != nullptr && std::strcmp(m, "exact") == 0) mode_ = SPEEXHIP_MODE_EXACT;
   if (m != nullptr && std::strcmp(m, "fast_f32") == 0) mode_ = SPEEXHIP_MODE_FAST_F32;
+  if (m != nullptr && std::strcmp(m, "fast_fixed") == 0) mode_ = SPEEXHIP_MODE_FAST_FIXED;
 
   pos_.assign(static_cast<size_t>(n_streams_) * channels_, StreamPos());
   started_.assign(n_streams_, 0);
@@ -730,6 +735,7 @@ int Batch::reset_mem() {  // resample.c:1208-1220
 }
 
 Batch::~Batch() {
+  if (device_ < 0) return;  // setup() never got as far as a device
   DeviceScope device_scope(device_);
   // everything goes back to the pool (pool.h) for the next state, once nothing in flight uses it:
   // this batch's calls are chained, so the tail of its last stream is all there is to wait for
@@ -757,7 +763,8 @@ CallPlan Batch::peek(uint32_t s, uint32_t in_len, uint32_t out_capacity, bool fl
 }
 
 int Batch::set_mode(int mode) {
-  if (mode != SPEEXHIP_MODE_FAST && mode != SPEEXHIP_MODE_EXACT && mode != SPEEXHIP_MODE_FAST_F32)
+  if (mode != SPEEXHIP_MODE_FAST && mode != SPEEXHIP_MODE_EXACT && mode != SPEEXHIP_MODE_FAST_F32 &&
+      mode != SPEEXHIP_MODE_FAST_FIXED)
     return SPEEXHIP_ERR_INVALID_ARG;
   mode_ = mode;
   return SPEEXHIP_ERR_SUCCESS;
@@ -906,6 +913,7 @@ int Batch::launch_chunk(const StreamDesc *descs, const DescPack &pack, uint32_t 
                         hipStream_t stream) {
   hipError_t e;
   const bool fast = mode_ != SPEEXHIP_MODE_EXACT;
+  const bool fixed = mode_ == SPEEXHIP_MODE_FAST_FIXED;  // (kernels.h: no tap-range shares -- an output's bits depend on the stream alone)
   if (zero_mode_) {
     ExactGeometry geo = exact_geo_;  // (its window geometry belongs to the filter no longer in force)
     geo.staged = false;
@@ -915,9 +923,9 @@ int Batch::launch_chunk(const StreamDesc *descs, const DescPack &pack, uint32_t 
   } else if (fast && acc64() && period64_.usable) {
     // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
     e = launch_period(filter_, period64_, reinterpret_cast<const float *>(d_period64_rows_), &period64_fine_,
-                      reinterpret_cast<const float *>(d_period64_fine_rows_), channels_, descs, &pack, n, float_io, stream);
+                      reinterpret_cast<const float *>(d_period64_fine_rows_), channels_, descs, &pack, n, float_io, stream, fixed);
   } else if (fast && acc64() && !period_.usable && slide64_.usable) {
-    e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, &pack, n, float_io, stream);
+    e = launch_slide64(filter_, slide64_, d_slide64_rows_, channels_, descs, &pack, n, float_io, stream, fixed);
   } else if (fast && period_pp_.usable &&
              period_launch_prefers_pp(filter_, (!float_io && !float_seen_ && period_w16_.usable) ? period_w16_ : period_,
                                       (!float_io && !float_seen_ && period_pp_w16_.usable) ? period_pp_w16_ : period_pp_, descs, n)) {
@@ -925,17 +933,17 @@ int Batch::launch_chunk(const StreamDesc *descs, const DescPack &pack, uint32_t 
     // launch gains
     const bool w16 = !float_io && !float_seen_ && period_pp_w16_.usable;
     e = launch_period(filter_, w16 ? period_pp_w16_ : period_pp_, w16 ? d_period_pp_w16_rows_ : d_period_pp_rows_, nullptr,
-                      nullptr, channels_, descs, &pack, n, float_io, stream);
+                      nullptr, channels_, descs, &pack, n, float_io, stream, fixed);
   } else if (fast && period_.usable && !float_io && !float_seen_ && period_w16_.usable &&
              (w16_always() || period_launch_prefers_w16(filter_, period_, period_fine_.usable, descs, n))) {
     // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- unless
     // the launch is too small for that to pay (period_launch_prefers_w16)
-    e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, &pack, n, false, stream);
+    e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, &pack, n, false, stream, fixed);
   } else if (fast && period_.usable) {
     e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs, &pack, n,
-                      float_io, stream);
+                      float_io, stream, fixed);
   } else if (fast && slide_.usable) {
-    e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, &pack, n, float_io, stream);
+    e = launch_slide(filter_, slide_, d_slide_rows_, channels_, descs, &pack, n, float_io, stream, fixed);
   } else {
     e = launch_exact(filter_, exact_geo_, d_table_, channels_, &pack, n, max_out, float_io, stream);
   }

@@ -203,7 +203,8 @@ class Batch {
   PeriodPlan period64_, period64_fine_;  // the period kernel's plans with an fp64 accumulator (kernels_period64.hip)
   double *d_period64_rows_ = nullptr, *d_period64_fine_rows_ = nullptr;
   bool acc64() const {     // the fast path sums in fp64 (mode FAST on a filter the reference sums in fp64)
-    return mode_ == SPEEXHIP_MODE_FAST && (filter_.kind == kDirectDouble || filter_.kind == kInterpolateDouble);
+    return (mode_ == SPEEXHIP_MODE_FAST || mode_ == SPEEXHIP_MODE_FAST_FIXED) &&
+           (filter_.kind == kDirectDouble || filter_.kind == kInterpolateDouble);
   }
 
   // Calls on one batch are chained: a call on another stream than the previous one waits for it on the device

@@ -97,7 +97,12 @@ void build_period_rows64(const FilterSpec &f, const PeriodPlan &t, std::vector<d
 hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, const PeriodPlan *fine,
                          const float *d_rows_fine, uint32_t channels, const StreamDesc *h_descs,
                          const DescPack *pack, uint32_t n_streams, bool float_io,
-                         hipStream_t stream);
+                         hipStream_t stream, bool fixed_shape = false);
+// fixed_shape (SPEEXHIP_MODE_FAST_FIXED, round 5): no tap-range shares / parts -- the only launch-time choice that
+// changes the ORDER in which an output's products are summed (partial sums of tap ranges meeting in LDS).  Everything
+// else a launch chooses -- phases per wave, int16 or float window, phase pairs, phase-group splits, trimmed head and
+// tail trips, tile size -- adds the same products in the same order (or skips exact zeros), so with this flag an
+// output's bits depend on the stream alone: not on chunking, batch size, launch size or the GPU's CU count.
 
 // Should this int16 launch run over the int16-window plan rather than `t` (the float-window plan, `has_fine`: with
 // an r = 5 companion)?  Launches of few tiles want more and shorter pieces (kernels_period.hip).
@@ -115,7 +120,7 @@ size_t slide_lds_bytes(const SlidePlan &t, uint32_t waves);  // LDS of a workgro
 void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float> *rows);
 hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
                         const StreamDesc *h_descs, const DescPack *pack,
-                        uint32_t n_streams, bool float_io, hipStream_t stream);
+                        uint32_t n_streams, bool float_io, hipStream_t stream, bool fixed_shape = false);
 
 // ---- ... with an fp64 accumulator (kernels_slide64_impl.h, round 4): the reference's "double" kernels (quality 9
 // and 10, resample.c:389-435, :501-558) on the same ratios.  The plan reuses SlidePlan: np = den (accumulators per
@@ -124,6 +129,6 @@ SlidePlan plan_slide64(const FilterSpec &f, uint32_t channels);
 void build_slide64_rows(const FilterSpec &f, const SlidePlan &t, std::vector<double> *rows);
 hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double *d_rows, uint32_t channels,
                           const StreamDesc *h_descs, const DescPack *pack,
-                          uint32_t n_streams, bool float_io, hipStream_t stream);
+                          uint32_t n_streams, bool float_io, hipStream_t stream, bool fixed_shape = false);
 
 }  // namespace speexhip

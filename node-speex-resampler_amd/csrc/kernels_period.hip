@@ -307,7 +307,8 @@ struct PeriodShape {
 };
 hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
                               const StreamDesc *h_descs, const DescPack *pack,
-                              uint32_t n_streams, bool float_io, hipStream_t stream, PeriodShape *probe = nullptr);
+                              uint32_t n_streams, bool float_io, hipStream_t stream, PeriodShape *probe = nullptr,
+                              bool fixed_shape = false);
 }  // namespace
 
 // Which window for an int16 launch of a ratio that has both?  The int16 window's tiles hold twice the periods
@@ -419,20 +420,20 @@ bool debug_period_shape(const FilterSpec &f, const PeriodPlan &t, uint32_t chann
 hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, const PeriodPlan *fine,
                          const float *d_rows_fine, uint32_t channels, const StreamDesc *h_descs,
                          const DescPack *pack, uint32_t n_streams, bool float_io,
-                         hipStream_t stream) {
+                         hipStream_t stream, bool fixed_shape) {
   if (fine != nullptr && fine->usable && d_rows_fine != nullptr) {
     const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
     const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
     if (split_count(t, tiles, n_streams, 2 * device_compute_units()) > 1)
-      return launch_period_plan(f, *fine, d_rows_fine, channels, h_descs, pack, n_streams, float_io, stream);
+      return launch_period_plan(f, *fine, d_rows_fine, channels, h_descs, pack, n_streams, float_io, stream, nullptr, fixed_shape);
   }
-  return launch_period_plan(f, t, d_rows, channels, h_descs, pack, n_streams, float_io, stream);
+  return launch_period_plan(f, t, d_rows, channels, h_descs, pack, n_streams, float_io, stream, nullptr, fixed_shape);
 }
 
 namespace {
 hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
                               const StreamDesc *h_descs, const DescPack *pack,
-                              uint32_t n_streams, bool float_io, hipStream_t stream, PeriodShape *probe) {
+                              uint32_t n_streams, bool float_io, hipStream_t stream, PeriodShape *probe, bool fixed_shape) {
   const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
   const uint32_t resident = 2 * device_compute_units();  // two workgroups fit per CU
@@ -598,7 +599,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // (R = 10 only: the R = 5 instances with shares take 76 VGPRs -- one 16-wave workgroup per CU where two of 8 waves
   //  ran: stereo 44.1k->8k in phase pairs 52.5 -> 57 us)
   const bool unsplit_ks = splits == 1 && t.r == 10 && !unsplit_ks_off;
-  if ((splits > 1 || unsplit_ks || env_ksplit > 0) && env_ksplit != 0 && isa_layout && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
+  if (!fixed_shape && (splits > 1 || unsplit_ks || env_ksplit > 0) && env_ksplit != 0 && isa_layout && wave_groups * splits >= t.groups && wave_groups * 2 <= max_waves) {
     uint32_t parts = env_ksplit > 0 ? static_cast<uint32_t>(env_ksplit) : max_waves / wave_groups;
     parts = std::min<uint32_t>(parts, max_waves / wave_groups);
     const uint32_t trips = t.l4;  // trips per group row

@@ -118,7 +118,7 @@ void build_slide_rows(const FilterSpec &f, const SlidePlan &t, std::vector<float
 
 hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_rows, uint32_t channels,
                         const StreamDesc *h_descs, const DescPack *pack,
-                        uint32_t n_streams, bool float_io, hipStream_t stream) {
+                        uint32_t n_streams, bool float_io, hipStream_t stream, bool fixed_shape) {
   uint32_t max_periods = 0;
   for (uint32_t s = 0; s < n_streams; s++) {
     if (h_descs[s].n_out == 0) continue;
@@ -169,7 +169,7 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
     if (env_parts > 0) parts = std::min<uint32_t>(parts, static_cast<uint32_t>(env_parts));
     while (parts > 1 && (pairs / parts < 2 || static_cast<size_t>(parts - 1) * waves * t.p * t.np * 64 * 8 > kSlideLdsLimit)) parts--;
     const bool small = static_cast<uint64_t>(tiles) * n_streams * waves <= 4ull * device_compute_units();  // at most one wave per SIMD
-    if (env_parts != 0 && parts > 1 && (env_parts > 0 || (small && chain >= 1500))) {
+    if (!fixed_shape && env_parts != 0 && parts > 1 && (env_parts > 0 || (small && chain >= 1500))) {
       p.parts = parts;
       lds = std::max(lds, static_cast<size_t>(parts - 1) * waves * t.p * t.np * 64 * 8);
     }
@@ -254,7 +254,7 @@ void build_slide64_rows(const FilterSpec &f, const SlidePlan &t, std::vector<dou
 
 hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double *d_rows, uint32_t channels,
                           const StreamDesc *h_descs, const DescPack *pack,
-                          uint32_t n_streams, bool float_io, hipStream_t stream) {
+                          uint32_t n_streams, bool float_io, hipStream_t stream, bool fixed_shape) {
   uint32_t max_periods = 0;
   for (uint32_t s = 0; s < n_streams; s++) {
     if (h_descs[s].n_out == 0) continue;
@@ -296,7 +296,7 @@ hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double 
     if (env_parts > 0) parts = std::min<uint32_t>(parts, static_cast<uint32_t>(env_parts));
     while (parts > 1 && (pairs / parts < 2 || static_cast<size_t>(parts - 1) * waves * t.p * f.den * 64 * 8 > kSlideLdsLimit)) parts--;
     const bool small = static_cast<uint64_t>(tiles) * n_streams * waves <= 4ull * device_compute_units();
-    if (env_parts != 0 && parts > 1 && (env_parts > 0 || (small && chain >= 1500))) {
+    if (!fixed_shape && env_parts != 0 && parts > 1 && (env_parts > 0 || (small && chain >= 1500))) {
       p.parts = parts;
       lds = std::max(lds, static_cast<size_t>(parts - 1) * waves * t.p * f.den * 64 * 8);
     }

@@ -76,44 +76,32 @@ void *take(Shelf &sh, size_t cls) {
 
 }  // namespace
 
-// ---- the slab of caller-owned result blocks (pool.h) -- first fit over a sorted free list, 4 KiB granules ----
+// ---- the slabs of caller-owned result blocks (pool.h) -- first fit over a sorted free list, 4 KiB granules ----
+// One slab of SPEEXHIP_TAKE_MB (64 MiB) is made by the first request, further ones when every slab is full, up to
+// SPEEXHIP_TAKE_MAX_MB (256 MiB) in all.  Why more than one (round 5, profiles/r05_steady.txt): the N-API addon's
+// external Buffers give their blocks back from a finalizer, and V8 runs finalizers from the event loop, a while after
+// the collection that found the Buffer dead.  A caller producing 3.5 MB results held 18 of them when the first
+// collection came (V8 starts collecting external memory at ~64 MB), the single slab was full, and every call until the
+// finalizers had run took the copying path at 0.30-0.55 ms instead of 0.14.  With room beyond V8's own threshold the
+// collector gets there first.
 namespace {
 struct Slab {
-  std::mutex mu;
   char *base = nullptr;
   size_t bytes = 0;
-  bool tried = false;
   std::map<size_t, size_t> free_at;    // offset -> length
   std::map<size_t, size_t> taken;      // offset -> length
 };
-Slab &slab() {
-  static Slab *s = new Slab();  // never destroyed, like the pool
+struct Slabs {
+  std::mutex mu;
+  std::vector<Slab> all;
+  size_t slab_bytes = 0, max_bytes = 0, total = 0;
+  bool configured = false;
+};
+Slabs &slabs() {
+  static Slabs *s = new Slabs();  // never destroyed, like the pool
   return *s;
 }
-}  // namespace
-
-bool block_get(void **ptr, size_t bytes) {
-  *ptr = nullptr;
-  Slab &sl = slab();
-  std::lock_guard<std::mutex> lock(sl.mu);
-  if (!sl.tried) {
-    sl.tried = true;
-    size_t mb = 64;
-    if (const char *e = std::getenv("SPEEXHIP_TAKE_MB")) mb = static_cast<size_t>(std::strtoull(e, nullptr, 10));
-    if (mb != 0) {
-      MissTimer timer("hipHostMalloc (slab of result blocks)", mb << 20);
-      void *p = nullptr;
-      if (hipHostMalloc(&p, mb << 20, hipHostMallocDefault) == hipSuccess) {
-        sl.base = static_cast<char *>(p);
-        sl.bytes = mb << 20;
-        sl.free_at[0] = sl.bytes;
-      } else {
-        (void)hipGetLastError();
-      }
-    }
-  }
-  if (sl.base == nullptr) return false;
-  const size_t want = (std::max<size_t>(bytes, 1) + 4095) & ~static_cast<size_t>(4095);
+bool carve(Slab &sl, size_t want, void **ptr) {
   for (auto it = sl.free_at.begin(); it != sl.free_at.end(); ++it) {
     if (it->second < want) continue;
     const size_t off = it->first, len = it->second;
@@ -125,31 +113,71 @@ bool block_get(void **ptr, size_t bytes) {
   }
   return false;
 }
+}  // namespace
 
-bool block_put(void *ptr) {
-  Slab &sl = slab();
-  std::lock_guard<std::mutex> lock(sl.mu);
-  if (sl.base == nullptr || ptr < static_cast<void *>(sl.base) || ptr >= static_cast<void *>(sl.base + sl.bytes)) return false;
-  const size_t off = static_cast<size_t>(static_cast<char *>(ptr) - sl.base);
-  auto it = sl.taken.find(off);
-  if (it == sl.taken.end()) return false;
-  size_t start = off, len = it->second;
-  sl.taken.erase(it);
-  auto next = sl.free_at.lower_bound(start);
-  if (next != sl.free_at.end() && next->first == start + len) {  // merge with the free range behind
-    len += next->second;
-    next = sl.free_at.erase(next);
+bool block_get(void **ptr, size_t bytes) {
+  *ptr = nullptr;
+  Slabs &ss = slabs();
+  std::lock_guard<std::mutex> lock(ss.mu);
+  if (!ss.configured) {
+    ss.configured = true;
+    size_t mb = 64, max_mb = 256;
+    if (const char *e = std::getenv("SPEEXHIP_TAKE_MB")) mb = static_cast<size_t>(std::strtoull(e, nullptr, 10));
+    if (const char *e = std::getenv("SPEEXHIP_TAKE_MAX_MB")) max_mb = static_cast<size_t>(std::strtoull(e, nullptr, 10));
+    ss.slab_bytes = mb << 20;
+    ss.max_bytes = std::max(max_mb, mb) << 20;
   }
-  if (next != sl.free_at.begin()) {  // ... and with the one in front
-    auto prev = std::prev(next);
-    if (prev->first + prev->second == start) {
-      start = prev->first;
-      len += prev->second;
-      sl.free_at.erase(prev);
+  if (ss.slab_bytes == 0) return false;
+  const size_t want = (std::max<size_t>(bytes, 1) + 4095) & ~static_cast<size_t>(4095);
+  for (Slab &sl : ss.all)
+    if (carve(sl, want, ptr)) return true;
+  // every slab is full (or there is none yet): one more, while the total stays under the cap
+  const size_t size = std::max(ss.slab_bytes, want);
+  if (ss.total + size > ss.max_bytes && !(ss.all.empty() && size <= ss.max_bytes)) return false;
+  void *p = nullptr;
+  {
+    MissTimer timer("hipHostMalloc (slab of result blocks)", size);
+    if (hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
     }
   }
-  sl.free_at[start] = len;
-  return true;
+  Slab sl;
+  sl.base = static_cast<char *>(p);
+  sl.bytes = size;
+  sl.free_at[0] = size;
+  ss.all.push_back(std::move(sl));
+  ss.total += size;
+  return carve(ss.all.back(), want, ptr);
+}
+
+bool block_put(void *ptr) {
+  Slabs &ss = slabs();
+  std::lock_guard<std::mutex> lock(ss.mu);
+  for (Slab &sl : ss.all) {
+    if (ptr < static_cast<void *>(sl.base) || ptr >= static_cast<void *>(sl.base + sl.bytes)) continue;
+    const size_t off = static_cast<size_t>(static_cast<char *>(ptr) - sl.base);
+    auto it = sl.taken.find(off);
+    if (it == sl.taken.end()) return false;
+    size_t start = off, len = it->second;
+    sl.taken.erase(it);
+    auto next = sl.free_at.lower_bound(start);
+    if (next != sl.free_at.end() && next->first == start + len) {  // merge with the free range behind
+      len += next->second;
+      next = sl.free_at.erase(next);
+    }
+    if (next != sl.free_at.begin()) {  // ... and with the one in front
+      auto prev = std::prev(next);
+      if (prev->first + prev->second == start) {
+        start = prev->first;
+        len += prev->second;
+        sl.free_at.erase(prev);
+      }
+    }
+    sl.free_at[start] = len;
+    return true;
+  }
+  return false;
 }
 
 size_t size_class(size_t bytes) {
@@ -332,16 +360,18 @@ size_t release_idle() {
       v.second.clear();
     }
   }
-  {  // the slab of result blocks, when nobody holds one (the next ..._take call makes it again)
-    Slab &sl = slab();
-    std::lock_guard<std::mutex> lock(sl.mu);
-    if (sl.base != nullptr && sl.taken.empty()) {
-      pin.push_back(sl.base);
-      bytes += sl.bytes;
-      sl.base = nullptr;
-      sl.bytes = 0;
-      sl.free_at.clear();
-      sl.tried = false;
+  {  // the slabs of result blocks nobody holds a block of (the next ..._take call makes one again)
+    Slabs &ss = slabs();
+    std::lock_guard<std::mutex> lock(ss.mu);
+    for (auto it = ss.all.begin(); it != ss.all.end();) {
+      if (it->taken.empty()) {
+        pin.push_back(it->base);
+        bytes += it->bytes;
+        ss.total -= it->bytes;
+        it = ss.all.erase(it);
+      } else {
+        ++it;
+      }
     }
   }
   for (void *p : dev) (void)hipFree(p);

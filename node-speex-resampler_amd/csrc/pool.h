@@ -38,10 +38,12 @@ hipError_t event_get(int device, hipEvent_t *e);
 void event_put(int device, hipEvent_t e);
 
 // Result blocks that a caller OWNS after a host-buffer call (Batch::process_host_take; the N-API addon's external
-// Buffers): carved out of one pinned slab (SPEEXHIP_TAKE_MB, default 64 MiB, 0 = none) made by the first request,
-// so that no call ever pays hipHostMalloc for its result -- a caller that keeps its blocks (JavaScript Buffers wait
-// for the garbage collector) exhausts the slab instead of growing pinned memory, and block_get says so: false =
-// nothing free right now (the caller falls back to the copying call).  block_put: false = not one of these blocks.
+// Buffers): carved out of pinned slabs of SPEEXHIP_TAKE_MB (default 64 MiB, 0 = none) -- the first made by the first
+// request, another whenever all are full, up to SPEEXHIP_TAKE_MAX_MB (256 MiB) in all -- so that a call pays
+// hipHostMalloc for its result at most four times in the life of a process.  A caller that keeps its blocks
+// (JavaScript Buffers wait for the garbage collector AND for the event loop to run their finalizers) exhausts the
+// slabs instead of growing pinned memory without bound, and block_get says so: false = nothing free right now (the
+// caller falls back to the copying call).  block_put: false = not one of these blocks.
 bool block_get(void **ptr, size_t bytes);
 bool block_put(void *ptr);
 

@@ -81,8 +81,11 @@ declare class SpeexResampler {
     /** mid-stream control (speex_resampler_set_rate / set_quality / skip_zeros / reset_mem) */
     setRate(inRate: number, outRate: number): void;
     setQuality(quality: number): void;
-    /** 'fast' (default, +-1 LSB, fp64 sums at quality 9 / 10), 'exact' (bit-identical to the reference) or 'fast_f32' */
-    setMode(mode: 'fast' | 'exact' | 'fast_f32'): void;
+    /**
+     * 'fast' (default, +-1 LSB, fp64 sums at quality 9 / 10), 'exact' (bit-identical to the reference), 'fast_f32', or
+     * 'fast_fixed': 'fast' whose bytes do not depend on chunking, batch size or GPU (pinned summation order)
+     */
+    setMode(mode: 'fast' | 'exact' | 'fast_f32' | 'fast_fixed'): void;
     skipZeros(): void;
     resetMem(): void;
     /** filter delay in frames at the input rate / at the output rate */

@@ -190,13 +190,15 @@ class SpeexResampler {
   /**
    * Arithmetic of this instance's kernels: 'fast' (default; every sample within +-1 LSB of the reference, fp64 sums
    * where the reference has them: quality 9 and 10), 'exact' (bit-identical to the reference, slower), 'fast_f32'
-   * (one fp32 FMA chain for every filter: the fast path of the first releases).  The environment variable
-   * SPEEXHIP_MODE sets the initial mode of every instance.
+   * (one fp32 FMA chain for every filter: the fast path of the first releases), 'fast_fixed' ('fast' with a pinned
+   * summation order: like the reference's, a stream's bytes then do not depend on how it is cut into chunks, on how
+   * many streams share a launch or on the GPU).  The environment variable SPEEXHIP_MODE sets the initial mode of every
+   * instance.
    */
   setMode(mode) {
     this._refuseWhileAsyncPending('setMode');
-    const code = { fast: 0, exact: 1, fast_f32: 2 }[mode];
-    if (code === undefined) throw new Error("mode must be 'fast', 'exact' or 'fast_f32'");
+    const code = { fast: 0, exact: 1, fast_f32: 2, fast_fixed: 3 }[mode];
+    if (code === undefined) throw new Error("mode must be 'fast', 'exact', 'fast_f32' or 'fast_fixed'");
     speexModule.setMode(this._ensureNative(), code);
   }
 

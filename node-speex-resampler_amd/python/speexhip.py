@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (SPEEXHIP_LIB_PATH: same-box A/B of two builds of the library, tools/gpu_ab.sh; never set in tests)
 LIB_PATH = os.environ.get("SPEEXHIP_LIB_PATH") or os.path.join(PKG_DIR, "libspeexhip.so")
 
-MODE_FAST, MODE_EXACT, MODE_FAST_F32 = 0, 1, 2
+MODE_FAST, MODE_EXACT, MODE_FAST_F32, MODE_FAST_FIXED = 0, 1, 2, 3
 KERNEL_NAMES = ("direct_single", "direct_double", "interpolate_single", "interpolate_double")
 # reference codes (deps/speex/speex_resampler.h:104-113) + 6 = HIP failure
 ERR_SUCCESS, ERR_ALLOC_FAILED, ERR_BAD_STATE, ERR_INVALID_ARG, ERR_PTR_OVERLAP, ERR_OVERFLOW = 0, 1, 2, 3, 4, 5

@@ -302,7 +302,7 @@ function poolTest() {
 function modeTest() {
   const pcm = lcg(60000, 1, 31);
   const outs = {};
-  for (const mode of ['exact', 'fast', 'fast_f32']) {
+  for (const mode of ['exact', 'fast', 'fast_f32', 'fast_fixed']) {
     const r = new SpeexResampler(1, 24000, 48000, 10);
     r.setMode(mode);
     outs[mode] = r.processChunk(pcm);
@@ -312,7 +312,7 @@ function modeTest() {
   try { new SpeexResampler(1, 24000, 48000, 10).setMode('fastest'); } catch (e) { bad = /mode must be/.test(e.message); }
   assert(bad, 'setMode must refuse unknown modes');
   const off = {};
-  for (const mode of ['fast', 'fast_f32']) {
+  for (const mode of ['fast', 'fast_f32', 'fast_fixed']) {
     assert(outs[mode].length === outs.exact.length, 'modes must agree on the counters');
     let n = 0;
     for (let i = 0; i < outs.exact.length; i += 2) {
@@ -323,7 +323,18 @@ function modeTest() {
     off[mode] = n;
   }
   assert(off.fast <= off.fast_f32, 'fp64 accumulate must not be further from the reference than the fp32 chain');
-  console.log(`modes: fast ${off.fast} / fast_f32 ${off.fast_f32} of ${outs.exact.length / 2} samples off by one`);
+  // 'fast_fixed': the bytes of a stream do not depend on how it is cut into chunks (the reference's property)
+  {
+    const whole = new SpeexResampler(2, 48000, 11025, 7), cut = new SpeexResampler(2, 48000, 11025, 7);
+    whole.setMode('fast_fixed'); cut.setMode('fast_fixed');
+    const x = lcg(200000, 2, 77);
+    const one = whole.processChunk(x);
+    const parts = [];
+    for (const [a, b] of [[0, 4800], [4800, 4900], [4900, 150000], [150000, 200000]]) parts.push(cut.processChunk(x.slice(a * 4, b * 4)));
+    assert(Buffer.concat(parts).equals(one), "'fast_fixed': four chunks differ from one");
+    whole.destroy(); cut.destroy();
+  }
+  console.log(`modes: fast ${off.fast} / fast_f32 ${off.fast_f32} / fast_fixed ${off.fast_fixed} of ${outs.exact.length / 2} samples off by one`);
 }
 
 function externalBufferTest() {

@@ -1958,3 +1958,52 @@ print("PIECES OK")
     env = dict(os.environ, SPEEXHIP_PIECES="3")
     res = subprocess.run([sys.executable, "-c", child, ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "PIECES OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("ch,i,o,q", [(2, 44100, 48000, 7), (1, 48000, 11025, 5), (2, 48000, 8000, 8), (1, 24000, 48000, 10),
+                                      (2, 48000, 11025, 7), (3, 44100, 16000, 6), (8, 48000, 44100, 5), (2, 44100, 48000, 10),
+                                      (1, 44100, 8000, 10), (2, 16000, 48000, 4), (6, 44100, 8000, 3)])
+def test_fast_fixed_mode_bytes_do_not_depend_on_chunking_or_batch_size(ch, i, o, q):
+    """SPEEXHIP_MODE_FAST_FIXED (round 5): FAST without tap-range shares, the one launch-time choice that re-associates
+    an output's sum.  Like the reference's (64 KiB chunks == one chunk, sha1 27003384...), a stream's bytes
+    then depend on the stream alone: one call == six ragged calls == the same stream inside a many-states call of 7 or
+    33 states (other launch shapes: tiles, splits, window format, phases per wave) -- byte for byte, and every one of
+    them within +-1 LSB of the oracle.  Ratios whose default-mode launches DO take shares, phase pairs, the int16
+    window or the r = 5 plan by size are among the cases."""
+    frames = 300000
+    x = orc.lcg_pcm(frames * ch, 5).reshape(frames, ch)
+    cap = int(frames * o / i) + 64
+    whole = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_FAST_FIXED)
+    a, ua = whole.process(x, cap)
+    whole.close()
+    want, _ = orc.Oracle(ch, i, o, q).process(x, cap)
+    assert ua == frames
+    assert_close(a, want, "fast_fixed, one call")
+    sizes = (480, 100000, 7, 20000, 150000, frames)
+    pieces = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_FAST_FIXED)
+    out, used = [], 0
+    for n in sizes:
+        n = min(n, frames - used)
+        if n == 0:
+            break
+        g, u = pieces.process(x[used:used + n], cap)
+        assert u == n
+        out.append(g)
+        used += n
+    pieces.close()
+    assert np.array_equal(np.concatenate(out), a), "fast_fixed: six calls differ from one call"
+    for others in (6, 32):   # the same stream as state 3 of a many-states call (other states: other audio)
+        states = [speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_FAST_FIXED) for _ in range(others + 1)]
+        out, used = [], 0
+        for n in sizes:
+            n = min(n, frames - used)
+            if n == 0:
+                break
+            chunks = [x[used:used + n] if s == 3 else orc.lcg_pcm(n * ch, 100 + s).reshape(n, ch) for s in range(others + 1)]
+            outs, us, codes = speexhip.process_many(states, chunks, [cap] * (others + 1))
+            assert us[3] == n and codes[3] == 0
+            out.append(outs[3])
+            used += n
+        for st in states:
+            st.close()
+        assert np.array_equal(np.concatenate(out), a), "fast_fixed: bytes depend on the batch size (%d)" % (others + 1)
