@@ -269,6 +269,51 @@ def cpu_baseline(cfg, frames, budget_s=12.0, max_chunks=32):
                 chunks, frames, ch, dt)}
 
 
+def cpu_baseline_workers(cfg, frames, total_streams, budget_s=10.0):
+    """SURVEY 8(d), configs[4]'s CPU column: the reference is one scalar thread per stream, so T streams on a host
+    with C cores run min(C, T) at a time.  Starts that many fresh CHILD processes (this process has not touched a GPU
+    yet), each timing the CPU path on its own stream for ~budget_s; value = samples all of them processed / the
+    slowest one's time."""
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, total_streams))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                               "%d,%d,%d,%d,%d,%d,%f" % (cfg + (frames, 12345 + w, budget_s))],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for w in range(workers)]
+    rows = []
+    for p_ in procs:
+        out, _ = p_.communicate()
+        if p_.returncode == 0 and out.strip():
+            rows.append(json.loads(out.decode().strip().splitlines()[-1]))
+    if len(rows) != workers:
+        return {"error": "%d of %d CPU workers failed" % (workers - len(rows), workers)}
+    ch = cfg[0]
+    total = sum(r["chunks"] for r in rows) * frames * ch
+    slowest = max(r["seconds"] for r in rows)
+    return {"value": round(total / slowest / 1e6, 3), "unit": "Msamples/s", "cores": cores, "workers": workers,
+            "kind": rows[0]["kind"],
+            "per_worker_msamples_per_s": round(sum(r["chunks"] * frames * ch / r["seconds"] for r in rows) / workers / 1e6, 3),
+            "sample": "%d worker processes (min(%d host cores, %d streams)), one stream each, %d chunks of %d frames x %d ch "
+                      "in all, %.1f s (slowest worker)" % (workers, cores, total_streams, sum(r["chunks"] for r in rows),
+                                                           frames, ch, slowest)}
+
+
+def cpu_worker(spec):
+    """child of cpu_baseline_workers: `ch,in,out,q,frames,seed,budget` -> one JSON line"""
+    v = spec.split(",")
+    cfg, frames, seed, budget = tuple(int(x) for x in v[:4]), int(v[4]), int(v[5]), float(v[6])
+    eng, kind = _oracle_engine(cfg)
+    ch, fi, fo, q = cfg
+    x = lcg_pcm(frames * ch, seed).reshape(frames, ch)
+    cap = wrapper_capacity(x.size * 2, fi, fo, ch)
+    eng.process(x, cap)
+    t0 = time.perf_counter()
+    chunks = 0
+    while chunks < 64 and (time.perf_counter() - t0) < budget:
+        eng.process(x, cap)
+        chunks += 1
+    print(json.dumps({"chunks": chunks, "seconds": time.perf_counter() - t0, "kind": kind}), flush=True)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,6 +339,7 @@ def parse_args(argv=None):
                          "clocks only after some milliseconds of load (measured: the first ~30 ms of a "
                          "launch train run 20-30 %% slower), and W steps of a 15 us kernel are over before that")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)  # (child of cpu_baseline_workers)
     ap.add_argument("--no-parity", action="store_true")
     return ap.parse_args(argv)
 
@@ -345,8 +391,17 @@ def main():
     args = parse_args()
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
+    # configs[4]'s CPU column (strong-scaling line at N = 1): min(cores, T) worker processes, started -- and finished --
+    # before anything in this process touches a GPU
+    cpu_many = None
+    if args.gpus == 1 and args.total_streams > 0 and not args.no_cpu_baseline and "WORLD_SIZE" not in os.environ:
+        cfg0 = tuple(int(v) for v in args.custom.split(",")) if args.custom else CONFIGS[args.config]
+        cpu_many = cpu_baseline_workers(cfg0, args.frames, args.total_streams)
 
     import numpy as np
     import torch
@@ -555,6 +610,10 @@ def main():
             if not fio:
                 line["end_to_end_streams"] = end_to_end_streams(speexhip, cfg, F, mode)
             line["cpu_baseline"] = cpu_baseline(cfg, F)
+            if cpu_many is not None:
+                # the strong-scaling line: T streams against min(cores, T) CPU workers; the 1-core figure stays beside it
+                one = line["cpu_baseline"]
+                line["cpu_baseline"] = dict(cpu_many, one_core=one)
         print(json.dumps(line), flush=True)
         if rc:
             sys.stderr.write("bench.py: PARITY FAILED: %s\n" % json.dumps(line["parity"]))

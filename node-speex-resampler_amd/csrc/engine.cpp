@@ -1473,8 +1473,15 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
     if (frames > 0x7fffffffull || made > 0x7fffffffull) return SPEEXHIP_ERR_OVERFLOW;
   }
   const bool direct_out = made * fb >= kDirectCopyBytes;
+  // Small runs -- what a Transform holds back, eight 64 KiB chunks say -- are all latency, like small single calls
+  // (process_host): the kernels read the pinned bounce buffer and write the pinned result buffer straight through
+  // PCIe, one wait, no copy-engine hand-overs.  (Until round 5 every coalesced run went through the device staging
+  // buffers: H2D copy, launch, D2H copy -- three in-order steps of ~10 us hand-over each -- and `coalesceChunks: 8` was
+  // SLOWER than the plain pipe on four of the reference's seven test tuples, profiles/r04_node_bench.json.)
+  const bool zero_copy = frames * fb < kZeroCopyBelow && made * fb < kZeroCopyBelow;
   DrainOnExit drain(&own_stream_);
-  int rc = ensure_stage(frames * fb, made * fb, frames * fb, direct_out ? 0 : made * fb);
+  int rc = zero_copy ? ensure_stage(0, 0, frames * fb, made * fb + 64)
+                     : ensure_stage(frames * fb, made * fb, frames * fb, direct_out ? 0 : made * fb);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   size_t off = 0;
   for (uint32_t i = 0; i < n_chunks; i++) {  // frames a call drops never reach the GPU
@@ -1485,17 +1492,17 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
       std::memset(h_pin_in_ + off, 0, bytes);
     off += bytes;
   }
-  if (off != 0) HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, off, hipMemcpyHostToDevice, own_stream_));
+  if (off != 0 && !zero_copy) HIP_TRY(hipMemcpyAsync(d_stage_in_, h_pin_in_, off, hipMemcpyHostToDevice, own_stream_));
+  char *src = zero_copy ? h_pin_in_ : d_stage_in_, *dst = zero_copy ? h_pin_out_ : d_stage_out_;
   for (const Group &g : groups) {
-    rc = run_plans(d_stage_in_ + g.in_off * fb, 0, &g.readable, d_stage_out_ + g.out_off * fb, 0, &g.fused,
-                   float_io, own_stream_);
+    rc = run_plans(src + g.in_off * fb, 0, &g.readable, dst + g.out_off * fb, 0, &g.fused, float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
-  if (made != 0)
+  if (made != 0 && !zero_copy)
     HIP_TRY(hipMemcpyAsync(direct_out ? out : h_pin_out_, d_stage_out_, made * fb, hipMemcpyDeviceToHost, own_stream_));
   HIP_TRY(hipStreamSynchronize(own_stream_));
   drain.armed = false;
-  if (made != 0 && !direct_out) std::memcpy(out, h_pin_out_, made * fb);
+  if (made != 0 && (zero_copy || !direct_out)) std::memcpy(out, h_pin_out_, made * fb);
   for (uint32_t i = 0; i < n_chunks; i++) {
     in_len[i] = plans[i].consumed;
     out_len[i] = plans[i].produced;

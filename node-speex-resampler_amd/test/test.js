@@ -328,9 +328,15 @@ function modeTest() {
     const whole = new SpeexResampler(2, 48000, 11025, 7), cut = new SpeexResampler(2, 48000, 11025, 7);
     whole.setMode('fast_fixed'); cut.setMode('fast_fixed');
     const x = lcg(200000, 2, 77);
-    const one = whole.processChunk(x);
+    const addon = require('../speex_hip_napi.node');
+    // (through the addon with room to spare: processChunk's capacity rule DROPS input when chunk sizes vary -- F5 --
+    //  and four chunks would then not be the stream of the one)
+    const one = addon.process(whole._resamplerPtr, x, 200000, 60000);
     const parts = [];
-    for (const [a, b] of [[0, 4800], [4800, 4900], [4900, 150000], [150000, 200000]]) parts.push(cut.processChunk(x.slice(a * 4, b * 4)));
+    for (const [a, b] of [[0, 4800], [4800, 4900], [4900, 150000], [150000, 200000]]) {
+      parts.push(addon.process(cut._resamplerPtr, x.slice(a * 4, b * 4), b - a, 60000));
+    }
+    assert(Buffer.concat(parts).length === one.length, "'fast_fixed': four chunks, another length");
     assert(Buffer.concat(parts).equals(one), "'fast_fixed': four chunks differ from one");
     whole.destroy(); cut.destroy();
   }

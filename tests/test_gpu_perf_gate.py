@@ -4,7 +4,9 @@ re-measured (50 launches through HIP events on the launch stream, best of 3 repe
 must stay under its ceiling: 10 % above the slowest time any box has measured for it (tools/perf_floor.py --measure
 --merge, run on several leases; the pool's boxes differ by 4-6 %).  It guards the fitted planners (launch_period_plan,
 period_launch_prefers_w16, launch_slide's rules): the forced-variant parity tests keep them correct, this keeps
-them fast.  SPEEXHIP_PERF_GATE=0 skips it (a box known to be throttled)."""
+them fast.  A box that holds a lower clock under load than every box the floor was measured on (the file records
+each lease's speexhip_debug_device_clock) gets its ceilings raised by that ratio: the gate is about the code, not the
+lease.  SPEEXHIP_PERF_GATE=0 skips it (a box known to be throttled)."""
 import importlib.util
 import json
 import os
@@ -30,15 +32,18 @@ def test_no_workload_is_slower_than_its_ceiling():
     floor = json.load(open(tool.FLOOR))
     ghz, ghz_min = speexhip.device_clock()
     known = {w[0]: w for w in tool.WORKLOADS}
+    slowest_box = min((b["ghz"] for b in floor.get("boxes", []) if b.get("ghz")), default=ghz)
+    slack = max(1.0, slowest_box / ghz) if ghz > 0 else 1.0   # this box is slower than any the floor has seen
     late, report = [], []
     for name, row in sorted(floor["workloads"].items()):
         assert name in known and list(known[name][1]) == row["config"], "perf_floor.json and tools/perf_floor.py disagree on %s" % name
         us, path = tool.measure(known[name])
-        if us > row["ceiling_us"]:  # once more before it counts: a neighbour's burst, a clock dip
+        ceiling = row["ceiling_us"] * slack
+        if us > ceiling:  # once more before it counts: a neighbour's burst, a clock dip
             us = min(us, tool.measure(known[name], reps=5)[0])
-        report.append("%-22s %9.2f us  ceiling %9.2f  (slowest seen %9.2f)  path %d" % (name, us, row["ceiling_us"], row["slowest_us"], path))
+        report.append("%-22s %9.2f us  ceiling %9.2f  (slowest seen %9.2f)  path %d" % (name, us, ceiling, row["slowest_us"], path))
         assert path == row["fast_path"], "%s runs fast_path %d, the floor was measured on %d" % (name, path, row["fast_path"])
-        if us > row["ceiling_us"]:
+        if us > ceiling:
             late.append(report[-1])
-    print("box: %.3f GHz under load (slowest workgroup %.3f)\n" % (ghz, ghz_min) + "\n".join(report))
+    print("box: %.3f GHz under load (slowest workgroup %.3f), ceilings x %.3f\n" % (ghz, ghz_min, slack) + "\n".join(report))
     assert not late, "slower than the ceiling of profiles/perf_floor.json (box at %.3f GHz):\n%s" % (ghz, "\n".join(late))
