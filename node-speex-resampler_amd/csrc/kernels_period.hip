@@ -101,6 +101,9 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // the same bank (ds_read_b32) / bank pair (ds_read_b64); 1 = conflict-free.  (Measured on
   // stereo 48k->44.1k, 32 streams: no pad 622 us, pad 4 -- two lanes per bank pair -- 188 us, pad 2
   // -- conflict-free, but 8-byte staging writes -- 199 us, pad 8: 288, pad 16: 411.)
+  // (padded float windows of four channel pairs on the fp32 chain run the ROW mapping of lane_ctx: channel pair =
+  //  lane / 16, period = lane % 16 -- kernels_period_impl.h; the unpadded instance keeps lane % 4)
+  const bool rows = t.ct == 2 && t.cgroups == 4 && !w16 && !a64 && !t.pp && t.r == 10;
   auto worst_bank_load = [&](uint32_t pad) {
     // float image: a lane reads `ct` floats (ds_read_b32 / _b64); int16 image: the dword its one or two
     // samples sit in (ds_read_i16 / _b32, 32 banks)
@@ -109,7 +112,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
     const uint32_t stride = f.num * channels + pad;
     uint32_t count[64] = {0}, worst = 0;
     for (uint32_t lane = 0; lane < 32; lane++) {
-      const uint32_t cg = lane % t.cgroups, pl = lane / t.cgroups;
+      const uint32_t cg = (rows && pad != 0) ? lane >> 4 : lane % t.cgroups, pl = (rows && pad != 0) ? (lane & 15u) : lane / t.cgroups;
       const uint32_t slot = ((pl * stride + cg * t.ct) / unit) % slots;
       worst = std::max(worst, ++count[slot]);
     }

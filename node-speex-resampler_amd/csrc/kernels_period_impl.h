@@ -119,7 +119,14 @@ struct LaneCtx {
   uint64_t K_lane;  // canonical output index of the lane's period, phase 0
 };
 
-template <int CT, bool ONE_GROUP, bool PADDED, int CGF = 0, bool PP = false>
+// ROWS (round 5; padded 8-channel frames on the fp32 chain: BASELINE configs[3]): the channel pair of a lane is its ROW
+// of 16 lanes (cg = lane / 16, period = lane % 16) instead of lane % 4.  Two things follow.  The four lanes of a frame
+// sit in the four rows of one column, where v_permlane32_swap / v_permlane16_swap exchange them: a 4 x 4 transpose of
+// (frame, channel pair) dwords is four swap instructions, and a lane then owns whole 16-byte frames -- 3 stores per
+// group instead of 10 four-byte ones 16 bytes apart (store_group_rows).  And with a pad of 4 floats per period the 32
+// lanes of a half-wave (2 channel pairs x 16 periods, 8 bytes each) cover all 64 banks once: the loop's reads are
+// conflict-free as before (plan_period_r picks the pad for this mapping).
+template <int CT, bool ONE_GROUP, bool PADDED, int CGF = 0, bool PP = false, bool ROWS = false>
 __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshift, uint32_t m_lo,
                                             uint32_t m_cnt, uint32_t lane) {
   // ONE_GROUP: the frame is exactly one channel group (mono, stereo): the sample stride is a
@@ -131,8 +138,9 @@ __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshi
   const uint32_t cgroups = kGroups != 0 ? kGroups : p.cgroups;
   LaneCtx c;
   c.C = kGroups != 0 ? kGroups * CT : p.channels;
-  c.cg = ONE_GROUP ? 0 : lane % cgroups;
-  const uint32_t pl = ONE_GROUP ? lane : lane / cgroups;  // period of this lane inside the tile
+  static_assert(!ROWS || (CGF == 4 && CT == 2), "the row mapping is for frames of four channel pairs");
+  c.cg = ONE_GROUP ? 0 : ROWS ? lane >> 4 : lane % cgroups;
+  const uint32_t pl = ONE_GROUP ? lane : ROWS ? (lane & 15u) : lane / cgroups;  // period of this lane inside the tile
   // CT == 1 (odd channel counts): a packed FMA has no second channel to work on, so the lane takes
   // a second PERIOD instead, half a tile further (p.half_periods): .x = period pl, .y = pl + half.
   // (PP -- phase pairs, round 4: a single-channel lane with ONE period and 2R phases of it; FirLoopAsmPP)
@@ -515,6 +523,67 @@ __device__ __forceinline__ void store_group(const PeriodParams &p, const StreamD
   }
 }
 
+// The stores of the ROWS mapping (lane_ctx): int16 frames of 8 channels.  Every lane of the wave runs this (the swaps
+// move data between lanes whatever their state); `live` = the lane's period exists.  A block of four frames that lies
+// wholly inside the call for every live lane (wave-uniform test) is transposed across the four rows by four swaps and
+// leaves as one 16-byte store per lane; the last two frames of a group of ten as 8 bytes per lane; any other block --
+// the call's first and last periods, the padding phases of the filter's last group -- as 4-byte pieces like store_group.
+template <int R>
+__device__ __forceinline__ void store_group_rows(const PeriodParams &p, const StreamDesc &d, const LaneCtx &c, uint32_t g,
+                                                 bool live, const f32x2 (&acc)[R]) {
+  static_assert(R == 10, "written for groups of ten phases");
+  const int64_t k0 = static_cast<int64_t>(c.K_lane) + static_cast<int64_t>(g) * R - d.k_shift;
+  const int64_t lo64 = k0 < 0 ? -k0 : 0;
+  const int64_t hi64 = min(static_cast<int64_t>(R), min(static_cast<int64_t>(p.den) - static_cast<int64_t>(g) * R,
+                                                       static_cast<int64_t>(d.n_out) - k0));
+  const int i_lo = static_cast<int>(min(lo64, static_cast<int64_t>(R)));
+  const int i_hi = static_cast<int>(max(hi64, static_cast<int64_t>(0)));
+  uint32_t v[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) v[i] = round_pack_pcm(acc[i].x, acc[i].y);
+  const bool dword_ok = (reinterpret_cast<uintptr_t>(d.out) & 3u) == 0;
+  g_i16 *frame0 = out_ptr<int16_t>(d) + k0 * 8;  // frame k0 of the call, channel 0
+  const uint32_t row = c.cg;                     // this lane's row = the channel pair it computed
+  auto narrow = [&](int first, int count) {      // frames [first, first + count) as the lane's own 4-byte pieces
+#pragma unroll
+    for (int i = first; i < first + count; i++) {
+      if (!live || i < i_lo || i >= i_hi) continue;
+      g_i16 *o = frame0 + i * 8 + row * 2;
+      if (dword_ok) {
+        *(g_u32 *)o = v[i];
+      } else {
+        o[0] = static_cast<int16_t>(v[i] & 0xffffu);
+        o[1] = static_cast<int16_t>(v[i] >> 16);
+      }
+    }
+  };
+  auto whole = [&](int first, int count) {       // wave-uniform: no live lane has a frame of the block outside the call
+    const bool cut = live && (i_lo > first || i_hi < first + count || !dword_ok);
+    return __builtin_amdgcn_ballot_w64(cut) == 0;
+  };
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    if (!whole(4 * b, 4)) {
+      narrow(4 * b, 4);
+      continue;
+    }
+    // rows hold columns: after the swaps row r holds frame 4b + r whole (w0..w3 = its four channel pairs)
+    auto s02 = __builtin_amdgcn_permlane32_swap(v[4 * b], v[4 * b + 2], false, false);
+    auto s13 = __builtin_amdgcn_permlane32_swap(v[4 * b + 1], v[4 * b + 3], false, false);
+    auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+    auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+    if (live) *(g_u32x4_a4 *)(frame0 + (4 * b + static_cast<int>(row)) * 8) = u32x4_a4{t01[0], t01[1], t23[0], t23[1]};
+  }
+  if (!whole(8, 2)) {
+    narrow(8, 2);
+  } else {
+    // two frames over four rows: row r gets channel pairs 2 (r & 1), 2 (r & 1) + 1 of frame 8 + (r >> 1)
+    auto s = __builtin_amdgcn_permlane32_swap(v[8], v[9], false, false);
+    auto t = __builtin_amdgcn_permlane16_swap(s[0], s[1], false, false);
+    if (live) *(g_u32x2_a4 *)(frame0 + (8 + static_cast<int>(row >> 1)) * 8 + (row & 1u) * 4) = u32x2_a4{t[0], t[1]};
+  }
+}
+
 // Phase pairs (round 4; FirLoopAsmPP): a lane is (period, channel) -- one period, ONE channel of a frame of CF = 1, 2
 // or 3 -- with 2R phases: acc[i] = phases 2i, 2i + 1 of group g.  rows: [group][trip][step][2R] floats; trips of 2 * steps_per_bank steps (2 for R = 10, 6 for R = 5).
 // part / parts: tap-range shares (fir_tile_parts): this wave runs trips [total*part/parts, total*(part+1)/parts).
@@ -732,7 +801,8 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
   //  further group on the copy read behind the previous one's loop: a read in FRONT of the first loop as well put
   //  a scalar-load round trip between the staging barrier and the FIR of every workgroup, ~0.2 us that a
   //  one-generation launch cannot hide)
-  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED, CGF, AM == 2>(p0, xshift, m_lo, m_cnt, lane);
+  constexpr bool kRows = PADDED && CGF == 4 && !W16 && AM == 0;  // (lane_ctx: rows of 16 lanes = channel pairs)
+  const LaneCtx c = lane_ctx<CT, ONE_GROUP, PADDED, CGF, AM == 2, kRows>(p0, xshift, m_lo, m_cnt, lane);
   const uint32_t g_step = p0.wave_groups * nsplit;
   uint32_t g = zsplit * p0.wave_groups + wave;
   if (g >= p0.groups) return;
@@ -772,7 +842,19 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
 #endif
     STAMP(5);
     const PeriodParams q = params();  // (... and the far side)
-    if (!(q.skip & 8u) && c.live) {
+    if constexpr (kRows && sizeof(T) == 2 && R == 10) {
+      if (!(q.skip & 8u)) {  // (every lane: the transposes exchange data between the rows of the wave)
+        StreamDesc d;
+        if constexpr (kReload)
+          d = load_k(dp);
+        else
+          d = d0;
+        if (q.prio & 2u) __builtin_amdgcn_s_setprio(2);
+        store_group_rows<R>(q, d, c, g, c.live, acc);
+        if (q.prio & 2u) set_fir_priority(q);
+        STAMP(6);
+      }
+    } else if (!(q.skip & 8u) && c.live) {
       StreamDesc d;
       if constexpr (kReload)
         d = load_k(dp);
@@ -858,7 +940,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
   for (int i = 0; i < R; i++) acc[i] = f32x2{0.f, 0.f};
   {
     const PeriodParams p = load_k(pp);
-    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF, PP>(p, xshift, m_lo, m_cnt, lane);
+    c = lane_ctx<CT, ONE_GROUP, PADDED, CGF, PP, PADDED && CGF == 4 && !W16 && !PP>(p, xshift, m_lo, m_cnt, lane);
     wg = p.wave_groups;
     parts = p.ksplit;
     part = 0;
@@ -898,6 +980,13 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
   }
   STAMP(12);  // (partial sums added)
   const PeriodParams q = load_k(pp);
+  if constexpr (PADDED && CGF == 4 && !W16 && !PP && sizeof(T) == 2 && R == 10) {
+    if (q.skip & 8u) return;
+    const StreamDesc d = load_k(dp);
+    store_group_rows<R>(q, d, c, g, c.live, acc);  // (every lane of the wave: see there)
+    STAMP(6);
+    return;
+  }
   if ((q.skip & 8u) || !c.live) return;
   const StreamDesc d = load_k(dp);
   if constexpr (PP)
