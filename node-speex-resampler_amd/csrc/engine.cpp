@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <list>
 #include <map>
@@ -1516,7 +1517,8 @@ namespace {
 // process like the shared streams.  A call holds the lock of every device it touches from its first copy to its last.
 struct ManyStage {
   std::mutex mu;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, copy_stream = nullptr;  // (copy_stream + events: the pipelined large path)
+  std::vector<hipEvent_t> events;
   char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0, h_in_cap = 0, h_out_cap = 0;
   uint32_t seq = 0;
@@ -1563,9 +1565,11 @@ int Batch::many_on_device(int device, const std::vector<uint32_t> &idx, Batch *c
     Batch *b;
     CallPlan plan;
     size_t in_bytes, out_bytes, in_off, out_off;
+    bool work;
   };
   std::vector<Item> items(idx.size());
   size_t total_in = 0, total_out = 0;
+  bool all_big = true;
   for (size_t k = 0; k < idx.size(); k++) {
     Item &it = items[k];
     it.i = idx[k];
@@ -1576,8 +1580,10 @@ int Batch::many_on_device(int device, const std::vector<uint32_t> &idx, Batch *c
     it.plan = plan_call(it.b->filter_.num, it.b->filter_.den, in_len[it.i], out_len[it.i], it.b->P(0, 0), rules);
     it.in_bytes = in[it.i] != nullptr ? static_cast<size_t>(in_len[it.i]) * it.b->channels_ * es : 0;
     it.out_bytes = static_cast<size_t>(it.plan.produced) * it.b->channels_ * es;
+    it.work = it.plan.produced != 0 || it.plan.magic_used + it.plan.consumed != 0;
     total_in += align64(it.in_bytes);
     total_out += align64(it.out_bytes);
+    if (it.work && (it.in_bytes < kDirectCopyBytes || it.out_bytes < kDirectCopyBytes)) all_big = false;
   }
   // Small calls (a server's 10-20 ms frames, a Transform's 64 KiB chunks) are all latency: the kernels read and write
   // pinned memory straight through PCIe, one wait (process_host's small-call path).  Larger ones: inputs of >= 256 KB
@@ -1606,6 +1612,163 @@ int Batch::many_on_device(int device, const std::vector<uint32_t> &idx, Batch *c
   if (rc == SPEEXHIP_ERR_SUCCESS && !zero_copy) rc = grow_stage(device, &ms.d_out, &ms.d_out_cap, total_out, false);
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   char *src_base = zero_copy ? ms.h_in : ms.d_in, *dst_base = zero_copy ? ms.h_out : ms.d_out;
+
+  // launches: the states that share (tables, mode, window format) go together, at most 32 per launch
+  std::vector<std::vector<Item *>> launches;
+  {
+    std::map<std::tuple<const void *, int, bool>, std::vector<Item *>> groups;
+    for (Item &it : items) {
+      if (float_io) it.b->float_seen_ = true;
+      if (in_len[it.i] != 0 && out_len[it.i] != 0) it.b->started_[0] = 1;  // resample.c:886
+      if (!it.work) continue;  // nothing to run: the state stays where it is
+      groups[std::make_tuple(static_cast<const void *>(it.b->tables_.get()), it.b->mode_, it.b->float_seen_)].push_back(&it);
+    }
+    // Large calls in pieces (below): a launch then carries about 16 MB of input, so that the transfer of the next
+    // piece and the results of the previous one have something to overlap with.
+    static const int env_pipe = std::getenv("SPEEXHIP_MANY_PIPELINE") ? std::atoi(std::getenv("SPEEXHIP_MANY_PIPELINE")) : -1;  // A/B: 0 off
+    const bool pipelined = !zero_copy && all_big && env_pipe != 0 && total_in >= (static_cast<size_t>(32) << 20);
+    for (auto &kv : groups) {
+      std::vector<Item *> &g = kv.second;
+      size_t per = kMaxPackedStreams;
+      if (pipelined) {
+        size_t bytes = 0;
+        for (Item *it : g) bytes += it->in_bytes;
+        const size_t pieces = std::max<size_t>(1, bytes / (static_cast<size_t>(16) << 20));
+        per = std::min<size_t>(kMaxPackedStreams, std::max<size_t>(1, (g.size() + pieces - 1) / pieces));
+      }
+      for (size_t g0 = 0; g0 < g.size(); g0 += per)
+        launches.emplace_back(g.begin() + g0, g.begin() + std::min(g.size(), g0 + per));
+    }
+  }
+  // one launch of `launches[k]` on `stream`
+  auto launch = [&](const std::vector<Item *> &g, hipStream_t stream) -> int {
+    const uint32_t cnt = static_cast<uint32_t>(g.size());
+    DescPack pack;
+    std::memset(&pack, 0, sizeof(pack));
+    uint32_t max_out = 0;
+    for (uint32_t j = 0; j < cnt; j++) {
+      Item &it = *g[j];
+      Batch *b = it.b;
+      const int crc = b->chain_to(stream);  // (each state's calls stay ordered, whatever stream its last one ran on)
+      if (crc != SPEEXHIP_ERR_SUCCESS) return crc;
+      StreamDesc &d = pack.d[j];
+      const FilterSpec &f = b->filter_;
+      d.in = in[it.i] != nullptr ? src_base + it.in_off : nullptr;
+      d.hist = b->d_hist_[b->hist_cur_];
+      d.out = dst_base + it.out_off;
+      d.hist_next = b->d_hist_[b->hist_cur_ ^ 1];
+      d.in_frames = in_len[it.i];
+      d.n_out = it.plan.produced;
+      d.consumed = it.plan.magic_used + it.plan.consumed;
+      d.hist_frames = f.taps - 1 + it.plan.begin.magic;
+      d.hist_keep = f.taps - 1 + it.plan.end.magic;
+      d.last0 = it.plan.begin.last;
+      d.frac0 = it.plan.begin.frac;
+      d.k_shift = phase_index_of(f.num, f.den, it.plan.begin.frac);
+      d.base_shift = it.plan.begin.last - static_cast<int32_t>((static_cast<uint64_t>(d.k_shift) * f.num) / f.den);
+      d.tile_begin = 0;
+      d.m_total = static_cast<uint32_t>((static_cast<uint64_t>(d.k_shift) + d.n_out + f.den - 1) / f.den);
+      max_out = std::max(max_out, it.plan.produced);
+    }
+    const int lrc = g[0]->b->launch_chunk(pack.d, pack, cnt, max_out, float_io, stream);
+    if (lrc != SPEEXHIP_ERR_SUCCESS) return lrc;
+    for (uint32_t j = 0; j < cnt; j++) g[j]->b->hist_cur_ ^= 1;
+    return SPEEXHIP_ERR_SUCCESS;
+  };
+  auto commit = [&]() {  // counters and positions of every fused state
+    for (Item &it : items) {
+      for (uint32_t c = 0; c < it.b->channels_; c++) it.b->P(0, c) = it.plan.end;
+      in_len[it.i] = it.plan.consumed;
+      out_len[it.i] = it.plan.produced;
+      rcs[it.i] = SPEEXHIP_ERR_SUCCESS;
+    }
+  };
+
+  static const int env_pipe2 = std::getenv("SPEEXHIP_MANY_PIPELINE") ? std::atoi(std::getenv("SPEEXHIP_MANY_PIPELINE")) : -1;
+  if (!zero_copy && all_big && env_pipe2 != 0 && total_in >= (static_cast<size_t>(32) << 20) && launches.size() >= 2) {
+    // Large calls, pipelined (round 5).  PCIe is full duplex, but the runtime's pageable copies keep the thread that
+    // issues them busy until they are staged, so one thread alone moves inputs, computes, and moves results strictly
+    // one after the other: 32 streams x 2^20 stereo frames 5.8 ms, of which 0.2 are the kernel.  Here the calling
+    // thread copies the inputs of launch after launch on the stage's copy stream (an event behind each launch's
+    // inputs), while a second thread waits for the events, runs the launches on the stage's stream and copies each
+    // launch's results out behind it: results leave while the next inputs arrive.
+    if (ms.copy_stream == nullptr) {
+      for (int tries = 0; tries < 4 && (ms.copy_stream == nullptr || ms.copy_stream == ms.stream); tries++)
+        HIP_TRY(pool::stream_get(device, &ms.copy_stream));
+    }
+    while (ms.events.size() < launches.size()) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(pool::event_get(device, &e));
+      ms.events.push_back(e);
+    }
+    DrainOnExit drain_copy(&ms.copy_stream);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t ready = 0;       // launches whose inputs are enqueued with their event recorded
+    bool copy_failed = false;
+    int worker_rc = SPEEXHIP_ERR_SUCCESS;
+    std::string worker_err;
+    std::thread worker([&] {
+      DeviceScope scope(device);
+      for (size_t k = 0; k < launches.size() && worker_rc == SPEEXHIP_ERR_SUCCESS; k++) {
+        {
+          std::unique_lock<std::mutex> l(mu);
+          cv.wait(l, [&] { return ready > k || copy_failed; });
+          if (copy_failed) return;
+        }
+        auto fail = [&](hipError_t e, const char *what) {
+          if (e == hipSuccess) return false;
+          worker_err = std::string("HIP device error: ") + what + ": " + hipGetErrorString(e);
+          worker_rc = SPEEXHIP_ERR_DEVICE;
+          return true;
+        };
+        if (fail(hipStreamWaitEvent(ms.stream, ms.events[k], 0), "hipStreamWaitEvent")) return;
+        const int lrc = launch(launches[k], ms.stream);
+        if (lrc != SPEEXHIP_ERR_SUCCESS) {
+          worker_rc = lrc;
+          worker_err = g_last_error;
+          return;
+        }
+        for (Item *it : launches[k])
+          if (it->out_bytes != 0 &&
+              fail(hipMemcpyAsync(out[it->i], ms.d_out + it->out_off, it->out_bytes, hipMemcpyDeviceToHost, ms.stream), "hipMemcpyAsync (results)"))
+            return;
+      }
+      if (worker_rc == SPEEXHIP_ERR_SUCCESS) {
+        const hipError_t e = hipStreamSynchronize(ms.stream);
+        if (e != hipSuccess) {
+          worker_err = std::string("HIP device error: hipStreamSynchronize: ") + hipGetErrorString(e);
+          worker_rc = SPEEXHIP_ERR_DEVICE;
+        }
+      }
+    });
+    hipError_t copy_err = hipSuccess;
+    for (size_t k = 0; k < launches.size() && copy_err == hipSuccess; k++) {
+      for (Item *it : launches[k])
+        if (it->in_bytes != 0 && copy_err == hipSuccess)
+          copy_err = hipMemcpyAsync(ms.d_in + it->in_off, in[it->i], it->in_bytes, hipMemcpyHostToDevice, ms.copy_stream);
+      if (copy_err == hipSuccess) copy_err = hipEventRecord(ms.events[k], ms.copy_stream);
+      {
+        std::lock_guard<std::mutex> l(mu);
+        if (copy_err == hipSuccess)
+          ready = k + 1;
+        else
+          copy_failed = true;
+      }
+      cv.notify_all();
+    }
+    worker.join();
+    if (hip_failed(copy_err, "hipMemcpyAsync (inputs)")) return SPEEXHIP_ERR_DEVICE;
+    if (worker_rc != SPEEXHIP_ERR_SUCCESS) {
+      g_last_error = worker_err;
+      return worker_rc;
+    }
+    drain.armed = false;
+    drain_copy.armed = false;
+    commit();
+    return SPEEXHIP_ERR_SUCCESS;
+  }
+
   for (const Item &it : items) {
     if (it.in_bytes == 0) continue;
     if (zero_copy || it.in_bytes < kDirectCopyBytes)
@@ -1614,63 +1777,18 @@ int Batch::many_on_device(int device, const std::vector<uint32_t> &idx, Batch *c
       HIP_TRY(hipMemcpyAsync(ms.d_in + it.in_off, in[it.i], it.in_bytes, hipMemcpyHostToDevice, ms.stream));
   }
   if (!zero_copy && small_in != 0) HIP_TRY(hipMemcpyAsync(ms.d_in, ms.h_in, small_in, hipMemcpyHostToDevice, ms.stream));
-  // launches: the states that share (tables, mode, window format) go together, 32 per launch
-  std::map<std::tuple<const void *, int, bool>, std::vector<Item *>> groups;
-  for (Item &it : items) {
-    if (float_io) it.b->float_seen_ = true;
-    if (in_len[it.i] != 0 && out_len[it.i] != 0) it.b->started_[0] = 1;  // resample.c:886
-    if (it.plan.produced == 0 && it.plan.magic_used + it.plan.consumed == 0) continue;  // nothing to run: the state stays
-    groups[std::make_tuple(static_cast<const void *>(it.b->tables_.get()), it.b->mode_, it.b->float_seen_)].push_back(&it);
+  for (const std::vector<Item *> &g : launches) {
+    rc = launch(g, ms.stream);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
-  for (auto &kv : groups) {
-    std::vector<Item *> &g = kv.second;
-    for (size_t g0 = 0; g0 < g.size(); g0 += kMaxPackedStreams) {
-      const uint32_t cnt = static_cast<uint32_t>(std::min<size_t>(kMaxPackedStreams, g.size() - g0));
-      DescPack pack;
-      std::memset(&pack, 0, sizeof(pack));
-      uint32_t max_out = 0;
-      for (uint32_t j = 0; j < cnt; j++) {
-        Item &it = *g[g0 + j];
-        Batch *b = it.b;
-        rc = b->chain_to(ms.stream);  // (each state's calls stay ordered, whatever stream its last one ran on)
-        if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-        StreamDesc &d = pack.d[j];
-        const FilterSpec &f = b->filter_;
-        d.in = in[it.i] != nullptr ? src_base + it.in_off : nullptr;
-        d.hist = b->d_hist_[b->hist_cur_];
-        d.out = dst_base + it.out_off;
-        d.hist_next = b->d_hist_[b->hist_cur_ ^ 1];
-        d.in_frames = in_len[it.i];
-        d.n_out = it.plan.produced;
-        d.consumed = it.plan.magic_used + it.plan.consumed;
-        d.hist_frames = f.taps - 1 + it.plan.begin.magic;
-        d.hist_keep = f.taps - 1 + it.plan.end.magic;
-        d.last0 = it.plan.begin.last;
-        d.frac0 = it.plan.begin.frac;
-        d.k_shift = phase_index_of(f.num, f.den, it.plan.begin.frac);
-        d.base_shift = it.plan.begin.last - static_cast<int32_t>((static_cast<uint64_t>(d.k_shift) * f.num) / f.den);
-        d.tile_begin = 0;
-        d.m_total = static_cast<uint32_t>((static_cast<uint64_t>(d.k_shift) + d.n_out + f.den - 1) / f.den);
-        max_out = std::max(max_out, it.plan.produced);
-      }
-      rc = g[g0]->b->launch_chunk(pack.d, pack, cnt, max_out, float_io, ms.stream);
-      if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-      for (uint32_t j = 0; j < cnt; j++) g[g0 + j]->b->hist_cur_ ^= 1;
-    }
-  }
-  for (Item &it : items) {
-    for (uint32_t c = 0; c < it.b->channels_; c++) it.b->P(0, c) = it.plan.end;
-    in_len[it.i] = it.plan.consumed;
-    out_len[it.i] = it.plan.produced;
-    rcs[it.i] = SPEEXHIP_ERR_SUCCESS;
-  }
+  commit();
   // results back
   if (zero_copy) {
     volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(ms.h_out + ((ms.h_out_cap - 64) & ~static_cast<size_t>(63)));
     const uint32_t seq = ++ms.seq;
     *done = seq - 1;
     bool signalled = false;
-    if (!groups.empty() && hipStreamWriteValue32(ms.stream, const_cast<uint32_t *>(done), seq, 0) == hipSuccess) {
+    if (!launches.empty() && hipStreamWriteValue32(ms.stream, const_cast<uint32_t *>(done), seq, 0) == hipSuccess) {
       const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
       for (uint32_t spins = 0; !signalled; spins++) {
         signalled = __atomic_load_n(const_cast<const uint32_t *>(done), __ATOMIC_ACQUIRE) == seq;

@@ -2008,3 +2008,37 @@ def test_fast_fixed_mode_bytes_do_not_depend_on_chunking_or_batch_size(ch, i, o,
         for st in states:
             st.close()
         assert np.array_equal(np.concatenate(out), a), "fast_fixed: bytes depend on the batch size (%d)" % (others + 1)
+
+
+def test_large_many_states_call_runs_pipelined_and_matches():
+    """Round 5: a many-states call of >= 32 MB of large buffers runs in pieces -- the calling thread copies launch
+    after launch's inputs on one stream, a second thread launches behind each event and copies that launch's results out
+    while the next inputs arrive (PCIe both ways at once).  12 stereo states x 2^20 frames (50 MB in), two consecutive
+    calls: EXACT bytes equal the oracle's for three states and the separate single-state calls' for all; counters,
+    positions, histories equal.  SPEEXHIP_MANY_PIPELINE=0 (a child process) is the same call in one piece."""
+    import sys
+    ch, i, o, q, S, frames = 2, 44100, 48000, 7, 12, 1 << 20
+    cap, _ = orc.wrapper_capacity(frames * ch * 2, i, o, ch)
+    many = [speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT) for _ in range(S)]
+    apart = [speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT) for _ in range(S)]
+    refs = {s: orc.Oracle(ch, i, o, q) for s in (0, 5, 11)}
+    for call in range(2):
+        chunks = [orc.lcg_pcm(frames * ch, 100 * call + s).reshape(frames, ch) for s in range(S)]
+        outs, used, codes = speexhip.process_many(many, chunks, [cap] * S)
+        assert codes == [0] * S
+        for s in range(S):
+            want, wu = apart[s].process(chunks[s], cap)
+            assert used[s] == wu and np.array_equal(outs[s], want), (call, s)
+            assert many[s].position() == apart[s].position()
+        for s, ref in refs.items():
+            want, wu = ref.process(chunks[s], cap)
+            assert used[s] == wu and np.array_equal(outs[s], want), (call, s)
+    for s in (0, 11):
+        assert np.array_equal(many[s].history(), apart[s].history())
+    for r in many + apart:
+        r.close()
+    if os.environ.get("SPEEXHIP_MANY_PIPELINE") is None:
+        env = dict(os.environ, SPEEXHIP_MANY_PIPELINE="0")
+        res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                              "large_many_states_call"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
