@@ -1710,6 +1710,7 @@ int Batch::many_on_device(int device, const std::vector<uint32_t> &idx, Batch *c
     std::string worker_err;
     std::thread worker([&] {
       DeviceScope scope(device);
+      try {
       for (size_t k = 0; k < launches.size() && worker_rc == SPEEXHIP_ERR_SUCCESS; k++) {
         {
           std::unique_lock<std::mutex> l(mu);
@@ -1740,6 +1741,9 @@ int Batch::many_on_device(int device, const std::vector<uint32_t> &idx, Batch *c
           worker_err = std::string("HIP device error: hipStreamSynchronize: ") + hipGetErrorString(e);
           worker_rc = SPEEXHIP_ERR_DEVICE;
         }
+      }
+      } catch (...) {  // (a host allocation inside a launcher: no exception leaves a thread)
+        worker_rc = SPEEXHIP_ERR_ALLOC_FAILED;
       }
     });
     hipError_t copy_err = hipSuccess;
