@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <condition_variable>
@@ -148,6 +149,21 @@ const size_t kPieceBytes = static_cast<size_t>(2) << 20;
 const size_t kZeroCopyBelow = 720 * 1024;    // ... and calls whose buffers are smaller than this run on pinned memory alone
 }  // namespace
 
+// SPEEXHIP_INIT_TRACE=1: where a state's creation goes, step by step (stderr; tools/first_call.py)
+struct InitTrace {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  static bool on() {
+    static const bool v = std::getenv("SPEEXHIP_INIT_TRACE") != nullptr;
+    return v;
+  }
+  void step(const char *what) {
+    if (!on()) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "speexhip init: %-40s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 const char *last_device_error() { return g_last_error.c_str(); }
 void set_last_device_error(const std::string &text) { g_last_error = text; }
 size_t lds_budget() { return kLdsBudget; }
@@ -207,7 +223,9 @@ Batch *Batch::create_frac(uint32_t n_streams, uint32_t channels, uint32_t ratio_
 }
 
 int Batch::setup() {
+  InitTrace trace;
   const int count = devices::count();
+  trace.step("device count (first HIP call)");
   if (count <= 0) {
     g_last_error = count < 0 ? "HIP device error: hipGetDeviceCount failed (libspeexhip has no CPU fallback)"
                              : "HIP device error: no GPU visible (libspeexhip has no CPU fallback)";
@@ -228,7 +246,9 @@ int Batch::setup() {
   }
   ON_DEVICE();  // (everything below -- pool, tables, uploads -- runs on the state's device)
   hipDeviceProp_t prop;
+  trace.step("placement + hipSetDevice");
   HIP_TRY(hipGetDeviceProperties(&prop, devices::physical(device_)));
+  trace.step("hipGetDeviceProperties");
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     g_last_error = std::string("HIP device error: built for gfx950 (MI355X), found ") + prop.gcnArchName;
     return SPEEXHIP_ERR_DEVICE;
@@ -242,6 +262,7 @@ int Batch::setup() {
   started_.assign(n_streams_, 0);
   const FilterSpec designed = filter_;
   int rc = install_filter(designed, std::vector<float>(), designed.taps - 1);  // resample.c:721-725: silence
+  trace.step("install_filter (total)");
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   return SPEEXHIP_ERR_SUCCESS;  // (install_filter waited for its own uploads)
 }
@@ -287,8 +308,10 @@ const size_t kCacheableBytes = static_cast<size_t>(64) << 20;  // bigger table s
 // are published: never on the null stream, whose copies would wait for every blocking stream of the process.
 int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t stream,
                  std::shared_ptr<const DeviceTables> *out) {
+  InitTrace trace;
   FilterSpec f;
   int rc = design_filter_frac(g.num, g.den, g.in_rate, g.out_rate, g.quality, &f);
+  trace.step("    filter design (host)");
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   auto t = std::make_shared<DeviceTables>();
   t->device = device;
@@ -306,6 +329,7 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
     return upload_bytes(reinterpret_cast<void **>(dst), src, count * sizeof(float));
   };
   rc = upload(&t->table, f.table.data(), f.table_len);
+  trace.step("    first allocation + upload (sinc table)");
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   t->geo = exact_geometry(f, channels, kLdsBudget);
   t->geo_ch = exact_geometry(f, 1, kLdsBudget);
@@ -388,6 +412,7 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
       if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     }
   }
+  trace.step("    plans, tap rows, their uploads");
   *out = t;
   return SPEEXHIP_ERR_SUCCESS;
 }
@@ -457,9 +482,12 @@ size_t release_cached_tables() {
 // the batch holds: a failed allocation leaves the batch exactly as it was (the caller decides what
 // a failure means, resample.c:785-791).
 int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, uint32_t hist_frames_cap) {
+  InitTrace trace;
   if (own_stream_ == nullptr) HIP_TRY(pool::stream_get(device_, &own_stream_));
+  trace.step("  stream");
   std::shared_ptr<const DeviceTables> tables;
   int rc = acquire_tables(device_, f, channels_, own_stream_, &tables);
+  trace.step("  tables (design, allocations, uploads)");
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   struct Fresh {
     int device = 0;
@@ -490,6 +518,7 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
     HIP_TRY(hipStreamSynchronize(own_stream_));  // the new buffers are in place for a launch on any stream
     drain.armed = false;
   }
+  trace.step("  history buffers + their image");
   // What the batch held goes back to the pool / the cache below, so nothing in flight may still read it:
   // wait for this batch's own last call -- not for the device: other states' launches keep running.
   if (tables_ != nullptr) {
