@@ -190,7 +190,9 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   t.window_bytes = t.lane_periods ? window_bytes_for(t.lane_periods) : 0;
   // needs enough phases to fill the R-wide register tile and a window that fits one CU's LDS
   // ... and at least a quarter of each wave at work (below that the exact kernel's mapping wins)
-  t.usable = f.den >= 7 && t.cgroups <= 64 && 4 * t.lane_periods >= full && t.window_bytes <= lds_budget;
+  // (SPEEXHIP_MIN_FILL=n, diagnostics: at least 1/n of the lanes instead of a quarter -- profiles/r05_wide_windows.txt)
+  static const uint32_t min_fill = std::getenv("SPEEXHIP_MIN_FILL") ? std::max(1, std::atoi(std::getenv("SPEEXHIP_MIN_FILL"))) : 4;
+  t.usable = f.den >= 7 && t.cgroups <= 64 && min_fill * t.lane_periods >= full && t.window_bytes <= lds_budget;
   // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py); so are the
   // tap rows of an fp64 accumulator
   if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1))) t.usable = false;

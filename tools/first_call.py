@@ -51,3 +51,7 @@ print("code objects in libspeexhip.so: %.1f MB" % (os.path.getsize(os.path.join(
 for a, b, unit in CASES:
     res = subprocess.run([sys.executable, "-c", CHILD % (ROOT, repr(a), repr(b), unit)], capture_output=True, text=True)
     print((res.stdout.strip() or res.stderr.strip()[-400:]), flush=True)
+    if os.environ.get("SPEEXHIP_INIT_TRACE") or os.environ.get("SPEEXHIP_POOL_TRACE"):   # the library's own stamps (stderr)
+        for line in res.stderr.splitlines():
+            if line.startswith("speexhip "):
+                print("    " + line, flush=True)
