@@ -90,6 +90,13 @@ SPEEXHIP_API SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channel
  * (SPEEXHIP_ALIAS_DEVICES=n, tests only: n logical devices, logical d on physical d mod the real count -- pools, table
  * caches, streams and this rule key on the logical ordinal, so a 1-GPU box walks the multi-device paths.) */
 SPEEXHIP_API int speexhip_device_count(void);   /* usable logical devices; <= 0: none (no CPU fallback) */
+/* The one-time costs of a process that the first states would otherwise pay -- the runtime's start (90-180 ms), the
+ * pool's four shared streams per device (20 + 3 x 8 ms), the copy engines' first copy (8 ms); a state itself is 0.04 ms
+ * of filter design and 0.2 ms of uploads -- paid now, on `device` or (device < 0) on every device the placement rule
+ * can choose.  Blocking; call it from a thread of its own beside the application's other start-up work.  The N-API addon
+ * does, at import, and SpeexResampler.initPromise resolves behind it -- where the reference compiles its WASM module
+ * (src/index.ts:18-19, :31).  Optional: without it the first states pay as before.  Returns an error code. */
+SPEEXHIP_API int speexhip_warmup(int device);
 SPEEXHIP_API SpeexHipResamplerState *speexhip_resampler_init_on(int device, uint32_t nb_channels, uint32_t in_rate,
                                                                 uint32_t out_rate, int quality, int *err);
 

@@ -42,6 +42,9 @@ struct SpeexHipBatch_ {
 extern "C" {
 
 int speexhip_device_count(void) { return speexhip::devices::count(); }
+int speexhip_warmup(int device) {
+  return guarded([&] { return speexhip::warmup(device); });
+}
 int speexhip_debug_placement(int device_count, const char *env_device, const char *env_devices, uint64_t k,
                              int current_device) {
   return speexhip::devices::placement_rule(device_count, env_device, env_devices, k, current_device);

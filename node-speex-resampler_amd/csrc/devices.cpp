@@ -94,6 +94,22 @@ int placement_rule(int device_count, const char *env_device, const char *env_dev
   return current_device >= 0 && current_device < device_count ? current_device : -1;
 }
 
+void placement_candidates(int *out, int *n, int cap) {
+  *n = 0;
+  const int cnt = count();
+  if (cnt <= 0) return;
+  const char *one = std::getenv("SPEEXHIP_DEVICE"), *many = std::getenv("SPEEXHIP_DEVICES");
+  const int cur = current();
+  // (the rule itself enumerates them: states 0 .. cnt-1 of a process)
+  for (int k = 0; k < cnt && *n < cap; k++) {
+    const int d = placement_rule(cnt, one, many, static_cast<uint64_t>(k), cur);
+    if (d < 0) return;
+    bool seen = false;
+    for (int j = 0; j < *n; j++) seen = seen || out[j] == d;
+    if (!seen) out[(*n)++] = d;
+  }
+}
+
 int place_next_state() {
   const int n = count();
   if (n <= 0) return -1;

@@ -34,6 +34,10 @@ int current();
 // malformed.
 int placement_rule(int device_count, const char *env_device, const char *env_devices, uint64_t k, int current);
 
+// The devices the rule can place a state on, given the environment (warm-up): the listed ones, or the one fixed
+// device, or the thread's current device; empty when the environment is invalid or no GPU is visible.
+void placement_candidates(int *out, int *n, int cap);
+
 // Device for the next new state of this process by the rule above (advances the state counter);
 // -1 = the environment is invalid for this node (init then fails with SPEEXHIP_ERR_DEVICE).
 int place_next_state();

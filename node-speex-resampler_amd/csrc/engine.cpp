@@ -1540,6 +1540,48 @@ int Batch::process_host_chunks(uint32_t n_chunks, const void *const *in, uint32_
   return SPEEXHIP_ERR_SUCCESS;
 }
 
+// ---- warm-up (speexhip_warmup) ------------------------------------------------------------------------------------
+// What the FIRST state of a process pays that has nothing to do with the state: the runtime's own start (the first HIP
+// call, 90-180 ms), the first stream (20 ms; 160 ms when it is also the runtime's first), each further shared stream
+// (~8 ms for the second to fourth state), the first copy (~8 ms: the copy engines' queues) -- against 0.04 ms of filter
+// design and 0.2 ms of uploads (profiles/r05_first_call_trace.txt).  The reference pays its counterpart -- compiling
+// the WASM module -- when the module is imported, behind SpeexResampler.initPromise (src/index.ts:18-19, :31); so does
+// the drop-in: the addon runs this on a pool thread at import and initPromise resolves behind it.
+int warm_device(int device) {
+  DeviceScope scope(device);
+  HIP_TRY(scope.error());
+  HIP_TRY(pool::streams_prewarm(device));
+  hipStream_t s = nullptr;
+  HIP_TRY(pool::stream_get(device, &s));
+  void *d = nullptr;
+  HIP_TRY(pool::device_get(device, &d, kCtlCopyMin));
+  const std::vector<char> zeros(kCtlCopyMin, 0);
+  const int rc = ctl_upload(d, zeros.data(), zeros.size(), s);  // (pinned image -> device through the copy engines)
+  pool::device_put(device, d);
+  return rc;
+}
+
+int warmup(int device) {
+  const int count = devices::count();
+  if (count <= 0) {
+    g_last_error = "HIP device error: no GPU visible (libspeexhip has no CPU fallback)";
+    return SPEEXHIP_ERR_DEVICE;
+  }
+  if (device >= count) return SPEEXHIP_ERR_INVALID_ARG;
+  if (device >= 0) return warm_device(device);
+  int list[64], n = 0;
+  devices::placement_candidates(list, &n, 64);
+  if (n == 0) {
+    g_last_error = "HIP device error: SPEEXHIP_DEVICE / SPEEXHIP_DEVICES names a device this node does not have";
+    return SPEEXHIP_ERR_DEVICE;
+  }
+  for (int k = 0; k < n; k++) {
+    const int rc = warm_device(list[k]);
+    if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  }
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
 // ---- host-buffer calls of many single-stream states at once (engine.h) ---------------------------------------------
 namespace {
 // Staging of the many-states call: one per logical device, grow-only, taken from the pool and kept for the life of the

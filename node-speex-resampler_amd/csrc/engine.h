@@ -46,6 +46,9 @@ struct DeviceTables {
   DeviceTables &operator=(const DeviceTables &) = delete;
   ~DeviceTables();
 };
+// speexhip_warmup: the runtime's and the pool's one-time start-up costs on `device` (< 0: every device the placement
+// rule can choose), paid now instead of by the first states.
+int warmup(int device);
 // Idle cache entries back to the pool (speexhip_release_cached_memory); the bytes they held.
 size_t release_cached_tables();
 

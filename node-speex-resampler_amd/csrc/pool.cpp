@@ -301,6 +301,24 @@ hipError_t stream_get(int device, hipStream_t *out) {
 
 void stream_put(int, hipStream_t) {}  // shared: nothing to give back
 
+// Warm-up (engine.cpp, warm_device): all of a device's shared streams made ahead of the first state -- the first
+// stream of a process costs 20-160 ms (the runtime sets up its hardware queues), each further one ~8 ms
+// (profiles/r05_first_call_trace.txt); made here, off the caller's path, a state's creation never meets that.
+hipError_t streams_prewarm(int device) {
+  State &s = st();
+  for (size_t k = 0; k < kSharedStreams; k++) {
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto &v = s.streams[device];
+    if (v.size() >= kSharedStreams) break;
+    MissTimer timer("hipStreamCreate (warm-up)", 0);
+    hipStream_t h = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&h, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    v.push_back(h);
+  }
+  return hipSuccess;
+}
+
 hipError_t event_get(int device, hipEvent_t *out) {
   State &s = st();
   {

@@ -19,7 +19,16 @@ const globalModulePromise = new Promise((resolve, reject) => {
   } catch (e) {
     reject(e);
   }
-}).then((m) => { speexModule = m; return m; });
+}).then((m) => {
+  // The reference compiles its WASM module here, behind initPromise (src/index.ts:18-19).  The counterpart: the GPU
+  // runtime's start, the library's shared streams and the copy engines' first copy -- 0.2-0.35 s that the first
+  // instances would otherwise pay inside their first processChunk -- run on a pool thread while the application goes
+  // on loading; initPromise resolves behind them.  A failure (no GPU) is not reported here: the first processChunk
+  // throws Error(strerror(code)) as always.  SPEEXHIP_NO_WARMUP=1 skips it.
+  const done = () => { speexModule = m; return m; };
+  if (process.env.SPEEXHIP_NO_WARMUP === '1' || typeof m.warmup !== 'function') return done();
+  return m.warmup().then(done, done);
+});
 
 class SpeexResampler {
   /**

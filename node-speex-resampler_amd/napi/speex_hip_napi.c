@@ -836,6 +836,41 @@ static napi_value ProcessManyAsync(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+/* warmup() -> Promise<number>: speexhip_warmup(-1) on a libuv pool thread; resolves with its return code (never rejects:
+ * a box without a GPU is reported by the first real call, like the reference's errors) */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  int rc;
+} WarmJob;
+static void warm_execute(napi_env env, void *data) {
+  (void)env;
+  ((WarmJob *)data)->rc = speexhip_warmup(-1);
+}
+static void warm_complete(napi_env env, napi_status status, void *data) {
+  WarmJob *j = (WarmJob *)data;
+  napi_value v;
+  (void)status;
+  napi_create_int32(env, j->rc, &v);
+  napi_resolve_deferred(env, j->deferred, v);
+  napi_delete_async_work(env, j->work);
+  free(j);
+}
+static napi_value Warmup(napi_env env, napi_callback_info info) {
+  (void)info;
+  WarmJob *j = (WarmJob *)calloc(1, sizeof(WarmJob));
+  napi_value promise, name;
+  if (j == NULL || napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+      napi_create_string_utf8(env, "speexhip.warmup", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+      napi_create_async_work(env, NULL, name, warm_execute, warm_complete, j, &j->work) != napi_ok ||
+      napi_queue_async_work(env, j->work) != napi_ok) {
+    free(j);
+    napi_throw_error(env, NULL, "speexhip N-API failure: queueing warmup");
+    return NULL;
+  }
+  return promise;
+}
+
 /* deviceCount() -> GPUs the library can place states on (speexhip_device_count) */
 static napi_value DeviceCount(napi_env env, napi_callback_info info) {
   (void)info;
@@ -887,6 +922,7 @@ NAPI_MODULE_INIT() {
       {"processMany", NULL, ProcessMany, NULL, NULL, NULL, napi_default, NULL},
       {"processManyAsync", NULL, ProcessManyAsync, NULL, NULL, NULL, napi_default, NULL},
       {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
+      {"warmup", NULL, Warmup, NULL, NULL, NULL, napi_default, NULL},
       {"stats", NULL, Stats, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props) != napi_ok)

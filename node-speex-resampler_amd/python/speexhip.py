@@ -54,7 +54,7 @@ EXPORTS = [
     # round 5: device placement, many states per call
     "speexhip_device_count", "speexhip_resampler_init_on", "speexhip_batch_init_on",
     "speexhip_resampler_process_many_int", "speexhip_resampler_process_many_float",
-    "speexhip_resampler_get_info2", "speexhip_debug_placement",
+    "speexhip_resampler_get_info2", "speexhip_debug_placement", "speexhip_warmup",
 ]
 
 
@@ -204,6 +204,8 @@ def lib():
                               C.POINTER(C.c_int)]
             L.speexhip_resampler_get_info2.restype = i32
             L.speexhip_resampler_get_info2.argtypes = [p, C.c_void_p, u32]
+            L.speexhip_warmup.restype = i32
+            L.speexhip_warmup.argtypes = [i32]
             L.speexhip_debug_placement.restype = i32
             L.speexhip_debug_placement.argtypes = [i32, C.c_char_p, C.c_char_p, C.c_uint64, i32]
         _lib = L

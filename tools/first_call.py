@@ -31,6 +31,9 @@ def ms(f):
 ch, i, o, q, frames = %s
 x = (np.random.RandomState(1).randn(frames, ch) * 3000).astype(np.int16)
 t_lib, _ = ms(speexhip.lib)
+t_warm = 0.0
+if os.environ.get("FIRST_CALL_WARMUP") == "1":   # (round 5: what the addon does at import, behind initPromise)
+    t_warm, _ = ms(lambda: speexhip.lib().speexhip_warmup(-1))
 t_new, r = ms(lambda: speexhip.Resampler(ch, i, o, q))
 t_first, _ = ms(lambda: r.process(x, frames * 7))
 t_second, _ = ms(lambda: r.process(x, frames * 7))
@@ -38,8 +41,8 @@ ch2, i2, o2, q2 = %s
 r2 = speexhip.Resampler(ch2, i2, o2, q2)
 x2 = (np.random.RandomState(2).randn(frames, ch2) * 3000).astype(np.int16)
 t_other, _ = ms(lambda: r2.process(x2, frames * 7))
-print("%%-34s HIP init %%7.1f ms | (import torch %%.0f) | dlopen libspeexhip %%5.1f | first state %%5.2f | first call %%6.2f | second %%5.2f | first call of %%s (same unit) %%5.2f   [fast_path %%d]" %%
-      ("%%dch %%d->%%d q%%d (%%s)" %% (ch, i, o, q, %r), t_init, t_torch, t_lib, t_new, t_first, t_second, "%%dch %%d->%%d q%%d" %% (ch2, i2, o2, q2), t_other, r.info()["fast_path"]))
+print("%%-34s HIP init %%7.1f ms | (import torch %%.0f) | dlopen libspeexhip %%5.1f | warm-up %%6.1f | first state %%5.2f | first call %%6.2f | second %%5.2f | first call of %%s (same unit) %%5.2f   [fast_path %%d]" %%
+      ("%%dch %%d->%%d q%%d (%%s)" %% (ch, i, o, q, %r), t_init, t_torch, t_lib, t_warm, t_new, t_first, t_second, "%%dch %%d->%%d q%%d" %% (ch2, i2, o2, q2), t_other, r.info()["fast_path"]))
 '''
 CASES = [((2, 44100, 48000, 7, 441000), (2, 48000, 44100, 5), "kernels_period.hip"),
          ((1, 24000, 48000, 5, 441000), (1, 16000, 48000, 7), "kernels_slide_i16.hip"),
