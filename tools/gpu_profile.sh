@@ -102,7 +102,19 @@ for IO in int16 float; do
   python bench.py --custom 1,44100,48000,7 --io $IO --steps 300 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
   python bench.py --custom 1,44100,48000,7 --io $IO --streams 32 --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 done
+# round 5: the pinned summation order at the BASELINE configs (cost of SPEEXHIP_MODE_FAST_FIXED), configs[4] whole on one
+# GPU with its CPU column on min(cores, 256) worker processes
+for CFG in cfg2 cfg3 cfg4; do
+  for S in 1 32; do
+    python bench.py --config $CFG --mode fast_fixed --streams $S --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+  done
+done
+python bench.py --total-streams 256 --steps 10 --warmup 2 > $O/r${N}_bench_total256.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_form.json 2>/dev/null
+python tools/r05_call_stamps.py > $O/r${N}_call_stamps.txt 2>/dev/null
+python tools/first_call.py > $O/r${N}_first_call.txt 2>/dev/null
+FIRST_CALL_WARMUP=1 python tools/first_call.py > $O/r${N}_first_call_warm.txt 2>/dev/null
+node --expose-gc tools/r05_steady.js > $O/r${N}_steady.txt 2>/dev/null
 python tools/host_path_bench.py > $O/r${N}_host_path.json 2>/dev/null
 python tools/small_call_latency.py > $O/r${N}_small_call_latency.txt 2>/dev/null
 python tools/init_cost.py > $O/r${N}_init_cost.txt 2>/dev/null
