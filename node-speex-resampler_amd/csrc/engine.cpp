@@ -1558,7 +1558,18 @@ int warm_device(int device) {
   const std::vector<char> zeros(kCtlCopyMin, 0);
   const int rc = ctl_upload(d, zeros.data(), zeros.size(), s);  // (pinned image -> device through the copy engines)
   pool::device_put(device, d);
-  return rc;
+  if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  // the code objects (kernels.h, SPEEXHIP_WARM_UNIT): one empty launch per translation unit
+  warm_unit_period(s);
+  warm_unit_slide_i16(s);
+  warm_unit_exact(s);
+  warm_unit_period64(s);
+  warm_unit_slide64_i16(s);
+  warm_unit_period_pp(s);
+  warm_unit_slide_f32(s);
+  warm_unit_slide64_f32(s);
+  HIP_TRY(hipStreamSynchronize(s));
+  return SPEEXHIP_ERR_SUCCESS;
 }
 
 int warmup(int device) {

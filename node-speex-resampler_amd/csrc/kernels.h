@@ -26,6 +26,24 @@ inline void opt_in_lds_on_this_device(K kern, std::atomic<uint64_t> &seen) {
   seen.fetch_or(bit, std::memory_order_release);
 }
 
+// Warm-up: each translation unit with kernels is a code object of its own, loaded onto a device by the first launch from
+// it (2-4 ms of a process's first call, tools/first_call.py).  Every such unit defines an empty kernel and
+// warm_unit_<name>(stream), which launches it; speexhip_warmup runs them all off the caller's path.
+#define SPEEXHIP_WARM_UNIT(name)                                             \
+  __global__ void warm_kernel_##name() {}                                    \
+  void warm_unit_##name(hipStream_t s) {                                     \
+    hipLaunchKernelGGL(warm_kernel_##name, dim3(1), dim3(64), 0, s);          \
+    (void)hipGetLastError();                                                 \
+  }
+void warm_unit_exact(hipStream_t s);
+void warm_unit_period(hipStream_t s);
+void warm_unit_slide_i16(hipStream_t s);
+void warm_unit_slide_f32(hipStream_t s);
+void warm_unit_slide64_i16(hipStream_t s);
+void warm_unit_slide64_f32(hipStream_t s);
+void warm_unit_period64(hipStream_t s);
+void warm_unit_period_pp(hipStream_t s);
+
 // compute units of the calling thread's current device (cached per device id)
 inline uint32_t device_compute_units() {
   static std::atomic<int> cached[64];

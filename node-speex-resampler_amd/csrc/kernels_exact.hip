@@ -295,4 +295,7 @@ hipError_t launch_exact(const FilterSpec &f, const ExactGeometry &g, const float
                   : launch_typed<int16_t>(f, p, pack, g, grid, stream);
 }
 
+// warm-up (engine.cpp, warm_device): one empty launch loads this translation unit's code object onto the device
+SPEEXHIP_WARM_UNIT(exact)
+
 }  // namespace speexhip

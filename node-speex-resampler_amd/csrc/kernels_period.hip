@@ -720,4 +720,7 @@ extern "C" __attribute__((visibility("default"))) int speexhip_debug_stamps(unsi
 }
 #endif
 
+// warm-up (engine.cpp, warm_device): one empty launch loads this translation unit's code object onto the device
+SPEEXHIP_WARM_UNIT(period)
+
 }  // namespace speexhip

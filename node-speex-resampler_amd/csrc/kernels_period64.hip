@@ -47,4 +47,7 @@ hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const D
   return hipErrorInvalidValue;
 }
 
+
+// warm-up (engine.cpp, warm_device): one empty launch loads this translation unit's code object onto the device
+SPEEXHIP_WARM_UNIT(period64)
 }  // namespace speexhip

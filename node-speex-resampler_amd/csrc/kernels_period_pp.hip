@@ -48,4 +48,7 @@ extern "C" __attribute__((visibility("default"))) int speexhip_debug_stamps_pp(u
 }
 #endif
 
+
+// warm-up (engine.cpp, warm_device): one empty launch loads this translation unit's code object onto the device
+SPEEXHIP_WARM_UNIT(period_pp)
 }  // namespace speexhip

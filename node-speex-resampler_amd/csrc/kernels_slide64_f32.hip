@@ -3,4 +3,7 @@
 #include "kernels_slide64_impl.h"
 namespace speexhip {
 template hipError_t launch_slide64_shape<float>(const SlidePlan &, const SlideParams &, const double *,                                                 const DescPack *, dim3, uint32_t, size_t, hipStream_t);
+// warm-up (engine.cpp, warm_device): one empty launch loads this translation unit's code object onto the device
+SPEEXHIP_WARM_UNIT(slide64_f32)
+
 }

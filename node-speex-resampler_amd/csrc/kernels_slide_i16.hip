@@ -4,4 +4,7 @@
 namespace speexhip {
 template hipError_t launch_slide_shape<int16_t>(const SlidePlan &, const SlideParams &, const DescPack *, dim3,
                                            uint32_t, size_t, hipStream_t);
+// warm-up (engine.cpp, warm_device): one empty launch loads this translation unit's code object onto the device
+SPEEXHIP_WARM_UNIT(slide_i16)
+
 }  // namespace speexhip
