@@ -28,3 +28,11 @@ for r in rows:
     sp = r['value'] / base['value'] * base['n_gpus']
     print('%4d %14.1f %12.4f %9.2fx %9.0f%%  %d' % (r['n_gpus'], r['value'], r['ms_per_step'], sp, 100 * sp / r['n_gpus'], r['config']['streams_per_gpu']))
 PY
+# Round 5: the same streams as ONE host process reaches them -- the library's own placement (SPEEXHIP_DEVICES=all: state
+# k on GPU k mod the GPU count) and one many-states call per step, host buffers in and out: every GPU is a PCIe link.
+echo "one process, host-fed, library placement (tools/host_many_bench.py):"
+for N in $GPUS; do
+  if [ "$N" -gt "$HAVE" ]; then continue; fi
+  LIST=$(python3 -c "print(','.join(str(i) for i in range($N)))")
+  SPEEXHIP_DEVICES=$LIST python tools/host_many_bench.py --streams $TOTAL --steps 4 | tail -1
+done
