@@ -269,12 +269,37 @@ def cpu_baseline(cfg, frames, budget_s=12.0, max_chunks=32):
                 chunks, frames, ch, dt)}
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask and the container's CPU quota (cgroup v2 cpu.max, v1
+    cfs_quota) bound os.cpu_count() -- a box that shows 256 cores to a container limited to a dozen ran 256 workers at
+    0.84 Msamples/s each against 11.2 for one alone (profiles/r05_bench_total256.json, first collection)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline_workers(cfg, frames, total_streams, budget_s=10.0):
     """SURVEY 8(d), configs[4]'s CPU column: the reference is one scalar thread per stream, so T streams on a host
     with C cores run min(C, T) at a time.  Starts that many fresh CHILD processes (this process has not touched a GPU
     yet), each timing the CPU path on its own stream for ~budget_s; value = samples all of them processed / the
     slowest one's time."""
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     workers = max(1, min(cores, total_streams))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
                                "%d,%d,%d,%d,%d,%d,%f" % (cfg + (frames, 12345 + w, budget_s))],
@@ -290,6 +315,7 @@ def cpu_baseline_workers(cfg, frames, total_streams, budget_s=10.0):
     total = sum(r["chunks"] for r in rows) * frames * ch
     slowest = max(r["seconds"] for r in rows)
     return {"value": round(total / slowest / 1e6, 3), "unit": "Msamples/s", "cores": cores, "workers": workers,
+            "cpu_count": os.cpu_count(),
             "kind": rows[0]["kind"],
             "per_worker_msamples_per_s": round(sum(r["chunks"] * frames * ch / r["seconds"] for r in rows) / workers / 1e6, 3),
             "sample": "%d worker processes (min(%d host cores, %d streams)), one stream each, %d chunks of %d frames x %d ch "
