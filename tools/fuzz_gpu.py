@@ -282,6 +282,89 @@ def batch_trial(seed, max_frames):
     return None, what
 
 
+def many_trial(seed, max_frames):
+    """Round 5: 2-40 single-stream states of 1-3 configurations through speexhip_resampler_process_many_int / _float
+    (host buffers, one call per step: per device one transfer in, one launch per <= 32 states of one filter, one
+    transfer out), modes mixed between the states, 1-4 steps of ragged lengths and capacities, NULL inputs, now and then
+    a state named twice and a set_quality between two steps; every state against an oracle state of its own."""
+    rng = np.random.RandomState(seed)
+    as_float = rng.rand() < 0.25
+    kinds = []
+    for _ in range(int(rng.randint(1, 4))):
+        i, o = pick_rates(rng)
+        kinds.append((int(rng.choice([1, 2, 2, 3, 4, 8])), i, o, int(rng.randint(0, 11))))
+    S = int(rng.choice([2, 3, 7, 16, 33, 40]))
+    cfg = [kinds[int(rng.randint(0, len(kinds)))] for _ in range(S)]
+    modes = [speexhip.MODE_EXACT if rng.rand() < 0.3 else (speexhip.MODE_FAST_FIXED if rng.rand() < 0.3 else speexhip.MODE_FAST) for _ in range(S)]
+    what = "seed=%d MANY S=%d kinds=%s %s" % (seed, S, kinds, "float" if as_float else "int16")
+    try:
+        refs = [orc.Oracle(*c) for c in cfg]
+    except Exception:
+        return None, what + " (oracle refuses)"
+    if any(r.den > 4000 and r.taps > 300 for r in refs):
+        return None, what + " (skipped: slow on the oracle)"
+    states = [speexhip.Resampler(*c, mode=m) for c, m in zip(cfg, modes)]
+    dt = np.float32 if as_float else np.int16
+    big = rng.rand() < 0.1   # one trial in ten crosses 32 MB: the pipelined large path
+    fmax = max(16, min(max_frames, int((48e6 if big else 4e6) / (S * 2))))
+    peak = [1.0] * S
+    for step in range(int(rng.randint(1, 5))):
+        order = list(range(S))
+        if rng.rand() < 0.2:
+            order.append(int(rng.randint(0, S)))   # a state twice in one call
+        chunks, caps, frames = [], [], []
+        for s_ in order:
+            ch, i, o, q = cfg[s_]
+            F = int(rng.randint(0, fmax + 1)) if rng.rand() < 0.8 else int(rng.choice([0, 1, 160, 480]))
+            full = int(F * o / max(i, 1)) + 64
+            cap = full if rng.rand() < 0.8 else int(rng.randint(0, full + 1))
+            if rng.rand() < 0.05:
+                chunks.append(None)
+                caps.append((F, cap))
+            else:
+                chunks.append(signal(rng, F, ch, as_float))
+                caps.append(cap)
+            frames.append(F)
+        outs, used, codes = speexhip.process_many([states[s_] for s_ in order], chunks, caps, dtype=dt)
+        for j, s_ in enumerate(order):
+            ref = refs[s_]
+            if chunks[j] is None:
+                want, wu = (ref.process_float if as_float else ref.process)(None, caps[j][1], null_frames=caps[j][0])
+            else:
+                want, wu = (ref.process_float if as_float else ref.process)(chunks[j], caps[j])
+                if frames[j]:
+                    peak[s_] = max(peak[s_], float(np.abs(chunks[j]).max()))
+            tag = "step %d entry %d state %d %s mode %d (%d frames)" % (step, j, s_, cfg[s_], modes[s_], frames[j])
+            if codes[j] != 0 or used[j] != wu or outs[j].shape[0] != want.shape[0]:
+                return "%s: code %d consumed/produced %d/%d, oracle %d/%d" % (tag, codes[j], used[j], outs[j].shape[0], wu, want.shape[0]), what
+            got = outs[j]
+            if got.size == 0:
+                continue
+            if modes[s_] == speexhip.MODE_EXACT:
+                if not np.array_equal(got, want):
+                    return "%s: EXACT differs in %d samples" % (tag, int((got != want).sum())), what
+            elif as_float:
+                scale = max(float(np.abs(want).max()), peak[s_])
+                err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+                if err > 4e-6 * scale * 8 * max(1.0, (ref.taps / 256.0) ** 0.5):
+                    return "%s: float error %.3g at scale %.3g" % (tag, err, scale), what
+            else:
+                d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+                if d.max() > 1:
+                    return "%s: %d LSB" % (tag, d.max()), what
+        for s_ in range(S):
+            if states[s_].position() != refs[s_].position():
+                return "step %d state %d: position %s, oracle %s" % (step, s_, states[s_].position(), refs[s_].position()), what
+        if rng.rand() < 0.2:
+            s_ = int(rng.randint(0, S))
+            q2 = int(rng.randint(0, 11))
+            if states[s_].set_quality(q2) != refs[s_].set_quality(q2):
+                return "set_quality(%d) on state %d: codes differ" % (q2, s_), what
+    for st in states:
+        st.close()
+    return None, what
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
@@ -291,6 +374,7 @@ def main():
     ap.add_argument("--many-channels", action="store_true", help="channel counts up to 100 (shorter calls)")
     ap.add_argument("--only-batch", action="store_true", help="with --only: the seed was a batch trial")
     ap.add_argument("--batch", action="store_true", help="every third trial: many streams through Batch.process_device")
+    ap.add_argument("--many", action="store_true", help="every trial: many single-stream states through the many-states host call")
     args = ap.parse_args()
     orc.build()
     t0 = time.time()
@@ -298,7 +382,9 @@ def main():
     seed = (args.seed * 1000003) % (2 ** 32 - 10 ** 7)  # (trial seeds = seed + n must stay below numpy's 2^32)
     while time.time() - t0 < args.seconds:
         s = args.only if args.only is not None else seed + trials
-        if (args.batch or args.only is not None) and (s % 3 == 0) and (args.batch or args.only_batch):
+        if args.many:
+            err, what = many_trial(s, args.max_frames)
+        elif (args.batch or args.only is not None) and (s % 3 == 0) and (args.batch or args.only_batch):
             err, what = batch_trial(s, args.max_frames)
         else:
             err, what = one_trial(s, args.max_frames if not args.many_channels else min(args.max_frames, 30000), args.many_channels)
