@@ -18,7 +18,8 @@ def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
     build = subprocess.run(
         ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
          "-I" + csrc, "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "san_host.cpp"),
-         os.path.join(csrc, "filter_design.cpp"), os.path.join(csrc, "stream_plan.cpp"), "-o", exe],
+         os.path.join(csrc, "filter_design.cpp"), os.path.join(csrc, "stream_plan.cpp"),
+         os.path.join(csrc, "devices_rule.cpp"), "-o", exe],
         capture_output=True, text=True, timeout=600)
     if build.returncode != 0 and "sanitize" in build.stderr:
         pytest.skip("this g++ has no sanitizer runtime: " + build.stderr[-200:])

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include "devices.h"
 #include "filter_design.h"
 #include "stream_plan.h"
 using namespace speexhip;
@@ -38,6 +39,27 @@ int main() {
     for (uint32_t m = 0; m < 400; m += 37) { Realign g = realign_history(f.taps, f.taps + 8 * (rng() % 40), m); (void)g; g = realign_history(f.taps + 8 * (rng() % 40), f.taps, m); (void)g; }
     uint32_t fr = rng() % f.den; (void)scale_phase(&fr, 1 + rng() % 100000, f.den);
   }
-  printf("sanitizer run ok: %ld filters, %ld plans\n", filters, plans);
+  // the placement rule (devices_rule.cpp) on well-formed, malformed and random environment strings
+  long placements = 0;
+  const char *envs[] = {nullptr, "", "all", "0", "7", "8", "-1", "0,1,2", "0,,1", ",", "3, 1 ,2", "all,1", "99999", "1,99999",
+                        "0,1,2,3,4,5,6,7,0,1,2,3,4,5,6,7,0,1,2,3,4,5,6,7", "x", " ", "1 2", "0x1"};
+  for (int count : {-1, 0, 1, 2, 8, 64})
+    for (const char *one : envs)
+      for (const char *many : envs)
+        for (uint64_t k : {0ull, 1ull, 7ull, 255ull, ~0ull}) {
+          const int d = devices::placement_rule(count, one, many, k, static_cast<int>(k % 9) - 1);
+          if (d < -1 || d >= (count > 0 ? count : 1)) { printf("BAD placement %d of %d\n", d, count); return 1; }
+          placements++;
+        }
+  for (int n = 0; n < 20000; n++) {
+    char buf[24];
+    const int len = rng() % 23;
+    for (int i = 0; i < len; i++) buf[i] = "0123456789, al-x"[rng() % 16];
+    buf[len] = 0;
+    const int d = devices::placement_rule(8, (rng() & 1) ? buf : nullptr, buf, rng(), rng() % 8);
+    if (d < -1 || d >= 8) { printf("BAD placement\n"); return 1; }
+    placements++;
+  }
+  printf("sanitizer run ok: %ld filters, %ld plans, %ld placements\n", filters, plans, placements);
   return 0;
 }
