@@ -312,6 +312,16 @@ class SpeexResamplerBatch {
     if (!Array.isArray(chunks) || chunks.length !== this.streams.length) {
       throw new Error('processChunks expects one chunk (or null) per stream: ' + this.streams.length);
     }
+    // every chunk is checked before any stream's state is touched (lazy init, capacity rule): a step is refused whole
+    if (!speexModule) {
+      throw new Error('You need to wait for SpeexResampler.initPromise before calling this method');
+    }
+    for (let k = 0; k < chunks.length; k++) {
+      if (chunks[k] === null || chunks[k] === undefined) continue;
+      if (chunks[k].length % (this.channels * Uint16Array.BYTES_PER_ELEMENT) !== 0) {
+        throw new Error('Chunk length should be a multiple of channels * 2 bytes');
+      }
+    }
     const picked = { index: [], handles: [], chunks: [], inFrames: [], caps: [] };
     for (let k = 0; k < chunks.length; k++) {
       if (chunks[k] === null || chunks[k] === undefined) continue; // this stream sits the step out

@@ -614,3 +614,62 @@ def test_device_placement_rule():
     for k in range(256):
         counts[P(8, None, "all", k)] += 1
     assert counts == [32] * 8
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_node_batch_class_and_many_call_check_their_arguments_without_a_gpu():
+    """Round 5's JS surface on a box without a GPU: the argument checks of SpeexResamplerBatch and of the addon's
+    processMany, the reference's messages through the batch, the init failure surfacing as Error(strerror) -- and the
+    addon loading in a worker_threads Worker (NAPI_MODULE_INIT), with initPromise resolving behind a warm-up that fails
+    quietly (no GPU is reported by the first real call, like every error of the reference)."""
+    index = os.path.join(ROOT, "node-speex-resampler_amd", "index.js")
+    if not os.path.exists(os.path.join(ROOT, "node-speex-resampler_amd", "speex_hip_napi.node")):
+        pytest.skip("addon not built")
+    js = r"""
+const R = require(process.argv[1]);
+const addon = require(require('path').join(require('path').dirname(process.argv[1]), 'speex_hip_napi.node'));
+const out = {};
+const grab = (k, f) => { try { const v = f(); out[k] = v === undefined ? 'no throw' : v; } catch (e) { out[k] = e.constructor.name + ': ' + e.message; } };
+R.default.initPromise.then(async () => {
+  grab('n0', () => new R.SpeexResamplerBatch(0, 2, 44100, 48000));
+  const b = new R.SpeexResamplerBatch(3, 2, 44100, 48000, 7, { devices: [0] });
+  out.fields = [b.length, b.channels, b.inRate, b.outRate, b.quality, b.streams.length];
+  grab('count', () => b.processChunks([Buffer.alloc(8)]));
+  grab('align', () => b.processChunks([Buffer.alloc(8), Buffer.alloc(7), Buffer.alloc(8)]));
+  grab('nogpu', () => b.processChunks([Buffer.alloc(8), null, Buffer.alloc(8)]));
+  out.asyncNoGpu = await b.processChunksAsync([Buffer.alloc(8), Buffer.alloc(8), Buffer.alloc(8)]).then(() => 'resolved', (e) => e.message);
+  grab('allNull', () => JSON.stringify(b.processChunks([null, null, null])));
+  grab('manyTypes', () => addon.processMany(1, 2, 3, 4));
+  grab('manyHandle', () => addon.processMany([{}], [Buffer.alloc(4)], [1], [2]));
+  grab('manyEmpty', () => addon.processMany([], [], [], []).length);
+  grab('deviceCount', () => typeof R.default.deviceCount());
+  grab('mode', () => new R.default(2, 44100, 48000).setMode('fastest'));
+  const { Worker } = require('worker_threads');
+  out.worker = await new Promise((res) => {
+    const w = new Worker(`
+      const { parentPort, workerData } = require('worker_threads');
+      const R = require(workerData);
+      R.default.initPromise.then(() => {
+        let m; try { new R.default(2, 44100, 48000).processChunk(Buffer.alloc(7)); } catch (e) { m = e.message; }
+        parentPort.postMessage(m);
+      });`, { eval: true, workerData: process.argv[1] });
+    w.on('message', res); w.on('error', (e) => res('worker error: ' + e.message));
+  });
+  console.log(JSON.stringify(out));
+});
+"""
+    res = subprocess.run(["node", "-e", js, index], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    import json
+    out = json.loads(res.stdout)
+    assert out["n0"].endswith("nStreams must be a positive integer")
+    assert out["fields"] == [3, 2, 44100, 48000, 7, 3]
+    assert "one chunk (or null) per stream: 3" in out["count"]
+    assert out["align"] == "Error: Chunk length should be a multiple of channels * 2 bytes"
+    assert out["nogpu"].startswith("Error: HIP device error"), out["nogpu"]     # no CPU fallback, through the batch too
+    assert out["asyncNoGpu"].startswith("HIP device error"), out["asyncNoGpu"]
+    assert out["allNull"] == "[null,null,null]"
+    assert out["manyTypes"].startswith("TypeError") and out["manyHandle"].startswith("TypeError")
+    assert out["manyEmpty"] == 0 and out["deviceCount"] == "number"
+    assert "mode must be" in out["mode"]
+    assert out["worker"] == "Chunk length should be a multiple of channels * 2 bytes"
