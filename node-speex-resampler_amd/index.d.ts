@@ -25,6 +25,15 @@ export interface SpeexResamplerTransformOptions {
     async?: boolean;
     /** at end of stream also emit the filter's tail */
     flushTail?: boolean;
+    /**
+     * Off the event loop AND batched by load: a chunk that arrives while a call is in flight is held, and everything
+     * held leaves as ONE call when that one returns -- an idle stream sends each chunk at once, a busy one a few large
+     * launches.  Same bytes out.  The fastest way through a pipe whose producer runs ahead of the GPU (a file read:
+     * profiles/r05_node_bench.json, `pipe_pipeline_ms`), and the event loop stays free.  `maxHeld` (default 256) bounds
+     * what is held before the producer is made to wait.
+     */
+    pipeline?: boolean;
+    maxHeld?: number;
 }
 
 /**
@@ -67,6 +76,8 @@ declare class SpeexResampler {
 
     /** consecutive chunks in one GPU launch; result[i] equals processChunk(chunks[i]) */
     processChunks(chunks: Buffer[]): Buffer[];
+    /** the same off the event loop */
+    processChunksAsync(chunks: Buffer[]): Promise<Buffer[]>;
     /**
      * processChunk off the event loop; calls on one instance stay in order.  Calls of DIFFERENT instances that become
      * ready in the same tick leave as one native call: one transfer in, one GPU launch per <= 32 instances of equal

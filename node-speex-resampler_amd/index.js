@@ -139,6 +139,26 @@ class SpeexResampler {
     return speexModule.processChunks(this._resamplerPtr, chunks, inFrames, caps);
   }
 
+  /** processChunks off the event loop (one pool-thread call for the whole list); chained with the instance's other async calls. */
+  processChunksAsync(chunks) {
+    const inFrames = [], caps = [];
+    try {
+      for (const chunk of chunks) {
+        const [f, cap] = this._prepare(chunk, Uint16Array.BYTES_PER_ELEMENT);
+        inFrames.push(f);
+        caps.push(cap);
+      }
+    } catch (e) {
+      return Promise.reject(e);
+    }
+    const run = () => speexModule.processChunksAsync(this._resamplerPtr, chunks, inFrames, caps);
+    this._inFlight++;
+    const settle = () => { this._inFlight--; };
+    const p = (this._pending || Promise.resolve()).then(run, run);
+    this._pending = p.then(settle, settle);
+    return p;
+  }
+
   /**
    * processChunk that does not block the event loop: the transfer and the kernels run on a
    * libuv pool thread.  Calls on one instance are chained, so their order (and therefore the
@@ -395,6 +415,9 @@ class SpeexResamplerTransform extends Transform {
    *                         (bytes out unchanged, they just arrive n chunks at a time)
    *   async: true        -- run each call off the event loop (processChunkAsync)
    *   flushTail: true    -- at end of stream also emit SpeexResampler.flush()
+   *   pipeline: true     -- off the event loop AND batched by load: a chunk that arrives while a call is in flight is
+   *                         held, and everything held leaves as ONE call when that one returns (an idle stream sends each
+   *                         chunk at once; a busy one sends few, large launches).  Same bytes out.
    */
   constructor(channels, inRate, outRate, quality = 7, options = undefined) {
     super();
@@ -406,7 +429,24 @@ class SpeexResamplerTransform extends Transform {
     this._alignementBuffer = EMPTY_BUFFER;
     this._options = options || {};
     this._held = [];
-    if (this._options.coalesceChunks > 1 || this._options.flushTail) {
+    if (this._options.pipeline) {
+      this._busy = false;       // a processChunksAsync call is in flight
+      this._waiting = null;     // the end of the stream, parked until the pipeline has drained
+      this._parked = null;      // a _transform callback parked while maxHeld chunks are held
+      this._flush = (callback) => {
+        const finish = () => {
+          try {
+            if (this._options.flushTail) this.push(this.resampler.flush());
+            callback();
+          } catch (e) {
+            callback(e);
+          }
+        };
+        if (!this._busy && this._held.length === 0) finish();
+        else this._waiting = finish;
+        this._pump();
+      };
+    } else if (this._options.coalesceChunks > 1 || this._options.flushTail) {
       // only defined when asked for: the reference has no _flush
       this._flush = (callback) => {
         try {
@@ -420,6 +460,35 @@ class SpeexResamplerTransform extends Transform {
     }
   }
 
+  // pipeline: send what is held as one asynchronous call; when it returns, push its results in order and go again
+  _pump() {
+    if (this._busy || this._held.length === 0) return;
+    const batch = this._held;
+    this._held = [];
+    this._busy = true;
+    if (this._parked) {  // room again: the producer may go on
+      const cb = this._parked;
+      this._parked = null;
+      cb();
+    }
+    this.resampler.processChunksAsync(batch).then((outs) => {
+      for (const out of outs) this.push(out);
+      this._busy = false;
+      if (this._held.length > 0) {
+        this._pump();
+      } else if (this._waiting) {
+        const w = this._waiting;
+        this._waiting = null;
+        w();
+      }
+    }, (e) => {
+      this._busy = false;
+      this._waiting = null;
+      this._parked = null;
+      this.destroy(e);
+    });
+  }
+
   _emitHeld() {
     if (this._held.length === 0) return;
     const held = this._held;
@@ -428,6 +497,20 @@ class SpeexResamplerTransform extends Transform {
   }
 
   _transform(chunk, encoding, callback) {
+    if (this._options.pipeline) {
+      try {
+        // (a copy: the held chunk must not change under us while it waits for its call)
+        this._held.push(Buffer.from(this._align(chunk)));
+      } catch (e) {
+        callback(e);
+        return;
+      }
+      this._pump();
+      // accept the next chunk at once -- unless so much is held already that the producer should wait for the GPU
+      if (this._held.length < (this._options.maxHeld || 256)) callback();
+      else this._parked = callback;
+      return;
+    }
     if (this._options.coalesceChunks > 1 || this._options.async) {
       return this._transformExtended(chunk, callback);
     }

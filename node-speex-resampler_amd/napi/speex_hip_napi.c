@@ -333,6 +333,128 @@ static napi_value ProcessChunks(napi_env env, napi_callback_info info) {
   return result;
 }
 
+/* processChunksAsync(handle, chunks[], inFrames[], outCapacities[]) -> Promise<Buffer[]>: processChunks on a libuv pool
+ * thread (the Transform's `pipeline` option: chunks that arrive while a call is in flight leave together as the next) */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref handle_ref;
+  napi_ref *chunk_refs;
+  Handle *h;
+  uint32_t n, channels;
+  const int16_t **ptrs;
+  uint32_t *in_len, *out_len;
+  int16_t *tmp;
+  int rc;
+  char errmsg[256];
+} ChunksJob;
+
+static void chunks_free(napi_env env, ChunksJob *j) {
+  if (j == NULL) return;
+  if (j->chunk_refs != NULL)
+    for (uint32_t i = 0; i < j->n; i++)
+      if (j->chunk_refs[i] != NULL) napi_delete_reference(env, j->chunk_refs[i]);
+  if (j->handle_ref != NULL) napi_delete_reference(env, j->handle_ref);
+  free(j->chunk_refs);
+  free(j->ptrs);
+  free(j->in_len);
+  free(j->out_len);
+  free(j->tmp);
+  free(j);
+}
+static void chunks_execute(napi_env env, void *data) {
+  (void)env;
+  ChunksJob *j = (ChunksJob *)data;
+  pthread_mutex_lock(&j->h->lock);
+  j->rc = j->h->st == NULL ? SPEEXHIP_ERR_BAD_STATE
+                           : speexhip_resampler_process_chunks_int(j->h->st, j->n, j->ptrs, j->in_len, j->tmp, j->out_len);
+  if (j->rc != 0) snprintf(j->errmsg, sizeof(j->errmsg), "%s", speexhip_resampler_strerror(j->rc));
+  pthread_mutex_unlock(&j->h->lock);
+}
+static void chunks_complete(napi_env env, napi_status status, void *data) {
+  ChunksJob *j = (ChunksJob *)data;
+  napi_value v, result;
+  int ok = status == napi_ok && j->rc == 0 && napi_create_array_with_length(env, j->n, &result) == napi_ok;
+  if (ok) {
+    size_t off = 0;
+    const size_t frame_bytes = (size_t)j->channels * 2;
+    for (uint32_t i = 0; ok && i < j->n; i++) {
+      napi_value buf;
+      void *copied = NULL;
+      ok = napi_create_buffer_copy(env, (size_t)j->out_len[i] * frame_bytes, (char *)j->tmp + off, &copied, &buf) == napi_ok &&
+           napi_set_element(env, result, i, buf) == napi_ok;
+      off += (size_t)j->out_len[i] * frame_bytes;
+    }
+  }
+  if (ok) {
+    napi_resolve_deferred(env, j->deferred, result);
+  } else {
+    napi_value msg;
+    napi_create_string_utf8(env, j->rc != 0 ? j->errmsg : "speexhip: asynchronous call failed", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &v);
+    napi_reject_deferred(env, j->deferred, v);
+  }
+  napi_delete_async_work(env, j->work);
+  chunks_free(env, j);
+}
+static napi_value ProcessChunksAsync(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  uint32_t n = 0;
+  NAPI_OK(napi_get_array_length(env, argv[1], &n));
+  Handle *h = NULL;
+  SpeexHipResamplerState *st = lock_state(env, argv[0], &h);
+  if (st == NULL) return NULL;
+  SpeexHipInfo si;
+  speexhip_resampler_get_info(st, &si); /* only the channel count is used: it never changes */
+  UNLOCK(h);
+  const size_t frame_bytes = (size_t)si.nb_channels * 2, m = n ? n : 1;
+  ChunksJob *j = (ChunksJob *)calloc(1, sizeof(ChunksJob));
+  const char *fail = NULL;
+  if (j != NULL) {
+    j->n = n;
+    j->h = h;
+    j->channels = si.nb_channels;
+    j->chunk_refs = (napi_ref *)calloc(m, sizeof(napi_ref));
+    j->ptrs = (const int16_t **)calloc(m, sizeof(*j->ptrs));
+    j->in_len = (uint32_t *)calloc(m, sizeof(uint32_t));
+    j->out_len = (uint32_t *)calloc(m, sizeof(uint32_t));
+  }
+  if (j == NULL || !j->chunk_refs || !j->ptrs || !j->in_len || !j->out_len) fail = speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED);
+  size_t total_cap = 0;
+  for (uint32_t i = 0; fail == NULL && i < n; i++) {
+    napi_value c, a, b;
+    void *data = NULL;
+    size_t bytes = 0;
+    if (napi_get_element(env, argv[1], i, &c) != napi_ok || napi_get_element(env, argv[2], i, &a) != napi_ok ||
+        napi_get_element(env, argv[3], i, &b) != napi_ok || !buffer_or_null(env, c, &data, &bytes) ||
+        napi_get_value_uint32(env, a, &j->in_len[i]) != napi_ok || napi_get_value_uint32(env, b, &j->out_len[i]) != napi_ok) {
+      fail = "processChunksAsync expects (handle, Buffer[], number[], number[])";
+    } else if (data != NULL && (size_t)j->in_len[i] * frame_bytes > bytes) {
+      fail = "input frame count exceeds the chunk";
+    } else if (data != NULL && napi_create_reference(env, c, 1, &j->chunk_refs[i]) != napi_ok) { /* keep the bytes alive */
+      fail = "speexhip N-API failure: napi_create_reference";
+    }
+    j->ptrs[i] = (const int16_t *)data;
+    total_cap += j->out_len[i];
+  }
+  napi_value promise = NULL, name;
+  if (fail == NULL && (j->tmp = (int16_t *)malloc(total_cap * frame_bytes + 2)) == NULL) fail = speexhip_resampler_strerror(SPEEXHIP_ERR_ALLOC_FAILED);
+  if (fail == NULL &&
+      (napi_create_reference(env, argv[0], 1, &j->handle_ref) != napi_ok || napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+       napi_create_string_utf8(env, "speexhip.processChunksAsync", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+       napi_create_async_work(env, NULL, name, chunks_execute, chunks_complete, j, &j->work) != napi_ok ||
+       napi_queue_async_work(env, j->work) != napi_ok))
+    fail = "speexhip N-API failure: queueing processChunksAsync";
+  if (fail != NULL) {
+    chunks_free(env, j);
+    napi_throw_error(env, NULL, fail);
+    return NULL;
+  }
+  return promise;
+}
+
 /* processAsync(handle, chunk, inFrames, outCapacityFrames) -> Promise<Buffer>: the same call on
  * a libuv pool thread, so H2D + kernels + D2H do not block the event loop.  The caller
  * (index.js) chains the promises of one instance, so calls on one state stay in order. */
@@ -908,6 +1030,7 @@ NAPI_MODULE_INIT() {
       {"processFloat", NULL, ProcessFloat, NULL, NULL, NULL, napi_default, NULL},
       {"processChunks", NULL, ProcessChunks, NULL, NULL, NULL, napi_default, NULL},
       {"processAsync", NULL, ProcessAsync, NULL, NULL, NULL, napi_default, NULL},
+      {"processChunksAsync", NULL, ProcessChunksAsync, NULL, NULL, NULL, napi_default, NULL},
       {"setRate", NULL, SetRate, NULL, NULL, NULL, napi_default, NULL},
       {"setQuality", NULL, SetQuality, NULL, NULL, NULL, napi_default, NULL},
       {"skipZeros", NULL, SkipZeros, NULL, NULL, NULL, napi_default, NULL},

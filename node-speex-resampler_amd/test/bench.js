@@ -56,6 +56,7 @@ async function pipeOnce(t, data, options) {
       await pipeOnce(t, data, undefined);
       await pipeOnce(t, data, { async: true });
       await pipeOnce(t, data, { coalesceChunks: 8 });
+      await pipeOnce(t, data, { pipeline: true });
     }
   }
   for (const t of tuples) {
@@ -88,7 +89,7 @@ async function pipeOnce(t, data, options) {
       if (r.destroy) r.destroy();
     }
     for (const [name, options] of [['pipe_ms', undefined], ['pipe_coalesce8_ms', { coalesceChunks: 8 }],
-      ['pipe_async_ms', { async: true }]]) {
+      ['pipe_async_ms', { async: true }], ['pipe_pipeline_ms', { pipeline: true }]]) {
       const ts = [];
       for (let rep = 0; rep < 7; rep++) ts.push((await pipeOnce(t, data, options))[0]);
       row[name] = +median(ts.slice(1)).toFixed(3);

@@ -137,6 +137,10 @@ async function extensionsTest() {
     const want = chunks.map((ch) => a.processChunk(ch));
     const got = b.processChunks(chunks);
     const promised = await Promise.all(chunks.map((ch) => c.processChunkAsync(ch))); // queued at once
+    const d = mk(mode);
+    const listed = (await Promise.all([d.processChunksAsync(chunks.slice(0, 4)), d.processChunksAsync(chunks.slice(4))]))
+      .reduce((x, y) => x.concat(y), []);
+    for (let i = 0; i < want.length; i++) assert(listed[i].equals(want[i]), `processChunksAsync: chunk ${i} differs (mode ${mode})`);
     assert(got.length === want.length, 'processChunks: count');
     for (let i = 0; i < want.length; i++) {
       assert(got[i].equals(want[i]), `processChunks: chunk ${i} differs (mode ${mode})`);
@@ -210,7 +214,13 @@ async function extensionsTest() {
   const [plain] = await pipe(undefined);
   const [coalesced] = await pipe({ coalesceChunks: 8 });
   const [asynced] = await pipe({ async: true });
+  const [piped] = await pipe({ pipeline: true });
+  const [pipedTight] = await pipe({ pipeline: true, maxHeld: 2 });
+  const [pipedTail] = await pipe({ pipeline: true, flushTail: true });
+  assert(piped.equals(plain), 'Transform pipeline changed the bytes');
+  assert(pipedTight.equals(plain), 'Transform pipeline (maxHeld 2) changed the bytes');
   const [tailed, tt] = await pipe({ coalesceChunks: 5, flushTail: true });
+  assert(pipedTail.equals(tailed), 'Transform pipeline + flushTail differs from coalesce + flushTail');
   assert(coalesced.equals(plain), 'Transform coalesceChunks changed the bytes');
   assert(asynced.equals(plain), 'Transform async changed the bytes');
   assert(tailed.slice(0, plain.length).equals(plain), 'Transform flushTail changed the stream');
