@@ -200,35 +200,15 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
     const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
     const float *rows_s = reinterpret_cast<const float *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
                                                           static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
-    // Round 5 (VERDICT r4 #3a): a padded window whose group crosses at most ONE period boundary -- BASELINE configs[3]:
-    // rows of 26 trips, boundaries 40 trips apart -- runs the UNPADDED loop on either side of it (the window address
-    // steps over the padding between the two runs) instead of counting down to the boundary in every trip: four scalar
-    // instructions less per trip (s_sub / s_cmp / 2 x s_cselect), at the price of one drained and refilled bank at the
-    // boundary.  SPEEXHIP_SKIP bit 256 keeps the counting loop (A/B).  8-channel frames only so far.
-    if constexpr (PADDED && CF == 8 && R == 10) {
-      using Flat = FirLoopAsm<R, CT, CF, false, false>;
-      static_assert(Flat::available, "the unpadded loop of the layout");
-      const uint32_t total = trips >> 8, main_end = total - tail;
-      const uint32_t w = p.delta[p.groups + g];  // trips in front of the first boundary (~0u: none)
-      if (!(p.skip & 256u) && (w >= total || total - w <= p.wrap_step)) {
-        auto run = [&](uint32_t t0, uint32_t t1, uint32_t at) {  // trips [t0, t1) from window address `at`
-          auto overlap = [&](uint32_t lo, uint32_t hi) {
-            const uint32_t a = max(t0, lo), b = min(t1, hi);
-            return b > a ? b - a : 0u;
-          };
-          Flat::run(acc, rows_s + static_cast<size_t>(t0) * (2 * bank_taps(R)), at, 0u, sgpr(overlap(0, head)),
-                    sgpr(overlap(head, main_end)), sgpr(overlap(main_end, total)), 0u, 0u, 0u);
-        };
-        if (w >= total) {
-          run(0, total, addr);
-        } else {
-          const uint32_t ws = sgpr(w);
-          run(0, ws, addr);
-          run(ws, total, addr + (ws * kStepsPerTrip * CF + p.pad) * 4u);
-        }
-        return;
-      }
-    }
+    // (Round 5, VERDICT r4 #3a, measured and not kept: a padded window whose group crosses ONE period boundary --
+    //  BASELINE configs[3]: rows of 26 trips, boundaries 40 trips apart -- run as the UNPADDED loop on either side of it,
+    //  the window address stepped over the padding between the two runs, instead of counting down to the boundary in
+    //  every trip: four scalar instructions less per trip, one drained and refilled bank per group.  Same box, same
+    //  library, three repetitions each: cfg4 x 32 573.8 / 573.8 / 574.0 us split against 574.7 / 573.9 / 575.8 counting,
+    //  one stream 25.08 / 24.96 / 25.18 against 25.10 / 24.95 / 24.86, 8 channels 32k->44.1k 375.8 / 377.0 / 374.5 against
+    //  381.1 / 375.4 / 376.2, 48k->11.025k 273.2 / 273.6 / 273.6 against 273.7 / 274.0 / 273.9: profiles/r05_ab_split.txt.
+    //  The scalar unit is 39 % busy in this launch (90 M scalar instructions on 231 M CU cycles) and its instructions
+    //  issue beside other waves' FMAs: they were never what the loop waits for.)
     Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 4u : 0u, sgpr(head), sgpr((trips >> 8) - head - tail),
              sgpr(tail), sgpr(PADDED ? p.delta[p.groups + g] : 0u), sgpr(p.wrap_step),
              sgpr((kStepsPerTrip * CF + p.pad) * 4u));
