@@ -12,8 +12,8 @@ import { Transform, TransformCallback } from 'stream';
 export interface SpeexResamplerTransformOptions {
     /**
      * Hold up to n chunks and resample them in one GPU launch (same bytes out).  Trades LATENCY -- the first
-     * output waits for n chunks -- for fewer launches: up to 25 % less time per file at n = 8 on five of the
-     * seven test tuples, none or a loss (mono 24k -> 48k: 1.04 vs 0.76 ms) where a chunk already fills a launch.
+     * output waits for n chunks -- for fewer launches: 20-55 % less time per file at n = 8 on five of the seven test
+     * tuples (round 5: the held run stays on pinned memory), a loss on mono 24k -> 48k and stereo 24k -> 48k q10.
      */
     coalesceChunks?: number;
     /**
@@ -28,9 +28,9 @@ export interface SpeexResamplerTransformOptions {
     /**
      * Off the event loop AND batched by load: a chunk that arrives while a call is in flight is held, and everything
      * held leaves as ONE call when that one returns -- an idle stream sends each chunk at once, a busy one a few large
-     * launches.  Same bytes out.  The fastest way through a pipe whose producer runs ahead of the GPU (a file read:
-     * profiles/r05_node_bench.json, `pipe_pipeline_ms`), and the event loop stays free.  `maxHeld` (default 256) bounds
-     * what is held before the producer is made to wait.
+     * launches.  Same bytes out.  What `async` is for -- an event loop that stays free -- at about the plain pipe's
+     * speed instead of 1.5-4x its time (profiles/r05_node_bench.json: 0.63-0.90 ms per 1.7 MB file, plain pipe
+     * 0.47-1.08, `async` 0.83-3.6).  `maxHeld` (default 256) bounds what is held before the producer is made to wait.
      */
     pipeline?: boolean;
     maxHeld?: number;
