@@ -1566,6 +1566,7 @@ int warm_device(int device) {
   warm_unit_period64(s);
   warm_unit_slide64_i16(s);
   warm_unit_period_pp(s);
+  warm_unit_period_odd(s);
   warm_unit_slide_f32(s);
   warm_unit_slide64_f32(s);
   HIP_TRY(hipStreamSynchronize(s));

@@ -6,6 +6,9 @@ namespace speexhip {
 // the fp64-accumulate instances (kernels_period64.hip): launch the one of plan `t`'s layout
 hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                              dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
+// the instances for frames of five and seven channels (kernels_period_odd.hip)
+hipError_t dispatch_period_odd(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
+                               dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
 // the phase-pair instances for mono (kernels_period_pp.hip)
 hipError_t dispatch_period_pp(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                               dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
@@ -198,7 +201,9 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   t.usable = f.den >= 7 && t.cgroups <= 64 && min_fill * t.lane_periods >= full && t.window_bytes <= lds_budget;
   // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py); so are the
   // tap rows of an fp64 accumulator
-  if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1))) t.usable = false;
+  // (round 5: frames of 5 and 7 single channels have an fp32 ISA loop too -- int16 window yes, fp64 rows no)
+  const bool odd_frame = t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7) && !a64;
+  if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1) || odd_frame)) t.usable = false;
   if (a64 && w16) t.usable = false;
   if (t.pp && t.pad != 0 && t.r != 10) t.usable = false;
   return t;
@@ -595,7 +600,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   const bool isa_layout = false;  // (the A/B library without the ISA loop has no tap-range shares either)
 #else
-  const bool isa_layout = t.pp || (t.ct == 1 && t.cgroups == 1) || (t.ct == 2 && t.cgroups <= 4);
+  const bool isa_layout = t.pp || (t.ct == 1 && (t.cgroups == 1 || t.cgroups == 5 || t.cgroups == 7)) || (t.ct == 2 && t.cgroups <= 4);
 #endif
   // (Round 4, late: an UNSPLIT launch whose workgroups have at most 8 waves takes the shares too.  The FIR loop waits
   //  ~500 cycles for every bank of taps -- a scalar load that misses to L2 -- and only other waves cover that: stamps of
@@ -652,6 +657,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   if (t.w16 && float_io) return hipErrorInvalidValue;
   if (t.a64) return dispatch_period64(t, p, pack, grid, threads, float_io, stream);  // kernels_period64.hip
   if (t.pp) return dispatch_period_pp(t, p, pack, grid, threads, float_io, stream);   // kernels_period_pp.hip
+  if (t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7)) return dispatch_period_odd(t, p, pack, grid, threads, float_io, stream);
   // (LRC: the kernel of the layout, or its tap-range-shares twin)
 #define SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, W)                                                                                    \
   (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, true>(p, pack, grid, threads, t.window_bytes, stream)              \

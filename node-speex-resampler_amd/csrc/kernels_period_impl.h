@@ -131,7 +131,7 @@ __device__ __forceinline__ LaneCtx lane_ctx(const PeriodParams &p, uint32_t xshi
                                             uint32_t m_cnt, uint32_t lane) {
   // ONE_GROUP: the frame is exactly one channel group (mono, stereo): the sample stride is a
   // compile-time constant and the LDS reads of an iteration share one address register.
-  // CGF != 0: a frame of CGF channel groups (4, 6, 8 channels as 2, 3, 4 pairs) known at compile time:
+  // CGF != 0: a frame of CGF channel groups (4, 6, 8 channels as 2, 3, 4 pairs; round 5: 5 and 7 single channels) known at compile time:
   // the same for the common multi-channel layouts -- the FIR loop of 8 channels spent 4 vector adds per
   // 40 FMAs on LDS addresses with the stride in a register.
   constexpr uint32_t kGroups = ONE_GROUP ? 1u : static_cast<uint32_t>(CGF);
@@ -798,7 +798,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
   // (layouts that run the C++ loop keep the copies the kernel already holds: re-reading them there only added
   //  register pressure -- scratch in every such instance)
 #ifndef SPEEXHIP_CXX_FIR_LOOP
-  constexpr bool kReload = AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available;
+  constexpr bool kReload = AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : CT * CGF, PADDED, W16>::available;
 #else
   constexpr bool kReload = AM != 0;
 #endif
@@ -830,12 +830,12 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
       double acc64[R][2];
 #pragma unroll
       for (int i = 0; i < R; i++) acc64[i][0] = acc64[i][1] = 0.0;
-      fir_group64<R, CT, PADDED, ONE_GROUP ? CT : 2 * CGF>(p, reinterpret_cast<const double *>(rows), xs, c, g, (p.skip & 4u) != 0,
+      fir_group64<R, CT, PADDED, ONE_GROUP ? CT : CT * CGF>(p, reinterpret_cast<const double *>(rows), xs, c, g, (p.skip & 4u) != 0,
                                                            0u, 1u, acc64);
 #pragma unroll
       for (int i = 0; i < R; i++) acc[i] = f32x2{static_cast<float>(acc64[i][0]), static_cast<float>(acc64[i][1])};
     } else {
-      fir_group<R, CT, PADDED, ONE_GROUP ? CT : 2 * CGF, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+      fir_group<R, CT, PADDED, ONE_GROUP ? CT : CT * CGF, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
     }
 #ifdef SPEEXHIP_STAMPS
     {
@@ -940,7 +940,7 @@ template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, b
 __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restrict__ rows, KDesc dp, float *xs,
                                                uint32_t xshift, uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane,
                                                uint32_t zsplit) {
-  constexpr int CF = ONE_GROUP ? CT : 2 * CGF;
+  constexpr int CF = ONE_GROUP ? CT : CT * CGF;
   LaneCtx c;
   uint32_t g, part, gw, wg, parts;
   bool valid;
@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
 template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0>
 __device__ __forceinline__ void fir_tile_parts64(KParams pp, const double *__restrict__ rows, KDesc dp, float *xs, uint32_t xshift,
                                                  uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit) {
-  constexpr int CF = ONE_GROUP ? CT : 2 * CGF;
+  constexpr int CF = ONE_GROUP ? CT : CT * CGF;
   LaneCtx c;
   uint32_t g, part, gw, wg, parts;
   bool valid;
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
     // the ones that run the C++ loop the statement alone -- never executed -- cost 20 VGPRs and 130-230 bytes of
     // scratch, three channels 44.1k->48k 64 -> 754 us; tests/test_gpu_perf_gate.py caught it.
 #ifndef SPEEXHIP_CXX_FIR_LOOP
-    if constexpr (AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available) touch_rows<R>(p, rows, row_sink);
+    if constexpr (AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : CT * CGF, PADDED, W16>::available) touch_rows<R>(p, rows, row_sink);
 #endif
     // (the loads of touch_rows land in row_sink: nothing reads it, the register stays reserved until they have)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1219,7 +1219,7 @@ hipError_t launch_rc(const PeriodParams &p, const DescPack *pack, dim3 grid, uin
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   constexpr bool kParts = false;
 #else
-  constexpr bool kParts = KS && (AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : 2 * CGF, PADDED, W16>::available);
+  constexpr bool kParts = KS && (AM != 0 || FirLoopAsm<R, CT, ONE_GROUP ? CT : CT * CGF, PADDED, W16>::available);
 #endif
   if constexpr (KS && !kParts) {  // (no ISA loop for this layout: the host never asks for tap-range shares of it)
     return hipErrorInvalidValue;
