@@ -600,7 +600,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   const bool isa_layout = false;  // (the A/B library without the ISA loop has no tap-range shares either)
 #else
-  const bool isa_layout = t.pp || (t.ct == 1 && (t.cgroups == 1 || t.cgroups == 5 || t.cgroups == 7)) || (t.ct == 2 && t.cgroups <= 4);
+  const bool isa_layout = t.pp || (t.ct == 1 && (t.cgroups == 1 || t.cgroups == 3 || t.cgroups == 5 || t.cgroups == 7)) || (t.ct == 2 && t.cgroups <= 4);
 #endif
   // (Round 4, late: an UNSPLIT launch whose workgroups have at most 8 waves takes the shares too.  The FIR loop waits
   //  ~500 cycles for every bank of taps -- a scalar load that misses to L2 -- and only other waves cover that: stamps of
@@ -657,7 +657,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   if (t.w16 && float_io) return hipErrorInvalidValue;
   if (t.a64) return dispatch_period64(t, p, pack, grid, threads, float_io, stream);  // kernels_period64.hip
   if (t.pp) return dispatch_period_pp(t, p, pack, grid, threads, float_io, stream);   // kernels_period_pp.hip
-  if (t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7)) return dispatch_period_odd(t, p, pack, grid, threads, float_io, stream);
+  if (t.ct == 1 && (t.cgroups == 3 || t.cgroups == 5 || t.cgroups == 7)) return dispatch_period_odd(t, p, pack, grid, threads, float_io, stream);
   // (LRC: the kernel of the layout, or its tap-range-shares twin)
 #define SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, W)                                                                                    \
   (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, true>(p, pack, grid, threads, t.window_bytes, stream)              \
