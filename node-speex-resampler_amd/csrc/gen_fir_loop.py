@@ -467,7 +467,7 @@ def variants_pp():
 
 def variants64():
     out = []
-    for CT, CF in ((2, 2), (2, 4), (2, 6), (2, 8), (1, 1)):
+    for CT, CF in ((2, 2), (2, 4), (2, 6), (2, 8), (1, 1), (1, 3), (1, 5), (1, 7)):   # (round 5: odd frames too)
         for padded in (False, True):
             out.append(Variant64(10, 1, CT, CF, padded))
         out.append(Variant64(5, R5_STEPS // 2, CT, CF, False))

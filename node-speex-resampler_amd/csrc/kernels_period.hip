@@ -201,8 +201,9 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   t.usable = f.den >= 7 && t.cgroups <= 64 && min_fill * t.lane_periods >= full && t.window_bytes <= lds_budget;
   // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py); so are the
   // tap rows of an fp64 accumulator
-  // (round 5: frames of 5 and 7 single channels have an fp32 ISA loop too -- int16 window yes, fp64 rows no)
-  const bool odd_frame = t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7) && !a64;
+  // (round 5: frames of 5 and 7 single channels have ISA loops too -- int16 window (kernels_period_odd.hip)
+  //  and fp64 rows (kernels_period64.hip); three channels the fp64 rows, their int16 window stays with their phase pairs)
+  const bool odd_frame = t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7 || (t.cgroups == 3 && a64));
   if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1) || odd_frame)) t.usable = false;
   if (a64 && w16) t.usable = false;
   if (t.pp && t.pad != 0 && t.r != 10) t.usable = false;

@@ -4,7 +4,7 @@
 // window, same launch shapes (kernels_period.hip plans them); the FIR loop is FirLoopAsm64 (csrc/gen_fir_loop.py):
 // taps as doubles in SGPR pairs, samples widened behind the LDS read, v_fma_f64 -- exact products, fp64 sums, i.e.
 // wider than the reference's fp64 sums of fp32-rounded products, where the fp32 FMA chain was narrower.  Layouts:
-// mono, stereo, 4 / 6 / 8 channels (the ISA loop's); others keep the fp32 chain.
+// mono, stereo, 4 / 6 / 8 channels and (round 5) 3 / 5 / 7 channels -- the ISA loop's; others keep the fp32 chain.
 #ifdef SPEEXHIP_STAMPS
 #undef SPEEXHIP_STAMPS  // (the diagnostics stamps belong to the fp32 translation unit)
 #endif
@@ -21,12 +21,24 @@ hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const D
   return float_io ? SPEEXHIP_P64_T(RV, CTV, ONE, PADV, float, CGV) : SPEEXHIP_P64_T(RV, CTV, ONE, PADV, int16_t, CGV)
   const bool padded = t.pad != 0;
   if (!t.a64 || t.w16 || (padded && t.r != 10)) return hipErrorInvalidValue;
-  if (t.ct == 1) {
-    if (t.cgroups != 1) return hipErrorInvalidValue;
+  if (t.ct == 1 && t.cgroups == 1) {
     if (t.r == 5) SPEEXHIP_P64(5, 1, true, false, 0);
     if (!padded) SPEEXHIP_P64(10, 1, true, false, 0);
     SPEEXHIP_P64(10, 1, true, true, 0);
   }
+  // frames of three, five, seven channels on single-channel lanes (round 5: until then quality 9 / 10 on those layouts
+  // kept the fp32 chain)
+#define SPEEXHIP_P64_ODD(CGV)                         \
+  if (t.ct == 1 && t.cgroups == CGV) {                \
+    if (t.r == 5) SPEEXHIP_P64(5, 1, false, false, CGV);  \
+    if (!padded) SPEEXHIP_P64(10, 1, false, false, CGV);  \
+    SPEEXHIP_P64(10, 1, false, true, CGV);                \
+  }
+  SPEEXHIP_P64_ODD(3)
+  SPEEXHIP_P64_ODD(5)
+  SPEEXHIP_P64_ODD(7)
+#undef SPEEXHIP_P64_ODD
+  if (t.ct == 1) return hipErrorInvalidValue;
   if (t.cgroups == 1) {
     if (t.r == 5) SPEEXHIP_P64(5, 2, true, false, 0);
     if (!padded) SPEEXHIP_P64(10, 2, true, false, 0);

@@ -1557,13 +1557,16 @@ def test_fp64_accumulate_period_kernel_on_every_layout():
     ratios with den >= 7 -- mono (two periods per lane), stereo, 4 / 6 / 8 channels, plain and padded windows, the
     r = 5 plan of one-generation launches and the r = 10 plan of batches -- against the oracle over multi-call
     streams with int16 and float calls mixed: +-1 LSB, counters, position and history equal.  Layouts without an
-    ISA loop (3 channels) keep the fp32 chain and say so."""
+    ISA loop (9 channels and more) keep the fp32 chain and say so."""
     import torch
     worst = 0.0
     cases = [(1, 44100, 48000, 10), (2, 44100, 48000, 10), (2, 44100, 48000, 9), (2, 48000, 44100, 10),
              (1, 48000, 44100, 9), (4, 44100, 48000, 10), (6, 48000, 44100, 9), (8, 48000, 44100, 10),
              (8, 44100, 48000, 9), (2, 48000, 11025, 10), (1, 44100, 8000, 9), (2, 44100, 8000, 10),
-             (2, 32000, 44100, 10), (1, 22050, 16000, 9), (2, 88200, 48000, 10), (2, 16000, 44100, 9)]
+             (2, 32000, 44100, 10), (1, 22050, 16000, 9), (2, 88200, 48000, 10), (2, 16000, 44100, 9),
+             # round 5: frames of three, five and seven channels (single-channel lanes, FirLoopAsm64<R, 1, 3 | 5 | 7>)
+             (3, 44100, 48000, 10), (3, 48000, 44100, 9), (5, 44100, 48000, 9), (5, 48000, 11025, 10),
+             (7, 48000, 44100, 10), (7, 44100, 8000, 9), (3, 44100, 8000, 10)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -1606,8 +1609,8 @@ def test_fp64_accumulate_period_kernel_on_every_layout():
         assert used[s] == wu and made[s] == want.shape[0]
         assert_close(out[s, : made[s]], want, "period64 batch stream %d" % s, rate=2e-3)
     b.close()
-    # no ISA loop for 3 channels: the fp32 chain, reported as such
-    r = speexhip.Resampler(3, 44100, 48000, 10)
+    # no ISA loop for 9 channels: the fp32 chain, reported as such
+    r = speexhip.Resampler(9, 44100, 48000, 10)
     assert r.info()["fast_path"] == 2 and r.info()["accumulate_bits"] == 32
     r.close()
 
