@@ -372,7 +372,6 @@ class SpeexResamplerBatch {
   processChunksAsync(chunks) {
     let g;
     try {
-      for (const r of this.streams) r._refuseWhileAsyncPending('SpeexResamplerBatch.processChunksAsync');
       g = this._gather(chunks);
     } catch (e) {
       return Promise.reject(e);
@@ -384,8 +383,12 @@ class SpeexResamplerBatch {
         g.index.forEach((k, i) => { result[k] = outs[i]; });
         return result;
       });
+    // (while the step is pending the synchronous methods of its streams refuse, like after processChunkAsync: the
+    //  results were sized from the streams' counters when the step was queued)
+    for (const k of g.index) this.streams[k]._inFlight++;
+    const settle = () => { for (const k of g.index) this.streams[k]._inFlight--; };
     const p = (this._pending || Promise.resolve()).then(run, run);
-    this._pending = p.then(() => undefined, () => undefined);
+    this._pending = p.then(settle, settle);
     return p;
   }
 
