@@ -65,6 +65,13 @@ WORKLOADS = [
     ("big_3ch_48k_11k", (3, 48000, 11025, 7), 32, 1 << 20, "fast", "int16"),
     ("big_2ch_48k_11k", (2, 48000, 11025, 7), 32, 1 << 20, "fast", "int16"),
     ("big_3ch_44k_16k", (3, 44100, 16000, 7), 32, 1 << 20, "fast", "int16"),
+    # round 5: frames of five / seven / three channels on their ISA loops, the wide window that left the exact kernel
+    ("sw_5ch_48k_11k", (5, 48000, 11025, 7), 32, 131072, "fast", "int16"),
+    ("sw_7ch_48k_11k", (7, 48000, 11025, 7), 32, 131072, "fast", "int16"),
+    ("sw_7ch_44k_48k", (7, 44100, 48000, 7), 32, 131072, "fast", "int16"),
+    ("big_3ch_44k_48k", (3, 44100, 48000, 7), 32, 1 << 20, "fast", "int16"),
+    ("sw_1ch_96k_11k", (1, 96000, 11025, 7), 32, 131072, "fast", "int16"),
+    ("q10_5ch_44k48k_s32", (5, 44100, 48000, 10), 32, 262144, "fast", "int16"),
     # launches of one generation with their own plans (tap-range shares, r = 5 shares)
     ("one_48k_11k_2ch", (2, 48000, 11025, 7), 1, 441000, "fast", "int16"),
     ("one_48k_8k_2ch", (2, 48000, 8000, 7), 1, 441000, "fast", "int16"),
