@@ -453,6 +453,39 @@ async function batchTest() {
     fused.concat(apart).forEach((r) => r.destroy());
     void before;
   }
+  // the coalescer under load: 120 instances of four filters, five ticks of ragged chunks each queued at once (a second
+  // call per instance behind the first in some ticks) against the same streams through synchronous separate calls
+  {
+    const kinds = [[2, 44100, 48000, 7], [1, 48000, 16000, 5], [2, 48000, 44100, 10], [4, 44100, 48000, 3]];
+    const mk = () => {
+      const v = [];
+      for (let n = 0; n < 120; n++) {
+        const a = kinds[n % kinds.length];
+        const r = new SpeexResampler(a[0], a[1], a[2], a[3]);
+        r.setMode('exact');
+        v.push(r);
+      }
+      return v;
+    };
+    const fused = mk(), apart = mk();
+    for (let tick = 0; tick < 5; tick++) {
+      const jobs = [], want = [];
+      fused.forEach((r, n) => {
+        const frames = [480, 160, 4096, 1, 960][(n + tick) % 5] + n;
+        const a = lcg(frames, r.channels, 7000 * tick + n);
+        jobs.push(r.processChunkAsync(a));
+        want.push(apart[n].processChunk(a));
+        if ((n + tick) % 7 === 0) {
+          const b = lcg(160, r.channels, 9000 * tick + n);
+          jobs.push(r.processChunkAsync(b));
+          want.push(apart[n].processChunk(b));
+        }
+      });
+      const got = await Promise.all(jobs);
+      got.forEach((g, k) => assert(g.equals(want[k]), `coalescer under load: tick ${tick} job ${k} differs`));
+    }
+    fused.concat(apart).forEach((r) => r.destroy());
+  }
   // misuse through the addon itself: a state twice in one call, a destroyed state, lengths that do not fit
   {
     const r = new SpeexResampler(2, 44100, 48000, 7);

@@ -2045,3 +2045,55 @@ def test_large_many_states_call_runs_pipelined_and_matches():
         res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                               "large_many_states_call"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_many_states_calls_from_several_threads_at_once():
+    """The library is thread-safe per state: two threads drive disjoint sets of states through many-states calls (the
+    per-device stage serialises them), a third makes single-state calls on states of its own, all at once (ctypes
+    releases the GIL inside the C calls) -- every state's bytes are the oracle's (EXACT), whatever the interleaving."""
+    import threading
+    ch, i, o, q = 2, 44100, 48000, 7
+    sets = [[speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT) for _ in range(9)] for _ in range(3)]
+    steps = [2000, 160, 70000, 5, 16384, 160, 300000, 1000]
+    got = [[[] for _ in s] for s in sets]
+    errors = []
+
+    def many(t):
+        try:
+            for step, f in enumerate(steps):
+                chunks = [orc.lcg_pcm((f + k) * ch, 1000 * t + 10 * step + k).reshape(f + k, ch) for k in range(9)]
+                outs, used, codes = speexhip.process_many(sets[t], chunks, [(f + k) * o // i + 64 for k in range(9)])
+                assert codes == [0] * 9 and used == [f + k for k in range(9)]
+                for k in range(9):
+                    got[t][k].append(outs[k])
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    def single(t):
+        try:
+            for step, f in enumerate(steps):
+                for k in range(9):
+                    x = orc.lcg_pcm((f + k) * ch, 1000 * t + 10 * step + k).reshape(f + k, ch)
+                    out, used = sets[t][k].process(x, (f + k) * o // i + 64)
+                    assert used == f + k
+                    got[t][k].append(out)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=many, args=(0,)), threading.Thread(target=many, args=(1,)),
+               threading.Thread(target=single, args=(2,))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(3):
+        for k in (0, 4, 8):
+            ref = orc.Oracle(ch, i, o, q)
+            for step, f in enumerate(steps):
+                x = orc.lcg_pcm((f + k) * ch, 1000 * t + 10 * step + k).reshape(f + k, ch)
+                want, _ = ref.process(x, (f + k) * o // i + 64)
+                assert np.array_equal(got[t][k][step], want), (t, k, step)
+    for s in sets:
+        for r in s:
+            r.close()
