@@ -1606,11 +1606,12 @@ struct ManyStage {
   size_t d_in_cap = 0, d_out_cap = 0, h_in_cap = 0, h_out_cap = 0;
   uint32_t seq = 0;
 };
-ManyStage &many_stage(int device) {
+// (device, lane): a large call on one device runs as two halves side by side, each on a stage of its own (below)
+ManyStage &many_stage(int device, int lane) {
   static std::mutex mu;
-  static std::map<int, ManyStage *> *all = new std::map<int, ManyStage *>();  // never destroyed, like the pool
+  static std::map<std::pair<int, int>, ManyStage *> *all = new std::map<std::pair<int, int>, ManyStage *>();  // never destroyed, like the pool
   std::lock_guard<std::mutex> lock(mu);
-  ManyStage *&m = (*all)[device];
+  ManyStage *&m = (*all)[std::make_pair(device, lane)];
   if (m == nullptr) m = new ManyStage();
   return *m;
 }
@@ -1634,9 +1635,9 @@ inline size_t align64(size_t v) { return (v + 63) & ~static_cast<size_t>(63); }
 }  // namespace
 
 // The fused states of ONE device: idx = their positions in the caller's arrays.
-int Batch::many_on_device(int device, const std::vector<uint32_t> &idx, Batch *const *st, const void *const *in,
+int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx, Batch *const *st, const void *const *in,
                           uint32_t *in_len, void *const *out, uint32_t *out_len, bool float_io, int *rcs) {
-  ManyStage &ms = many_stage(device);
+  ManyStage &ms = many_stage(device, lane);
   std::lock_guard<std::mutex> lock(ms.mu);
   DeviceScope device_scope(device);
   HIP_TRY(device_scope.error());
@@ -1923,36 +1924,47 @@ int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in
     else
       by_device[b->device_].push_back(i);
   }
-  std::vector<int> dev_rc(by_device.size(), SPEEXHIP_ERR_SUCCESS);
-  std::vector<std::string> dev_err(by_device.size());
-  auto run_device = [&](size_t slot, int device, const std::vector<uint32_t> *idx) {
+  // Units of work: a device's states -- or, for a large call, two halves of them ("lanes"): one thread's pageable copies
+  // do not fill a PCIe link (64 x 2^20 stereo frames on one GPU: 11.0 ms through one stage, 7.6 ms as two logical
+  // devices of 32 states each, profiles/r05_host_many.txt), two stages side by side nearly do.
+  struct Unit {
+    int device, lane;
+    std::vector<uint32_t> idx;
+  };
+  std::vector<Unit> units;
+  static const int env_lanes = std::getenv("SPEEXHIP_MANY_LANES") ? std::atoi(std::getenv("SPEEXHIP_MANY_LANES")) : -1;  // A/B: 1 = never split
+  for (auto &kv : by_device) {
+    uint64_t bytes = 0;
+    for (uint32_t i : kv.second) bytes += static_cast<uint64_t>(in_len[i]) * st[i]->channels_ * (float_io ? 4 : 2);
+    const bool split = env_lanes != 1 && kv.second.size() >= 8 && bytes >= (static_cast<uint64_t>(64) << 20);
+    if (!split) {
+      units.push_back(Unit{kv.first, 0, kv.second});
+    } else {
+      const size_t half = kv.second.size() / 2;
+      units.push_back(Unit{kv.first, 0, std::vector<uint32_t>(kv.second.begin(), kv.second.begin() + half)});
+      units.push_back(Unit{kv.first, 1, std::vector<uint32_t>(kv.second.begin() + half, kv.second.end())});
+    }
+  }
+  std::vector<int> dev_rc(units.size(), SPEEXHIP_ERR_SUCCESS);
+  std::vector<std::string> dev_err(units.size());
+  auto run_device = [&](size_t slot) {
+    const Unit &u = units[slot];
     try {
-      dev_rc[slot] = many_on_device(device, *idx, st, in, in_len, out, out_len, float_io, rcs.data());
+      dev_rc[slot] = many_on_device(u.device, u.lane, u.idx, st, in, in_len, out, out_len, float_io, rcs.data());
     } catch (const std::bad_alloc &) {
       dev_rc[slot] = SPEEXHIP_ERR_ALLOC_FAILED;
     }
     if (dev_rc[slot] != SPEEXHIP_ERR_SUCCESS) {
       dev_err[slot] = g_last_error;  // (the text lives per thread)
-      for (uint32_t i : *idx) rcs[i] = dev_rc[slot];
+      for (uint32_t i : u.idx) rcs[i] = dev_rc[slot];
     }
   };
   {
-    // GPUs side by side: every further device of the call gets a thread of its own (a GPU is a PCIe link of its own,
+    // GPUs side by side: every further unit of the call gets a thread of its own (a GPU is a PCIe link of its own,
     // and the runtime's pageable copies keep the calling thread busy while they run)
     std::vector<std::thread> workers;
-    size_t slot = 0;
-    const std::vector<uint32_t> *first_idx = nullptr;
-    int first_device = 0;
-    for (auto &kv : by_device) {
-      if (slot == 0) {
-        first_idx = &kv.second;
-        first_device = kv.first;
-      } else {
-        workers.emplace_back(run_device, slot, kv.first, &kv.second);
-      }
-      slot++;
-    }
-    if (first_idx != nullptr) run_device(0, first_device, first_idx);
+    for (size_t slot = 1; slot < units.size(); slot++) workers.emplace_back(run_device, slot);
+    if (!units.empty()) run_device(0);
     for (std::thread &w : workers) w.join();
     for (size_t k = 0; k < dev_rc.size(); k++)
       if (dev_rc[k] != SPEEXHIP_ERR_SUCCESS) {

@@ -161,7 +161,7 @@ class Batch {
                    hipStream_t stream);
   // a large host call as pieces: input copies on a second stream, one launch per piece behind each (process_host_take)
   int take_in_pieces(const void *in, uint32_t *in_len, uint32_t *out_len, bool float_io, void *blk, uint32_t pieces);
-  static int many_on_device(int device, const std::vector<uint32_t> &idx, Batch *const *st, const void *const *in,
+  static int many_on_device(int device, int lane, const std::vector<uint32_t> &idx, Batch *const *st, const void *const *in,
                             uint32_t *in_len, void *const *out, uint32_t *out_len, bool float_io, int *rcs);
   bool have_copy_stream();  // copy_stream_ = a pool stream other than own_stream_ (false: none -> no piecewise call)
 
