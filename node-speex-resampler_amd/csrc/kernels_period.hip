@@ -198,7 +198,10 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // 245 / 119; one stream 37.6 / 21.8, 51.9 / 21.1, 16.4 / 13.1, 20.3 / 23.3: profiles/r05_wide_windows.txt.)
   // (SPEEXHIP_MIN_FILL=n, diagnostics: at least 1/n of the lanes instead of a quarter -- profiles/r05_wide_windows.txt)
   static const uint32_t min_fill = std::getenv("SPEEXHIP_MIN_FILL") ? std::max(1, std::atoi(std::getenv("SPEEXHIP_MIN_FILL"))) : 8;
-  t.usable = f.den >= 7 && t.cgroups <= 64 && min_fill * t.lane_periods >= full && t.window_bytes <= lds_budget;
+  // (the fp64 plans keep the quarter: at quality 10 the same two ratios, 32 streams, took 459 / 898 / 429 / 886 us on the
+  //  exact kernel -- bit-exact there -- against 643 / 977 / 473 / 998 here; profiles/r05_wide_windows.txt)
+  const uint32_t fill_rule = a64 && !std::getenv("SPEEXHIP_MIN_FILL") ? 4u : min_fill;
+  t.usable = f.den >= 7 && t.cgroups <= 64 && fill_rule * t.lane_periods >= full && t.window_bytes <= lds_budget;
   // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py); so are the
   // tap rows of an fp64 accumulator
   // (round 5: frames of 5 and 7 single channels have ISA loops too -- int16 window (kernels_period_odd.hip)
