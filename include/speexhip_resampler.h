@@ -422,7 +422,8 @@ SPEEXHIP_API int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int
 /* ... and the round-4 plans beside it: out[0] = 5 / 4 when FAST runs the configuration through the fp64-accumulate
  * period / slide kernel (quality 9, 10: out[1] = phases per wave / periods per lane, out[2] = periods per tile,
  * out[3] = row length, out[4] = LDS bytes, out[5] = bank padding / row stride, out[6] = trips per row, out[7] = tap
- * steps per iteration of the slide kernel), 6 when the mono filter also has phase-pair plans (wide windows: same
+ * steps per iteration of the slide kernel, or -- period kernel -- periods per tile of the int16-window plan that int16
+ * calls take instead, 0 = none), 6 when the mono filter also has phase-pair plans (wide windows: same
  * fields as the period plan, out[7] = periods per tile of their int16-window plan), 0 otherwise. */
 SPEEXHIP_API int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, uint32_t channels,
                                        uint32_t out[8]);

@@ -340,6 +340,8 @@ int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, u
         out[4] = static_cast<uint32_t>(t.window_bytes);
         out[5] = t.pad;
         out[6] = t.l4;
+        const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, speexhip::lds_budget(), t);  // (round 5)
+        out[7] = w16.usable ? w16.lane_periods : 0;
       }
     } else if (double_kind && speexhip::plan_slide(f, channels).usable) {
       const speexhip::SlidePlan sl = speexhip::plan_slide64(f, channels);

@@ -279,6 +279,7 @@ DeviceTables::~DeviceTables() {
   pool::device_put(device, pp_w16_rows);
   pool::device_put(device, period64_rows);
   pool::device_put(device, fine64_rows);
+  pool::device_put(device, period64_w16_rows);
 }
 
 namespace {
@@ -402,6 +403,15 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
           rc = upload_bytes(reinterpret_cast<void **>(&t->fine64_rows), rows.data(), rows.size() * sizeof(double));
           if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
         }
+      }
+    }
+    if (t->period64.usable) {
+      t->period64_w16 = plan_period_w16(f, channels, kLdsBudget, t->period64);
+      if (t->period64_w16.usable) {
+        std::vector<double> rows;
+        build_period_rows64(f, t->period64_w16, &rows);
+        rc = upload_bytes(reinterpret_cast<void **>(&t->period64_w16_rows), rows.data(), rows.size() * sizeof(double));
+        if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
       }
     }
     if (t->slide.usable) t->slide64 = plan_slide64(f, channels);
@@ -540,6 +550,7 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   d_period_pp_rows_ = tables->pp_rows;
   d_period_pp_w16_rows_ = tables->pp_w16_rows;
   d_period64_fine_rows_ = tables->fine64_rows;
+  d_period64_w16_rows_ = tables->period64_w16_rows;
   const std::vector<float> no_table;
   filter_ = f;
   filter_.table = no_table;  // the host copy of the sinc table lives only while the tables are built
@@ -557,6 +568,7 @@ int Batch::install_filter(const FilterSpec &f, const std::vector<float> &hist, u
   period_pp_ = tables->pp;
   period_pp_w16_ = tables->pp_w16;
   period64_fine_ = tables->fine64;
+  period64_w16_ = tables->period64_w16;
   return SPEEXHIP_ERR_SUCCESS;
 }
 
@@ -950,6 +962,11 @@ int Batch::launch_chunk(const StreamDesc *descs, const DescPack &pack, uint32_t 
     geo.lds_bytes = 0;
     geo.outs_per_block = 256;
     e = launch_exact(filter_, geo, d_table_, channels_, &pack, n, max_out, float_io, stream, nullptr, true);
+  } else if (fast && acc64() && period64_.usable && !float_io && !float_seen_ && period64_w16_.usable &&
+             (w16_always() || period_launch_prefers_w16(filter_, period64_, period64_fine_.usable, descs, n))) {
+    // ... over an int16 LDS window where the float window holds a fraction of a tile (wide windows; round 5)
+    e = launch_period(filter_, period64_w16_, reinterpret_cast<const float *>(d_period64_w16_rows_), nullptr, nullptr, channels_,
+                      descs, &pack, n, false, stream, fixed);
   } else if (fast && acc64() && period64_.usable) {
     // the reference sums these filters in fp64 (resample.c:389-435, :501-558): v_fma_f64 kernels
     e = launch_period(filter_, period64_, reinterpret_cast<const float *>(d_period64_rows_), &period64_fine_,
@@ -1567,6 +1584,7 @@ int warm_device(int device) {
   warm_unit_slide64_i16(s);
   warm_unit_period_pp(s);
   warm_unit_period_odd(s);
+  warm_unit_period64_w16(s);
   warm_unit_slide_f32(s);
   warm_unit_slide64_f32(s);
   HIP_TRY(hipStreamSynchronize(s));

@@ -36,9 +36,10 @@ struct DeviceTables {
   float *slide_rows = nullptr;   // kernels_slide.hip
   double *slide64_rows = nullptr;  // kernels_slide64_impl.h: fp64 taps (filters of the reference's double kinds)
   double *period64_rows = nullptr, *fine64_rows = nullptr;  // kernels_period64.hip: the same for the period kernel
+  double *period64_w16_rows = nullptr;                      // ... over an int16 LDS window (kernels_period64_w16.hip)
   float *pp_rows = nullptr, *pp_w16_rows = nullptr;         // kernels_period_pp.hip: phase pairs (mono, wide windows)
   ExactGeometry geo, geo_ch;     // exact kernel, all channels / one channel per launch
-  PeriodPlan period, fine, w16, period64, fine64, pp, pp_w16;
+  PeriodPlan period, fine, w16, period64, fine64, pp, pp_w16, period64_w16;
   SlidePlan slide, slide64;
   size_t bytes = 0;
   DeviceTables() = default;
@@ -205,6 +206,8 @@ class Batch {
   float *d_period_pp_rows_ = nullptr, *d_period_pp_w16_rows_ = nullptr;
   PeriodPlan period64_, period64_fine_;  // the period kernel's plans with an fp64 accumulator (kernels_period64.hip)
   double *d_period64_rows_ = nullptr, *d_period64_fine_rows_ = nullptr;
+  PeriodPlan period64_w16_;              // ... over an int16 LDS window (wide windows; int16 calls)
+  double *d_period64_w16_rows_ = nullptr;
   bool acc64() const {     // the fast path sums in fp64 (mode FAST on a filter the reference sums in fp64)
     return (mode_ == SPEEXHIP_MODE_FAST || mode_ == SPEEXHIP_MODE_FAST_FIXED) &&
            (filter_.kind == kDirectDouble || filter_.kind == kInterpolateDouble);

@@ -213,11 +213,16 @@ class Variant64(Variant):
     issues at the rate of v_pk_fma_f32 (tools/ubench_fma64.hip), so this is the fp32 loop's instruction stream with
     half the multiply-adds per instruction.  No int16 window (its conversions would come on top)."""
 
-    def __init__(self, R, S, CT, CF, padded):
+    def __init__(self, R, S, CT, CF, padded, w16=False):
         Variant.__init__(self, R, 2 * S, CT, CF, padded, False)   # register homes of the fp32 scheme with 2S steps
         self.S = S                                                # steps per bank here
         self.vbase = {10: 56, 5: 64}[R]   # (R = 10: the top of the 64 VGPRs of 8 waves per SIMD, v0-v55 left in one piece)
-        self.name = "A64_R%d_S%d_CT%d_CF%d_P%d" % (R, S, CT, CF, int(padded))
+        # Round 5: an int16 LDS window here too (wide windows of quality 9 / 10 decimators: twice the periods per tile).
+        # Single-channel lanes pay nothing for it -- ds_read_i16 sign-extends, v_cvt_f64_i32 replaces v_cvt_f64_f32 --,
+        # channel pairs two instructions per frame (the dword's halves sign-extended before they are widened).
+        self.w16 = w16
+        self.eb = 2 if w16 else 4
+        self.name = "A64_R%d_S%d_CT%d_CF%d_P%d_W%d" % (R, S, CT, CF, int(padded), int(w16))
 
     # step k (0 .. 2S-1) of a trip: four VGPRs, x as a double in [q, q+1], y in [q+2, q+3]; the raw floats arrive
     # in q (x) and q+2 (y)
@@ -256,11 +261,15 @@ class Variant64(Variant):
         out = []
         for u in range(self.S):
             k = u if which == "A" else self.S + u
-            o = (first_step + u) * self.CF * 4
+            o = (first_step + u) * self.CF * self.eb
             q = self.quad(k)
-            if self.CT == 2:
+            if self.CT == 2 and self.w16:
+                out.append("ds_read_b32 v%d, %%[addr] offset:%d" % (q + 1, o))   # both int16 samples of the frame
+            elif self.CT == 2:
                 # both channels of the frame: x lands in q, y in q+1 and moves to its own pair when widened
                 out.append("ds_read_b64 v[%d:%d], %%[addr] offset:%d" % (q, q + 1, o))
+            elif self.w16:
+                out += ["ds_read_i16 v%d, %%[addr] offset:%d" % (q, o), "ds_read_i16 v%d, %%[addr2] offset:%d" % (q + 2, o)]
             else:
                 out += ["ds_read_b32 v%d, %%[addr] offset:%d" % (q, o), "ds_read_b32 v%d, %%[addr2] offset:%d" % (q + 2, o)]
         return out
@@ -270,8 +279,14 @@ class Variant64(Variant):
         for u in range(self.S):
             k = u if which == "A" else self.S + u
             q = self.quad(k)
-            if self.CT == 2:
+            if self.CT == 2 and self.w16:
+                # the dword in q+1: y = its upper half (arithmetic shift), x = its lower half (signed bit field), then widened
+                out += ["v_ashrrev_i32_e32 v%d, 16, v%d" % (q + 2, q + 1), "v_bfe_i32 v%d, v%d, 0, 16" % (q, q + 1),
+                        "v_cvt_f64_i32_e32 v[%d:%d], v%d" % (q + 2, q + 3, q + 2), "v_cvt_f64_i32_e32 v[%d:%d], v%d" % (q, q + 1, q)]
+            elif self.CT == 2:
                 out += ["v_cvt_f64_f32_e32 v[%d:%d], v%d" % (q + 2, q + 3, q + 1), "v_cvt_f64_f32_e32 v[%d:%d], v%d" % (q, q + 1, q)]
+            elif self.w16:
+                out += ["v_cvt_f64_i32_e32 v[%d:%d], v%d" % (q, q + 1, q), "v_cvt_f64_i32_e32 v[%d:%d], v%d" % (q + 2, q + 3, q + 2)]
             else:
                 out += ["v_cvt_f64_f32_e32 v[%d:%d], v%d" % (q, q + 1, q), "v_cvt_f64_f32_e32 v[%d:%d], v%d" % (q + 2, q + 3, q + 2)]
         return out
@@ -279,7 +294,7 @@ class Variant64(Variant):
     def loop(self, label, cnt, lo, hi):
         S, R = self.S, self.R
         bank_bytes = 8 * S * R
-        adv = 2 * S * self.CF * 4
+        adv = 2 * S * self.CF * self.eb
         body = ["s_sub_u32 %%[%s], %%[%s], 1" % (cnt, cnt), "s_cbranch_scc1 %d1f" % label, "%d0:" % label]
         body += ["s_waitcnt lgkmcnt(0)"] + self.converts("A") + self.tap_loads("B", bank_bytes) + self.sample_reads("B", S)
         body += self.fma_bank("A", lo, hi)
@@ -318,7 +333,7 @@ class Variant64(Variant):
             ins += ['[advpad] "s"(adv_pad)', '[wrapstep] "s"(wrap_step)']
         clob = ['"s%d"' % r for r in bank_regs(self.banks["A"]) + bank_regs(self.banks["B"])] + ['"v%d"' % r for r in self.vgprs()]
         return '''template <>
-struct FirLoopAsm64<%d, %d, %d, %s> {
+struct FirLoopAsm64<%d, %d, %d, %s, %s> {
   static constexpr bool available = true;
   static constexpr int steps_per_bank = %d;
   // as FirLoopAsm::run; acc[i][0 / 1]: the two halves of row i (channel pair, or the lane's two periods) in fp64;
@@ -335,7 +350,7 @@ struct FirLoopAsm64<%d, %d, %d, %s> {
       : %s, "scc", "memory");
   }
 };
-''' % (R, self.CT, self.CF, "true" if self.padded else "false", self.S, R, asm,
+''' % (R, self.CT, self.CF, "true" if self.padded else "false", "true" if self.w16 else "false", self.S, R, asm,
        ", ".join(outs), ", ".join(ins), ", ".join(clob))
 
     def lines(self):
@@ -467,10 +482,11 @@ def variants_pp():
 
 def variants64():
     out = []
-    for CT, CF in ((2, 2), (2, 4), (2, 6), (2, 8), (1, 1), (1, 3), (1, 5), (1, 7)):   # (round 5: odd frames too)
-        for padded in (False, True):
-            out.append(Variant64(10, 1, CT, CF, padded))
-        out.append(Variant64(5, R5_STEPS // 2, CT, CF, False))
+    for w16 in (False, True):                                                              # (round 5: int16 window)
+        for CT, CF in ((2, 2), (2, 4), (2, 6), (2, 8), (1, 1), (1, 3), (1, 5), (1, 7)):   # (round 5: odd frames too)
+            for padded in (False, True):
+                out.append(Variant64(10, 1, CT, CF, padded, w16))
+            out.append(Variant64(5, R5_STEPS // 2, CT, CF, False, w16))
     return out
 
 
@@ -504,7 +520,7 @@ struct FirLoopAsm {
 
 HEAD64 = '''
 // ---- fp64 accumulator (round 4; gen_fir_loop.py, Variant64) ----
-template <int R, int CT, int CF, bool PADDED>
+template <int R, int CT, int CF, bool PADDED, bool W16 = false>
 struct FirLoopAsm64 {
   static constexpr bool available = false;
 };

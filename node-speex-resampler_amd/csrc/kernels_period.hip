@@ -6,6 +6,9 @@ namespace speexhip {
 // the fp64-accumulate instances (kernels_period64.hip): launch the one of plan `t`'s layout
 hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                              dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
+// ... over an int16 LDS window (kernels_period64_w16.hip)
+hipError_t dispatch_period64_w16(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
+                                 dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
 // the instances for frames of five and seven channels (kernels_period_odd.hip)
 hipError_t dispatch_period_odd(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                                dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
@@ -51,7 +54,7 @@ PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_bu
   PeriodPlan w;
   static const bool off = std::getenv("SPEEXHIP_NO_W16") != nullptr;  // diagnostics: A/B
   if (!t.usable || off) return w;
-  w = plan_period_r(f, channels, lds_budget, t.r, true, false, t.pp);
+  w = plan_period_r(f, channels, lds_budget, t.r, true, t.a64, t.pp);
   static const bool force = std::getenv("SPEEXHIP_FORCE_W16") != nullptr;  // diagnostics: every layout that has one
   // What the int16 window costs is two conversions per sample read: +20 % vector instructions where a read
   // feeds 10 packed FMAs (R = 10, channel pairs), +40 % at R = 5, and single-channel lanes convert two
@@ -59,7 +62,9 @@ PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_bu
   // 28 -> 58 periods per tile 530 -> 338 us, 4 channels 14 -> 28: 1032 -> 687, stereo 44.1k->16k 42 -> 64: 363 -> 277,
   // mono 48k->11.025k 58 -> 116: 289 -> 197; but stereo 44.1k->8k (R = 5) 41 -> 64 only 304 -> 272 and mono
   // 44.1k->16k 86 -> 128 nothing (196 -> 198).  So: 5/4 of the periods for R = 10 on channel pairs, 7/4 otherwise.
-  const bool cheap = t.r == 10 && t.ct == 2;
+  // (fp64 loops, round 5: single-channel lanes convert for free -- v_cvt_f64_i32 where v_cvt_f64_f32 stood --, channel
+  //  pairs pay two instructions per 2 R v_fma_f64)
+  const bool cheap = t.a64 || (t.r == 10 && t.ct == 2);
   // (phase pairs: a tile is 64 periods either way; what the int16 window buys there is a second and third workgroup
   //  per CU -- taken when the float window leaves room for one only)
   const bool pp_fits_more = t.pp && w.usable && t.window_bytes > 80 * 1024 && w.window_bytes <= 80 * 1024;
@@ -208,7 +213,6 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   //  and fp64 rows (kernels_period64.hip); three channels the fp64 rows, their int16 window stays with their phase pairs)
   const bool odd_frame = t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7 || (t.cgroups == 3 && a64));
   if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1) || odd_frame)) t.usable = false;
-  if (a64 && w16) t.usable = false;
   if (t.pp && t.pad != 0 && t.r != 10) t.usable = false;
   return t;
 }
@@ -659,7 +663,9 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   }
   // (an int16 window -- t.w16 -- exists for int16 calls on the layouts the ISA loop is generated for: ONE or CGV)
   if (t.w16 && float_io) return hipErrorInvalidValue;
-  if (t.a64) return dispatch_period64(t, p, pack, grid, threads, float_io, stream);  // kernels_period64.hip
+  if (t.a64)  // kernels_period64.hip / kernels_period64_w16.hip
+    return t.w16 ? dispatch_period64_w16(t, p, pack, grid, threads, float_io, stream)
+                 : dispatch_period64(t, p, pack, grid, threads, float_io, stream);
   if (t.pp) return dispatch_period_pp(t, p, pack, grid, threads, float_io, stream);   // kernels_period_pp.hip
   if (t.ct == 1 && (t.cgroups == 3 || t.cgroups == 5 || t.cgroups == 7)) return dispatch_period_odd(t, p, pack, grid, threads, float_io, stream);
   // (LRC: the kernel of the layout, or its tap-range-shares twin)

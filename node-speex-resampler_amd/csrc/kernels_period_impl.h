@@ -338,11 +338,12 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
 // The same with an fp64 accumulator (round 4; FirLoopAsm64, csrc/gen_fir_loop.py): the reference's double kernels,
 // deps/speex/resample.c:389-435 and :501-558.  rows: the group's taps as doubles [trip][step][R]; a trip is
 // 2 * steps_per_bank steps (2 for R = 10, 6 for R = 5), the host's tables count in those (build_period_rows64).
-template <int R, int CT, bool PADDED, int CF>
+template <int R, int CT, bool PADDED, int CF, bool W16 = false>
 __device__ __forceinline__ void fir_group64(const PeriodParams &p, const double *__restrict__ rows, const float *xs,
                                             const LaneCtx &c, uint32_t g, bool skip_all, uint32_t part, uint32_t parts,
                                             double (&acc)[R][2]) {
-  using Isa = FirLoopAsm64<R, CT, CF, PADDED>;
+  using Isa = FirLoopAsm64<R, CT, CF, PADDED, W16>;
+  constexpr uint32_t EB = W16 ? 2u : 4u;  // bytes per window element (round 5: an int16 window here too)
   static_assert(CF != 0 && Isa::available, "the fp64 accumulator runs the ISA loop of its layout");
   constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
   // (padded windows: the host's boundary tables count 4-step iterations; a trip here is kStepsPerTrip steps)
@@ -373,12 +374,12 @@ __device__ __forceinline__ void fir_group64(const PeriodParams &p, const double 
   }
   const double *rows_g = rows + (static_cast<size_t>(g) * p.l4 + t0) * (kStepsPerTrip * R);
   const uint32_t addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xs)) +
-                        ((c.xlane + delta_g * c.C) + t0 * kStepsPerTrip * CF + wraps * p.pad) * 4u;
+                        ((c.xlane + delta_g * c.C) + t0 * kStepsPerTrip * CF + wraps * p.pad) * EB;
   const uint64_t rows_bits = reinterpret_cast<uint64_t>(rows_g);
   const double *rows_s = reinterpret_cast<const double *>(static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits))) |
                                                           static_cast<uint64_t>(sgpr(static_cast<uint32_t>(rows_bits >> 32))) << 32);
-  Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * 4u : 0u, sgpr(overlap(0, head)), sgpr(overlap(head, main_end)),
-           sgpr(overlap(main_end, total)), sgpr(to_wrap), sgpr(wrap_step), sgpr((kStepsPerTrip * CF + p.pad) * 4u));
+  Isa::run(acc, rows_s, addr, CT == 1 ? addr + p.half_offset * EB : 0u, sgpr(overlap(0, head)), sgpr(overlap(head, main_end)),
+           sgpr(overlap(main_end, total)), sgpr(to_wrap), sgpr(wrap_step), sgpr((kStepsPerTrip * CF + p.pad) * EB));
 }
 
 // Round / interleave / store the R phases of group g for this lane's period: R consecutive
@@ -836,8 +837,8 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
       double acc64[R][2];
 #pragma unroll
       for (int i = 0; i < R; i++) acc64[i][0] = acc64[i][1] = 0.0;
-      fir_group64<R, CT, PADDED, ONE_GROUP ? CT : CT * CGF>(p, reinterpret_cast<const double *>(rows), xs, c, g, (p.skip & 4u) != 0,
-                                                           0u, 1u, acc64);
+      fir_group64<R, CT, PADDED, ONE_GROUP ? CT : CT * CGF, W16>(p, reinterpret_cast<const double *>(rows), xs, c, g,
+                                                                (p.skip & 4u) != 0, 0u, 1u, acc64);
 #pragma unroll
       for (int i = 0; i < R; i++) acc[i] = f32x2{static_cast<float>(acc64[i][0]), static_cast<float>(acc64[i][1])};
     } else {
@@ -1012,7 +1013,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
 }
 
 // ... with an fp64 accumulator: the partial sums meet in LDS as doubles (twice the room: launch_period_plan)
-template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0>
+template <int R, int CT, bool ONE_GROUP, bool PADDED, typename T, int CGF = 0, bool W16 = false>
 __device__ __forceinline__ void fir_tile_parts64(KParams pp, const double *__restrict__ rows, KDesc dp, float *xs, uint32_t xshift,
                                                  uint32_t m_lo, uint32_t m_cnt, uint32_t wave, uint32_t lane, uint32_t zsplit) {
   constexpr int CF = ONE_GROUP ? CT : CT * CGF;
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ void fir_tile_parts64(KParams pp, const double *__res
     }
     g = zsplit * wg + gw;
     valid = g < p.groups;
-    if (valid) fir_group64<R, CT, PADDED, CF>(p, rows, xs, c, g, (p.skip & 4u) != 0, part, parts, acc);
+    if (valid) fir_group64<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, part, parts, acc);
   }
   __syncthreads();  // every wave is done with the window
   double *sums = reinterpret_cast<double *>(xs);
@@ -1203,8 +1204,8 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
         (const __attribute__((address_space(4))) KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const KDesc dp = &ka->pack.d[blockIdx.y];
     if constexpr (AM == 1)
-      fir_tile_parts64<R, CT, ONE_GROUP, PADDED, T, CGF>(&ka->p, reinterpret_cast<const double *>(rows), dp, xs, wg.xshift, m_lo,
-                                                         m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
+      fir_tile_parts64<R, CT, ONE_GROUP, PADDED, T, CGF, W16>(&ka->p, reinterpret_cast<const double *>(rows), dp, xs, wg.xshift,
+                                                              m_lo, m_cnt, wave, threadIdx.x & 63u, blockIdx.z);
     else
       fir_tile_parts<R, CT, ONE_GROUP, PADDED, T, CGF, W16, AM == 2>(&ka->p, rows, dp, xs, wg.xshift, m_lo, m_cnt, wave,
                                                                     threadIdx.x & 63u, blockIdx.z);

@@ -462,7 +462,7 @@ def test_generated_fir_loop_is_in_step_with_its_generator():
         assert max(v.vgprs()) < (64 if v.R == 10 else 128), v.name
     # the fp64-accumulate variants (round 4): one v_fma_f64 per tap and half of the lane's pair, one conversion per
     # half of every sample read, doubles in aligned SGPR pairs of the same homes, aligned VGPR pairs
-    assert len(gen.variants64()) == 24   # (round 5: + frames of 3 / 5 / 7 channels)
+    assert len(gen.variants64()) == 48   # (round 5: + frames of 3 / 5 / 7 channels, x int16 window)
     for v in gen.variants64():
         lines = v.lines()
         loops = 3 if v.R == 10 else 1
@@ -470,7 +470,12 @@ def test_generated_fir_loop_is_in_step_with_its_generator():
         assert sum(1 for l in lines if l.startswith("v_fma_f64")) == 2 * v.S * rows * 2, v.name
         assert not any(l.startswith("v_pk_fma_f32") for l in lines), v.name
         assert sum(1 for l in lines if l.startswith("ds_read")) == (loops * 2 + 1) * v.S * (2 if v.CT == 1 else 1), v.name
-        assert sum(1 for l in lines if l.startswith("v_cvt_f64_f32")) == loops * 2 * v.S * 2, v.name
+        # samples widened behind the wait: from floats, or (int16 window, round 5) sign-extended and widened from ints --
+        # channel pairs then pay a shift and a bit-field extract per frame, single-channel lanes nothing extra
+        widen = "v_cvt_f64_i32" if v.w16 else "v_cvt_f64_f32"
+        assert sum(1 for l in lines if l.startswith(widen)) == loops * 2 * v.S * 2, v.name
+        assert sum(1 for l in lines if l.startswith("v_cvt")) == loops * 2 * v.S * 2, v.name
+        assert sum(1 for l in lines if l.startswith(("v_bfe_i32", "v_ashrrev_i32"))) == (loops * 2 * v.S * 2 if v.w16 and v.CT == 2 else 0), v.name
         assert sum(1 for l in lines if l == "s_waitcnt lgkmcnt(0)") == 2 * loops + 1, v.name
         used = set(gen.bank_regs(v.banks["A"]) + gen.bank_regs(v.banks["B"]))
         assert len(used) == 2 * (2 * v.S * v.R) and 32 not in used and max(used) <= 73, v.name   # two dwords per tap
