@@ -169,10 +169,16 @@ void set_last_device_error(const std::string &text) { g_last_error = text; }
 size_t lds_budget() { return kLdsBudget; }
 
 // diagnostics / tests: the int16-window plan at every launch size (normally only launches that fill the chip)
-static bool w16_always() {
-  static const bool on = std::getenv("SPEEXHIP_W16_ALWAYS") != nullptr;
-  return on;
+// (SPEEXHIP_W16_ALWAYS=0: never -- A/B runs)
+static int w16_env() {
+  static const int v = [] {
+    const char *e = std::getenv("SPEEXHIP_W16_ALWAYS");
+    return e == nullptr ? -1 : (e[0] == '0' && e[1] == '\0' ? 0 : 1);
+  }();
+  return v;
 }
+static bool w16_always() { return w16_env() == 1; }
+static bool w16_never() { return w16_env() == 0; }
 void debug_fail_device_allocs(int n) { g_fail_allocs.store(n < 0 ? 0 : n); }
 
 bool Batch::uniform(uint32_t s) const {
@@ -962,7 +968,7 @@ int Batch::launch_chunk(const StreamDesc *descs, const DescPack &pack, uint32_t 
     geo.lds_bytes = 0;
     geo.outs_per_block = 256;
     e = launch_exact(filter_, geo, d_table_, channels_, &pack, n, max_out, float_io, stream, nullptr, true);
-  } else if (fast && acc64() && period64_.usable && !float_io && !float_seen_ && period64_w16_.usable &&
+  } else if (fast && acc64() && period64_.usable && !float_io && !float_seen_ && period64_w16_.usable && !w16_never() &&
              (w16_always() || period_launch_prefers_w16(filter_, period64_, period64_fine_.usable, descs, n))) {
     // ... over an int16 LDS window where the float window holds a fraction of a tile (wide windows; round 5)
     e = launch_period(filter_, period64_w16_, reinterpret_cast<const float *>(d_period64_w16_rows_), nullptr, nullptr, channels_,
