@@ -325,6 +325,7 @@ uint32_t split_count(const PeriodPlan &t, uint32_t tiles, uint32_t n_streams, ui
 // probe != null: the launch's shape only (tiles, shares, waves), nothing is launched
 struct PeriodShape {
   uint32_t tiles, splits, wave_groups, ksplit, threads, touch;
+  bool rounds_3_4 = false;  // in: the shares as rounds 3-4 counted them (the phase-pair rule was fitted on those shapes)
 };
 hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
                               const StreamDesc *h_descs, const DescPack *pack,
@@ -393,6 +394,7 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
   // frames: 642 -> 459 us; 44.1k->16k at 4 waves per SIMD lost, 578 -> 681).
   if (n_streams < 2) return false;
   PeriodShape so{}, sp{};
+  so.rounds_3_4 = sp.rounds_3_4 = true;
   if (launch_period_plan(f, two, nullptr, two.ct * two.cgroups, h_descs, nullptr, n_streams, false, nullptr, &so) != hipSuccess ||
       launch_period_plan(f, pp, nullptr, pp.cgroups, h_descs, nullptr, n_streams, false, nullptr, &sp) != hipSuccess)
     return false;
@@ -504,7 +506,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // fitted to the launches of profiles/r03_small_decimators.txt: a wave alone on its SIMD spends ~19 cycles per
   // packed FMA, w of them together 4.75 w; a workgroup takes its window in at ~11 bytes per cycle; workgroups
   // beyond one per CU queue.  A candidate must beat the incumbent by 10 %.
-  static const bool model_off = std::getenv("SPEEXHIP_SPLIT_MODEL") && std::atoi(std::getenv("SPEEXHIP_SPLIT_MODEL")) == 0;  // A/B
+  static const bool model_off = std::getenv("SPEEXHIP_SPLIT_MODEL") && std::atoi(std::getenv("SPEEXHIP_SPLIT_MODEL")) == 0;  // A/B (0: neither model)
   if (splits > 1 && !model_off && !std::getenv("SPEEXHIP_SPLITS")) {
     const double cus = device_compute_units();
     auto cost = [&](uint32_t s) {
@@ -522,6 +524,38 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
     };
     uint32_t best = splits;
     for (uint32_t s2 = splits + 1; s2 <= 2 * splits + 1 && s2 <= 16 && (t.groups + s2 - 1) / s2 >= 2; s2++)
+      if (cost(s2) < 0.9 * cost(best)) best = s2;
+    splits = best;
+  }
+  // Windows of more than half the LDS (one workgroup per CU; round 5).  There the launch runs in whole GENERATIONS of
+  // workgroups -- the history-roll block of every (stream, share) is a workgroup too and asks for the same LDS -- and
+  // the doubling above neither counts those nor knows three shares: 8 streams x 131 072 frames of 4-channel 32k ->
+  // 11.025k is 8 tiles + 1 per stream, x 4 shares = 288 workgroups on 256 CUs, 70 us against 48 in 3 shares (216); 32
+  // mono streams in 2 tiles each took 4 shares, 384 workgroups, 85 us against 49 in 2.  The shares by a model of the
+  // generations instead, fitted to tools/r05_wide_grid.sh (profiles/r05_wide_grid.txt: 27 launches x 7 split counts): a
+  // workgroup stages its window at ~5 bytes per cycle (all CUs at once) and then spends 4.75 cycles per packed FMA and
+  // SIMD on the groups of its share, its slowest wave at least `walks` chains; within +-15 % of the measured launches,
+  // argmin within 6 % of the best measured on 25 of the 27.  A candidate has to beat fewer shares by 10 %.
+  static const bool wide_model_off = std::getenv("SPEEXHIP_SPLIT_MODEL") && std::atoi(std::getenv("SPEEXHIP_SPLIT_MODEL")) <= 1;  // A/B: 1 = rounds 3-4
+  // Only where the count above does not fit one generation: inside one, its shares (and the tap-range shares they allow)
+  // are the better-fitted choice -- the model in their place lost 25-40 % on one-stream and mono launches
+  // (profiles/r05_ab_split_model.txt, first table).
+  if (t.window_bytes > 80 * 1024 && !wide_model_off && !std::getenv("SPEEXHIP_SPLITS") && max_periods != 0 &&
+      !(probe != nullptr && probe->rounds_3_4) &&
+      static_cast<uint64_t>(tiles) * n_streams * splits + n_streams > device_compute_units()) {
+    // (of the history-roll blocks only those of share 0 do anything; the others leave at once)
+    const double cus = device_compute_units();
+    const double chain = static_cast<double>(t.r) * t.row_len * (t.a64 ? 2 : 1) * 4.75 * (t.w16 ? 1.2 : 1.0);
+    auto cost = [&](uint32_t s) {
+      const double gens = std::ceil((static_cast<double>(tiles) * n_streams * s + n_streams) / cus);
+      const uint32_t gps = (t.groups + s - 1) / s;
+      const double walks = std::ceil(static_cast<double>(gps) / max_waves);
+      // (tap-range shares, below: the waves a share leaves idle take pieces of its groups' chains)
+      const double parts = (gps * 2 <= max_waves && static_cast<uint64_t>(t.r) * t.row_len * (t.a64 ? 2 : 1) >= 1800) ? max_waves / gps : 1;
+      return gens * (t.window_bytes / 5.0 + std::max(gps / 4.0, walks / parts) * chain);
+    };
+    uint32_t best = 1;
+    for (uint32_t s2 = 2; s2 <= 16 && (t.groups + s2 - 1) / s2 >= 2; s2++)
       if (cost(s2) < 0.9 * cost(best)) best = s2;
     splits = best;
   }
@@ -640,7 +674,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
       (p.ksplit > 1 ? wave_groups * p.ksplit : helpers ? std::max<uint32_t>(wave_groups, max_waves) : wave_groups) * 64;
   p.threads = threads;
   if (probe != nullptr) {
-    *probe = PeriodShape{tiles, splits, wave_groups, p.ksplit, threads, p.touch};
+    *probe = PeriodShape{tiles, splits, wave_groups, p.ksplit, threads, p.touch, probe->rounds_3_4};
     return hipSuccess;
   }
   // Grid: x = tiles + 1 (the extra block rolls the history), padded to a multiple of 8

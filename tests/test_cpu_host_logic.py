@@ -604,6 +604,34 @@ def test_round4_launch_rules_shares_fetch_and_phase_pairs_by_launch():
     assert shape(1, 24000, 48000, 1, 1 << 20, q=10)["r"] == 0 and shape(2, 44100, 48000, 1, 4096, q=10)["r"] == 0
 
 
+def test_round5_shares_of_wide_window_launches_count_generations():
+    """Round 5: a window of more than half the LDS means one workgroup per CU, and the history-roll block of every
+    (stream, share) is a workgroup too.  Where the doubling rule's count -- which neither sees those blocks nor knows
+    odd counts -- does not fit one generation (256 CUs without a device), the shares come from a model of the
+    generations (launch_period_plan; profiles/r05_wide_grid.txt, r05_ab_split_model.txt); inside one generation the
+    launch is what rounds 3-4 fitted."""
+    from math import gcd
+
+    def shape(ch, i, o, streams, frames, q=7):
+        g = gcd(i, o)
+        return speexhip.debug_launch_shape(i // g, o // g, q, ch, streams, frames, False)
+
+    # 4 channels 32k -> 11.025k, 8 x 131 072 frames: 8 tiles x 8 streams x 4 shares = 256 workgroups + 8 that roll histories -> 3 shares
+    t = shape(4, 32000, 11025, 8, 131072)
+    assert t["tiles"] == 8 and t["splits"] == 3 and t["wave_groups"] == 15, t
+    # ... 32 streams: 256 + 32 workgroups unsplit (two generations, the second nearly empty) -> 2 shares
+    t = shape(4, 32000, 11025, 32, 131072)
+    assert t["splits"] == 2, t
+    # mono, 32 streams in 2 tiles each: 4 shares were 256 tile workgroups + 32 that roll histories -> 3 (192 + 32)
+    t = shape(1, 32000, 11025, 32, 131072)
+    assert t["phase_pairs"] and t["tiles"] == 2 and t["splits"] == 3, t
+    # one generation: untouched (one stream of 48k -> 11.025k mono: 29 tiles + 1 in 8 shares = 240 workgroups, tap-range shares)
+    t = shape(1, 48000, 11025, 1, 1 << 20)
+    assert t["splits"] == 8 and t["shares"] == 8, t
+    # narrow windows (two workgroups per CU) never take this path: BASELINE configs[1]
+    assert shape(2, 44100, 48000, 1, 1 << 20)["splits"] == 2 and shape(2, 44100, 48000, 32, 1 << 20)["splits"] == 1
+
+
 def test_device_placement_rule():
     """Round 5: which GPU a new state lives on (csrc/devices.cpp) as a pure function of the device count, the two
     environment variables and the state's number in its process -- SPEEXHIP_DEVICES=all is BASELINE configs[4]'s
