@@ -197,12 +197,15 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   if (full_tile) t.lane_periods = fit_all;
   t.window_bytes = t.lane_periods ? window_bytes_for(t.lane_periods) : 0;
   // needs enough phases to fill the R-wide register tile and a window that fits one CU's LDS
-  // ... and at least an eighth of each wave at work.  (A quarter until round 5: 96k -> 11.025k and 32k -> 11.025k,
+  // ... and at least a ninth of each wave at work.  (A quarter until round 5, then an eighth: 96k -> 11.025k and 32k -> 11.025k,
   // num = 1280, fit 28 of a mono tile's 128 periods and 14 of a stereo tile's 64 -- just under it -- and ran the exact
   // kernel: 32 streams x 131 072 frames mono 223 us there against 52 us here, stereo 265 / 81, 32k -> 11.025k 212 / 83 and
   // 245 / 119; one stream 37.6 / 21.8, 51.9 / 21.1, 16.4 / 13.1, 20.3 / 23.3: profiles/r05_wide_windows.txt.)
   // (SPEEXHIP_MIN_FILL=n, diagnostics: at least 1/n of the lanes instead of a quarter -- profiles/r05_wide_windows.txt)
-  static const uint32_t min_fill = std::getenv("SPEEXHIP_MIN_FILL") ? std::max(1, std::atoi(std::getenv("SPEEXHIP_MIN_FILL"))) : 8;
+  // (a ninth, late in round 5: seven channels at num = 1280 fit 2 of a tile's 18 periods and still ran the exact kernel --
+  //  32 x 131 072 frames of 96k / 32k -> 11.025k 1430 / 1400 us there, 387 / 269 here, one stream 361 -> 133 / 98:
+  //  tools/r05_minfill9.sh)
+  static const uint32_t min_fill = std::getenv("SPEEXHIP_MIN_FILL") ? std::max(1, std::atoi(std::getenv("SPEEXHIP_MIN_FILL"))) : 9;
   // (the fp64 plans keep the quarter: at quality 10 the same two ratios, 32 streams, took 459 / 898 / 429 / 886 us on the
   //  exact kernel -- bit-exact there -- against 643 / 977 / 473 / 998 here; profiles/r05_wide_windows.txt)
   const uint32_t fill_rule = a64 && !std::getenv("SPEEXHIP_MIN_FILL") ? 4u : min_fill;

@@ -529,7 +529,7 @@ def test_round4_planners_fp64_accumulate_and_phase_pairs():
                         den = o // np.gcd(i, o)
                         assert steps * den <= 30, (i, o, q, ch, t)                # one bank of tap doubles in SGPR pairs
                     elif base["fast_path"] == 2:
-                        # (round 5: 3 / 5 / 7 channels too; and the fp32 plans run from an eighth of the lanes where the fp64
+                        # (round 5: 3 / 5 / 7 channels too; and the fp32 plans run from a ninth of the lanes where the fp64
                         #  plans keep the quarter: 1280:N at quality 9 / 10 rides the fp32 chain, accumulate_bits says 32)
                         full = 64 // (ch // 2 if ch % 2 == 0 else ch) * (1 if ch % 2 == 0 else 2)
                         quarter = 4 * base["lane_periods"] >= full
