@@ -213,8 +213,13 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py); so are the
   // tap rows of an fp64 accumulator
   // (round 5: frames of 5 and 7 single channels have ISA loops too -- int16 window (kernels_period_odd.hip)
-  //  and fp64 rows (kernels_period64.hip); three channels the fp64 rows, their int16 window stays with their phase pairs)
-  const bool odd_frame = t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7 || (t.cgroups == 3 && a64));
+  //  and fp64 rows (kernels_period64.hip); three channels likewise)
+  // (three channels: the int16 window of the two-period plan too, late in round 5 -- until then only their phase-pair
+  //  plans had one: one stream of 2^20 frames 48k / 32k / 96k -> 11.025k 40.9 / 76.5 / 67.1 -> 25.1 / 40.4 / 35.2 us,
+  //  32 such streams 1555 / 1496 -> 822 / 794; +6.9 % in the geometric mean of 40 launches, five of them 5-13 % slower:
+  //  profiles/r05_w16_3ch.txt.  SPEEXHIP_W16_3CH=0: as before, A/B)
+  static const bool w16_3ch = !(std::getenv("SPEEXHIP_W16_3CH") && std::atoi(std::getenv("SPEEXHIP_W16_3CH")) == 0);
+  const bool odd_frame = t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7 || (t.cgroups == 3 && (a64 || w16_3ch)));
   if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1) || odd_frame)) t.usable = false;
   if (t.pp && t.pad != 0 && t.r != 10) t.usable = false;
   return t;

@@ -416,10 +416,12 @@ def test_planner_choices_for_the_named_configurations():
     for i, o in ((44100, 8000), (88200, 48000), (88200, 16000), (176400, 8000)):
         assert plan(i, o, 7, 2)["r_or_p"] == 5, (i, o)
     # wide windows (round 3): int16 calls run over an int16 LDS window with twice the periods per tile; not where
-    # the float window already fills the waves, not for the layouts without an ISA loop (odd channel counts >= 3)
+    # the float window already fills the waves, not for the layouts without an ISA loop (9 channels and more)
     assert plan(48000, 11025, 7, 2)["w16_lane_periods"] >= 2 * plan(48000, 11025, 7, 2)["lane_periods"]
     assert plan(44100, 16000, 7, 2)["w16_lane_periods"] == 64 and plan(48000, 11025, 7, 4)["w16_lane_periods"] == 28
-    assert cfg2["w16_lane_periods"] == 0 and cfg4["w16_lane_periods"] == 0 and plan(48000, 11025, 7, 3)["w16_lane_periods"] == 0
+    assert cfg2["w16_lane_periods"] == 0 and cfg4["w16_lane_periods"] == 0
+    # (round 5: three channels too -- 18 -> 38 of a tile's 42 periods)
+    assert plan(48000, 11025, 7, 3)["w16_lane_periods"] == 38 and plan(48000, 11025, 7, 3)["lane_periods"] == 18
     # n:1 shapes: one period per lane from 16:1 on; 11:1 and 7:6 have no fast kernel
     assert plan(192000, 8000, 7, 2)["r_or_p"] == 1 and plan(96000, 8000, 7, 2)["r_or_p"] == 2
     assert plan(48000, 8000, 7, 2)["r_or_p"] == 4 and plan(48000, 24000, 7, 2)["r_or_p"] == 8
@@ -571,10 +573,13 @@ def test_round4_launch_rules_shares_fetch_and_phase_pairs_by_launch():
         return speexhip.debug_launch_shape(i // g, o // g, q, ch, streams, frames, float_io)
 
     # three channels 48k -> 11.025k: phase pairs, 8 groups of 20 phases on 8 waves -> two shares each, rows fetched
-    for frames in (131072, 1 << 20):
-        t = shape(3, 48000, 11025, 32, frames)
-        assert t["phase_pairs"] and t["r"] == 10 and t["splits"] == 1 and t["wave_groups"] == 8, t
-        assert t["shares"] == 2 and t["threads"] == 1024 and t["touch"], t
+    t = shape(3, 48000, 11025, 32, 131072)
+    assert t["phase_pairs"] and t["r"] == 10 and t["splits"] == 1 and t["wave_groups"] == 8, t
+    assert t["shares"] == 2 and t["threads"] == 1024 and t["touch"], t
+    # (round 5: launches of several generations run the two-period plan over its int16 window, 38 of 42 periods per tile --
+    #  until then that plan had only a float window, 18 periods, and phase pairs took these too: profiles/r05_w16_3ch.txt)
+    t = shape(3, 48000, 11025, 32, 1 << 20)
+    assert not t["phase_pairs"] and t["int16_window"] and t["lane_periods"] == 38 and t["wave_groups"] == 15 and t["touch"], t
     # stereo 48k -> 11.025k: the other plan would split its 150 KB tiles -> phase pairs, shares, rows (415 KB) fetched
     t = shape(2, 48000, 11025, 32, 131072)
     assert t["phase_pairs"] and t["splits"] == 1 and t["shares"] == 2 and t["touch"], t
