@@ -688,7 +688,10 @@ def test_window_layout_variants_of_the_period_kernel():
              (7, 22050, 16000, 8), (2, 88200, 96000, 9),
              # round 3: int16 calls of these run over an int16 LDS window (twice the periods per tile)
              (2, 48000, 11025, 7), (4, 48000, 11025, 7), (2, 44100, 16000, 7), (1, 48000, 11025, 7), (2, 44100, 8000, 10),
-             (8, 48000, 11025, 5), (6, 44100, 16000, 6)]
+             (8, 48000, 11025, 5), (6, 44100, 16000, 6),
+             # round 5: three channels' two-period plan over an int16 window; the widest windows (num = 1280), of which
+             # seven channels fit a ninth of a tile's periods
+             (3, 48000, 11025, 7), (3, 32000, 11025, 7), (7, 32000, 11025, 7), (5, 96000, 11025, 6), (4, 32000, 11025, 7)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)

@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--forget", default=None,
                     help="comma-separated workload names whose recorded numbers are dropped first (a kernel got faster: "
                          "its old slowest time is no floor any more)")
+    ap.add_argument("--forget-faster", type=float, default=None, metavar="RATIO",
+                    help="with --merge: a workload measured below RATIO x its recorded slowest time starts over from this "
+                         "box's number (a kernel or a launch rule got faster; e.g. 0.85)")
     ap.add_argument("--out", default=FLOOR, help="where to write (gpurun brings back gpurun_out/ only)")
     args = ap.parse_args()
     if not args.measure:
@@ -156,6 +159,9 @@ def main():
         print("%-22s %9.2f us   path %d   (slowest so far %s, ceiling %s)" % (
             w[0], us, path, old.get("slowest_us"), old.get("ceiling_us")))
         if args.merge or args.reset:
+            if args.forget_faster and old.get("slowest_us") and us < args.forget_faster * old["slowest_us"]:
+                print("   (faster than %.2f x the record: starting over)" % args.forget_faster)
+                old = {}
             slowest = max(us, old.get("slowest_us", 0.0))
             floor["workloads"][w[0]] = {"config": list(w[1]), "streams": w[2], "frames": w[3], "mode": w[4], "io": w[5],
                                         "fast_path": path, "slowest_us": round(slowest, 2),
