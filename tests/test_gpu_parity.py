@@ -782,6 +782,38 @@ def test_many_generation_launch_with_ragged_ends():
     b.close()
 
 
+@pytest.mark.parametrize("ch,i,o,q,S,frames", [(4, 32000, 11025, 7, 8, 131072), (1, 32000, 11025, 7, 32, 131072),
+                                               (4, 32000, 11025, 7, 32, 65536), (2, 48000, 11025, 10, 32, 65536),
+                                               (3, 32000, 11025, 7, 8, 200000), (7, 96000, 11025, 5, 4, 131072)])
+def test_wide_window_batches_whose_shares_come_from_the_generation_model(ch, i, o, q, S, frames):
+    """Round 5: batches of the widest windows (one workgroup per CU) whose phase-group shares the launch now takes from a model of
+    workgroup generations -- three shares, two where four were 256 + 32 workgroups -- plus the layouts this round gave an int16
+    window (three channels' two-period plan, the fp64 period kernel) and a ninth of a tile (seven channels at num = 1280):
+    two calls, ragged lengths, counters and +-1 LSB against the oracle on three streams."""
+    import torch
+    cap = int(frames * o / i) + 16
+    base = orc.lcg_pcm(frames * ch, 991 + ch).reshape(frames, ch)
+    xs = np.stack([np.roll(base, 17 * s, axis=0) for s in range(S)])
+    d_in = torch.from_numpy(xs).cuda()
+    d_out = torch.zeros((S, cap, ch), dtype=torch.int16, device="cuda")
+    b = speexhip.Batch(S, ch, i, o, q)
+    lens = [frames - 777 * (s % 5) - (s % 3) for s in range(S)]
+    sp = torch.cuda.current_stream().cuda_stream
+    picks = sorted(set([0, S // 2, S - 1]))
+    refs = {s: orc.Oracle(ch, i, o, q) for s in picks}
+    for call in range(2):
+        used, made = b.process_device(d_in.data_ptr(), frames * ch, lens, d_out.data_ptr(), cap * ch, cap, sp)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        for s in picks:
+            want, wu = refs[s].process(xs[s, : lens[s]], cap)
+            assert (used[s], made[s]) == (wu, want.shape[0]), (call, s)
+            # (the rate grows with the filter's length like every fp32 re-association: 376 ... 1 120 taps here)
+            assert_close(out[s, : made[s]], want, "call %d stream %d" % (call, s),
+                         rate=MISMATCH_RATE * max(1.0, (b.info()["filt_len"] / 256.0) ** 0.5))
+    b.close()
+
+
 def test_peek_predicts_the_counters_and_leaves_the_state_alone():
     """speexhip_resampler_peek: what the next call would consume / produce, from the integer state
     alone (the N-API addon sizes its result Buffer with it)."""
