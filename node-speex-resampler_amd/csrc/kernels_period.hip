@@ -209,7 +209,16 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // (the fp64 plans keep the quarter: at quality 10 the same two ratios, 32 streams, took 459 / 898 / 429 / 886 us on the
   //  exact kernel -- bit-exact there -- against 643 / 977 / 473 / 998 here; profiles/r05_wide_windows.txt)
   const uint32_t fill_rule = a64 && !std::getenv("SPEEXHIP_MIN_FILL") ? 4u : min_fill;
-  t.usable = f.den >= 7 && t.cgroups <= 64 && fill_rule * t.lane_periods >= full && t.window_bytes <= lds_budget;
+  bool filled = fill_rule * t.lane_periods >= full;
+  // (... or its int16-window plan does: 8 channels at num = 1280 with 2 232 taps -- 96k -> 11.025k, quality 8-10 -- fit ONE
+  //  period of the float window, a sixteenth of a tile, and three of the int16 one.  The float plan then exists for the
+  //  int16 plan to hang off -- int16 calls run over that -- and serves the float calls of such a state itself.  Late in
+  //  round 5: 32 x 131 072 frames 3 241 us on the exact kernel, tools/r05_q10_sweep.sh)
+  if (!filled && !w16 && !a64 && !t.pp && t.lane_periods >= 1 && t.window_bytes <= lds_budget) {
+    const PeriodPlan i16 = plan_period_r(f, channels, lds_budget, r, true, false, false);
+    filled = i16.usable;
+  }
+  t.usable = f.den >= 7 && t.cgroups <= 64 && filled && t.window_bytes <= lds_budget;
   // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py); so are the
   // tap rows of an fp64 accumulator
   // (round 5: frames of 5 and 7 single channels have ISA loops too -- int16 window (kernels_period_odd.hip)

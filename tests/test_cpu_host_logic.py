@@ -547,7 +547,8 @@ def test_round4_planners_fp64_accumulate_and_phase_pairs():
                     wide = base["fast_path"] == 2 and num >= 320 and ch <= 3    # lane = (period, channel): up to 3 channels
                     assert (t["fast_path"] == 6) == wide, (i, o, q, ch, base, t)
                     if wide:
-                        assert 64 // ch // 4 <= t["lane_periods"] <= 64 // ch and t["lds_bytes"] <= 150 * 1024, (i, o, q, ch, t)
+                        # (from a ninth of a tile, like the other fp32 plans: 64k -> 11.025k mono, 14 of 64 periods)
+                        assert 64 // ch // 9 <= t["lane_periods"] <= 64 // ch and t["lds_bytes"] <= 150 * 1024, (i, o, q, ch, t)
                         assert t["last"] in (0,) or t["last"] <= 64, (i, o, q, ch, t)
     assert min(seen.values()) > 0, seen
     p64 = speexhip.debug_plan64

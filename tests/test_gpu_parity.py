@@ -784,11 +784,13 @@ def test_many_generation_launch_with_ragged_ends():
 
 @pytest.mark.parametrize("ch,i,o,q,S,frames", [(4, 32000, 11025, 7, 8, 131072), (1, 32000, 11025, 7, 32, 131072),
                                                (4, 32000, 11025, 7, 32, 65536), (2, 48000, 11025, 10, 32, 65536),
-                                               (3, 32000, 11025, 7, 8, 200000), (7, 96000, 11025, 5, 4, 131072)])
+                                               (3, 32000, 11025, 7, 8, 200000), (7, 96000, 11025, 5, 4, 131072),
+                                               (8, 96000, 11025, 9, 4, 65536), (1, 64000, 11025, 7, 8, 131072)])
 def test_wide_window_batches_whose_shares_come_from_the_generation_model(ch, i, o, q, S, frames):
     """Round 5: batches of the widest windows (one workgroup per CU) whose phase-group shares the launch now takes from a model of
     workgroup generations -- three shares, two where four were 256 + 32 workgroups -- plus the layouts this round gave an int16
-    window (three channels' two-period plan, the fp64 period kernel) and a ninth of a tile (seven channels at num = 1280):
+    window (three channels' two-period plan, the fp64 period kernel), a ninth of a tile (seven channels at num = 1280) and
+    float plans that exist for their int16 plan's sake (8 channels of 2 232 taps: one period of the float window per tile):
     two calls, ragged lengths, counters and +-1 LSB against the oracle on three streams."""
     import torch
     cap = int(frames * o / i) + 16
