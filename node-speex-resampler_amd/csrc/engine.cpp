@@ -1590,6 +1590,7 @@ int warm_device(int device) {
   warm_unit_slide64_i16(s);
   warm_unit_period_pp(s);
   warm_unit_period_odd(s);
+  warm_unit_period_frames(s);
   warm_unit_period64_w16(s);
   warm_unit_slide_f32(s);
   warm_unit_slide64_f32(s);

@@ -496,7 +496,9 @@ def variants():
         # (1, 3), (1, 5), (1, 7): three-, five- and seven-channel frames on single-channel lanes (round 5): until then
         # those layouts ran the C++ loop, without int16 window or tap-range shares (three channels: an int16 window
         # and shares only through their phase-pair plans)
-        for CT, CF in ((2, 2), (2, 4), (2, 6), (2, 8), (1, 1), (1, 3), (1, 5), (1, 7)):
+        # (2, 10), (2, 12), (2, 16): frames of 10, 12 and 16 channels as 5, 6, 8 channel pairs (late in round 5,
+        # kernels_period_frames.hip): until then those ran the C++ loop -- no int16 window, no tap-range shares
+        for CT, CF in ((2, 2), (2, 4), (2, 6), (2, 8), (1, 1), (1, 3), (1, 5), (1, 7), (2, 10), (2, 12), (2, 16)):
             for padded in (False, True):
                 out.append(Variant(10, 2, CT, CF, padded, w16))
             out.append(Variant(5, R5_STEPS, CT, CF, False, w16))

@@ -10,6 +10,8 @@ hipError_t dispatch_period64(const PeriodPlan &t, const PeriodParams &p, const D
 hipError_t dispatch_period64_w16(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                                  dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
 // the instances for frames of five and seven channels (kernels_period_odd.hip)
+hipError_t dispatch_period_frames(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
+                                  dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);  // kernels_period_frames.hip
 hipError_t dispatch_period_odd(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                                dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
 // the phase-pair instances for mono (kernels_period_pp.hip)
@@ -229,7 +231,10 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   //  profiles/r05_w16_3ch.txt.  SPEEXHIP_W16_3CH=0: as before, A/B)
   static const bool w16_3ch = !(std::getenv("SPEEXHIP_W16_3CH") && std::atoi(std::getenv("SPEEXHIP_W16_3CH")) == 0);
   const bool odd_frame = t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7 || (t.cgroups == 3 && (a64 || w16_3ch)));
-  if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1) || odd_frame)) t.usable = false;
+  // (frames of 10 / 12 / 16 channels -- 5, 6, 8 channel pairs -- have ISA loops of the fp32 chain since late in round 5:
+  //  the int16 window, not the fp64 rows)
+  const bool wide_frame = t.ct == 2 && (t.cgroups == 5 || t.cgroups == 6 || t.cgroups == 8) && !a64;
+  if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1) || odd_frame || wide_frame)) t.usable = false;
   if (t.pp && t.pad != 0 && t.r != 10) t.usable = false;
   return t;
 }
@@ -659,7 +664,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   const bool isa_layout = false;  // (the A/B library without the ISA loop has no tap-range shares either)
 #else
-  const bool isa_layout = t.pp || (t.ct == 1 && (t.cgroups == 1 || t.cgroups == 3 || t.cgroups == 5 || t.cgroups == 7)) || (t.ct == 2 && t.cgroups <= 4);
+  const bool isa_layout = t.pp || (t.ct == 1 && (t.cgroups == 1 || t.cgroups == 3 || t.cgroups == 5 || t.cgroups == 7)) || (t.ct == 2 && (t.cgroups <= 6 || t.cgroups == 8));
 #endif
   // (Round 4, late: an UNSPLIT launch whose workgroups have at most 8 waves takes the shares too.  The FIR loop waits
   //  ~500 cycles for every bank of taps -- a scalar load that misses to L2 -- and only other waves cover that: stamps of
@@ -719,6 +724,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
                  : dispatch_period64(t, p, pack, grid, threads, float_io, stream);
   if (t.pp) return dispatch_period_pp(t, p, pack, grid, threads, float_io, stream);   // kernels_period_pp.hip
   if (t.ct == 1 && (t.cgroups == 3 || t.cgroups == 5 || t.cgroups == 7)) return dispatch_period_odd(t, p, pack, grid, threads, float_io, stream);
+  if (t.ct == 2 && (t.cgroups == 5 || t.cgroups == 6 || t.cgroups == 8)) return dispatch_period_frames(t, p, pack, grid, threads, float_io, stream);
   // (LRC: the kernel of the layout, or its tap-range-shares twin)
 #define SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, W)                                                                                    \
   (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, true>(p, pack, grid, threads, t.window_bytes, stream)              \

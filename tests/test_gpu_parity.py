@@ -691,7 +691,11 @@ def test_window_layout_variants_of_the_period_kernel():
              (8, 48000, 11025, 5), (6, 44100, 16000, 6),
              # round 5: three channels' two-period plan over an int16 window; the widest windows (num = 1280), of which
              # seven channels fit a ninth of a tile's periods
-             (3, 48000, 11025, 7), (3, 32000, 11025, 7), (7, 32000, 11025, 7), (5, 96000, 11025, 6), (4, 32000, 11025, 7)]
+             (3, 48000, 11025, 7), (3, 32000, 11025, 7), (7, 32000, 11025, 7), (5, 96000, 11025, 6), (4, 32000, 11025, 7),
+             # frames of 10 / 12 / 16 channels (5, 6, 8 channel pairs; kernels_period_frames.hip): unpadded, padded, groups of 5,
+             # wide windows (int16 window under SPEEXHIP_W16_ALWAYS, test_int16_window_on_small_launches_too)
+             (10, 44100, 48000, 7), (12, 48000, 44100, 5), (16, 44100, 48000, 4), (12, 44100, 8000, 6), (10, 48000, 11025, 7),
+             (16, 48000, 11025, 5), (12, 32000, 44100, 8)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -785,7 +789,9 @@ def test_many_generation_launch_with_ragged_ends():
 @pytest.mark.parametrize("ch,i,o,q,S,frames", [(4, 32000, 11025, 7, 8, 131072), (1, 32000, 11025, 7, 32, 131072),
                                                (4, 32000, 11025, 7, 32, 65536), (2, 48000, 11025, 10, 32, 65536),
                                                (3, 32000, 11025, 7, 8, 200000), (7, 96000, 11025, 5, 4, 131072),
-                                               (8, 96000, 11025, 9, 4, 65536), (1, 64000, 11025, 7, 8, 131072)])
+                                               (8, 96000, 11025, 9, 4, 65536), (1, 64000, 11025, 7, 8, 131072),
+                                               (12, 48000, 11025, 7, 8, 65536), (16, 44100, 16000, 7, 6, 65536),
+                                               (10, 44100, 48000, 7, 12, 200000)])
 def test_wide_window_batches_whose_shares_come_from_the_generation_model(ch, i, o, q, S, frames):
     """Round 5: batches of the widest windows (one workgroup per CU) whose phase-group shares the launch now takes from a model of
     workgroup generations -- three shares, two where four were 256 + 32 workgroups -- plus the layouts this round gave an int16

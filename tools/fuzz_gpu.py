@@ -70,7 +70,7 @@ def signal(rng, frames, ch, as_float):
 
 def one_trial(seed, max_frames, many_channels=False):
     rng = np.random.RandomState(seed)
-    ch = int(rng.choice([1, 1, 2, 2, 2, 3, 4, 5, 6, 7, 8] + ([9, 12, 16, 24, 32, 64, 65, 100] if many_channels else [])))
+    ch = int(rng.choice([1, 1, 2, 2, 2, 3, 4, 5, 6, 7, 8] + ([9, 10, 10, 12, 12, 16, 16, 24, 32, 64, 65, 100] if many_channels else [])))
     i, o = pick_rates(rng)
     q = int(rng.randint(0, 11))
     mode = speexhip.MODE_EXACT if rng.rand() < 0.35 else speexhip.MODE_FAST
