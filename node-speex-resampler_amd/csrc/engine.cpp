@@ -341,13 +341,13 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
   t->geo = exact_geometry(f, channels, kLdsBudget);
   t->geo_ch = exact_geometry(f, 1, kLdsBudget);
   t->period = plan_period(f, channels, kLdsBudget);
-  if (t->period.usable) {
+  if (t->period.usable && t->period.float_ok) {
     std::vector<float> rows;
     build_period_rows(f, t->period, &rows);
     rc = upload(&t->period_rows, rows.data(), rows.size());
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
-  if (t->period.usable && t->period.r == 10) {
+  if (t->period.usable && t->period.float_ok && t->period.r == 10) {
     static const bool no_fine = std::getenv("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
     t->fine = plan_period_r(f, channels, kLdsBudget, 5);
     if (no_fine || t->fine.lane_periods != t->period.lane_periods) t->fine.usable = false;
@@ -992,7 +992,7 @@ int Batch::launch_chunk(const StreamDesc *descs, const DescPack &pack, uint32_t 
     // wide windows: twice the periods per tile over an int16 LDS image (the histories hold PCM values) -- unless
     // the launch is too small for that to pay (period_launch_prefers_w16)
     e = launch_period(filter_, period_w16_, d_period_w16_rows_, nullptr, nullptr, channels_, descs, &pack, n, false, stream, fixed);
-  } else if (fast && period_.usable) {
+  } else if (fast && period_.usable && period_.float_ok) {
     e = launch_period(filter_, period_, d_period_rows_, &period_fine_, d_period_fine_rows_, channels_, descs, &pack, n,
                       float_io, stream, fixed);
   } else if (fast && slide_.usable) {

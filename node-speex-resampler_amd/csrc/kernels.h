@@ -94,6 +94,8 @@ struct PeriodPlan {         // per filter, fixed at init
   bool pp = false;           // phase pairs (round 4; mono): a lane owns ONE period and 2r phases per group -- a tile is
                              // 64 periods, not 128 (half the window), the rows are [step][2r]
   size_t rows_floats = 0, window_bytes = 0;
+  bool float_ok = true;      // false (late in round 5): not even one period of the FLOAT window fits the LDS; the plan stands for
+                             // its int16-window plan to hang off (int16 calls run over that), float calls take the exact kernel
 };
 PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16 = false, bool a64 = false,
                        bool pp = false);

@@ -70,7 +70,7 @@ PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_bu
   // (phase pairs: a tile is 64 periods either way; what the int16 window buys there is a second and third workgroup
   //  per CU -- taken when the float window leaves room for one only)
   const bool pp_fits_more = t.pp && w.usable && t.window_bytes > 80 * 1024 && w.window_bytes <= 80 * 1024;
-  if (w.usable && !force && !pp_fits_more && 4 * w.lane_periods < (cheap ? 5 : 7) * t.lane_periods) w.usable = false;
+  if (w.usable && !force && !pp_fits_more && t.float_ok && 4 * w.lane_periods < (cheap ? 5 : 7) * t.lane_periods) w.usable = false;
   return w;
 }
 
@@ -221,6 +221,17 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
     filled = i16.usable;
   }
   t.usable = f.den >= 7 && t.cgroups <= 64 && filled && t.window_bytes <= lds_budget;
+  // (... or not even ONE period of the float window fits -- 16 channels at num = 1280 with 1 120 taps: 155 KB -- and the int16
+  //  window holds a ninth of a tile: a plan that exists only for its int16 plan, float_ok = false)
+  if (!t.usable && fit_all == 0 && !w16 && !a64 && !t.pp && f.den >= 7 && t.cgroups <= 64) {
+    const PeriodPlan i16 = plan_period_r(f, channels, lds_budget, r, true, false, false);
+    if (i16.usable) {
+      t.usable = true;
+      t.float_ok = false;
+      t.lane_periods = 1;
+      t.window_bytes = 0;
+    }
+  }
   // an int16 window is read by the ISA loop only: mono, stereo, 4 / 6 / 8 channels (csrc/gen_fir_loop.py); so are the
   // tap rows of an fp64 accumulator
   // (round 5: frames of 5 and 7 single channels have ISA loops too -- int16 window (kernels_period_odd.hip)
@@ -367,6 +378,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 // the ratio has no r = 5 plan, and from T = 32 when the launch is a batch of at least 4 streams.
 bool period_launch_prefers_w16(const FilterSpec &f, const PeriodPlan &t, bool has_fine, const StreamDesc *h_descs,
                                uint32_t n_streams) {
+  if (!t.float_ok) return true;  // (there is no float window to prefer)
   const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
   if (split_count(t, tiles, n_streams, 2 * device_compute_units()) == 1) return true;
@@ -719,6 +731,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   }
   // (an int16 window -- t.w16 -- exists for int16 calls on the layouts the ISA loop is generated for: ONE or CGV)
   if (t.w16 && float_io) return hipErrorInvalidValue;
+  if (!t.float_ok) return hipErrorInvalidValue;  // (a plan that only carries its int16 plan: engine.cpp never launches it)
   if (t.a64)  // kernels_period64.hip / kernels_period64_w16.hip
     return t.w16 ? dispatch_period64_w16(t, p, pack, grid, threads, float_io, stream)
                  : dispatch_period64(t, p, pack, grid, threads, float_io, stream);

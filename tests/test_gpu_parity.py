@@ -695,7 +695,7 @@ def test_window_layout_variants_of_the_period_kernel():
              # frames of 10 / 12 / 16 channels (5, 6, 8 channel pairs; kernels_period_frames.hip): unpadded, padded, groups of 5,
              # wide windows (int16 window under SPEEXHIP_W16_ALWAYS, test_int16_window_on_small_launches_too)
              (10, 44100, 48000, 7), (12, 48000, 44100, 5), (16, 44100, 48000, 4), (12, 44100, 8000, 6), (10, 48000, 11025, 7),
-             (16, 48000, 11025, 5), (12, 32000, 44100, 8)]
+             (16, 48000, 11025, 5), (12, 32000, 44100, 8), (16, 96000, 11025, 7), (12, 96000, 11025, 8)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -1366,7 +1366,9 @@ def test_int16_window_plan_serves_int16_calls_until_a_float_call():
     samples in the history) the stream goes back to the float window for good.  Int16 / float / int16 calls on
     one state against the oracle doing the same, FAST mode within +-1 LSB (float: relative), counters equal;
     and the window kind shows in nothing but speed: SPEEXHIP_NO_W16-style A/B is tools/gpu_ab.sh's job."""
-    for (ch, i, o, q) in [(2, 48000, 11025, 7), (4, 48000, 11025, 5), (2, 44100, 16000, 7)]:
+    # (16 channels 96k -> 11.025k, late in round 5: not even one period of the float window fits the LDS -- the plan exists for its
+    #  int16 plan alone, float calls and every call after one run the exact kernel)
+    for (ch, i, o, q) in [(2, 48000, 11025, 7), (4, 48000, 11025, 5), (2, 44100, 16000, 7), (16, 96000, 11025, 7)]:
         assert speexhip.debug_plan(i, o, q, ch)["w16_lane_periods"] > 0
         r = speexhip.Resampler(ch, i, o, q)
         ref = orc.Oracle(ch, i, o, q)
