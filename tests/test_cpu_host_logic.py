@@ -638,6 +638,31 @@ def test_round5_shares_of_wide_window_launches_count_generations():
     assert shape(2, 44100, 48000, 1, 1 << 20)["splits"] == 2 and shape(2, 44100, 48000, 32, 1 << 20)["splits"] == 1
 
 
+def test_round5_plans_for_wide_frames_and_plans_that_stand_for_their_int16_window():
+    """Late in round 5 (host-only planner checks): frames of 10 / 12 / 16 channels have ISA loops (kernels_period_frames.hip) and
+    with them an int16-window plan; a float-window plan under the fill rule stands when its int16-window plan passes it; and
+    where not even one period of the float window fits (lds_bytes reported as 0) the plan stands for its int16 plan alone --
+    float calls of such a state run the exact kernel (tests/test_gpu_parity.py walks that)."""
+    plan = speexhip.debug_plan
+    # 10 / 12 / 16 channels, a wide window: twice the periods per tile over int16
+    for ch, lp, lp16 in ((10, 5, 11), (12, 4, 9), (16, 2, 6)):
+        t = plan(640, 147, 7, ch)
+        assert (t["fast_path"], t["r_or_p"], t["lane_periods"], t["w16_lane_periods"]) == (2, 10, lp, lp16), (ch, t)
+        assert plan(147, 160, 7, ch)["fast_path"] == 2 and plan(147, 160, 7, ch)["w16_lane_periods"] == 0, ch  # narrow: float window
+    # 9 channels (no ISA loop): no int16 window
+    assert plan(640, 147, 7, 9)["w16_lane_periods"] == 0
+    # 8 channels of 2 232 taps at num = 1280: one period of the float window (a sixteenth of a tile), five of the int16 one
+    t = plan(1280, 147, 10, 8)
+    assert (t["fast_path"], t["lane_periods"], t["w16_lane_periods"]) == (2, 1, 5) and t["lds_bytes"] > 0, t
+    # 16 channels at num = 1280: no float window at all, two periods of the int16 one
+    t = plan(1280, 147, 7, 16)
+    assert (t["fast_path"], t["lane_periods"], t["w16_lane_periods"], t["lds_bytes"]) == (2, 1, 2, 0), t
+    sh = speexhip.debug_launch_shape(1280, 147, 7, 16, 32, 131072)
+    assert sh["int16_window"] and sh["lane_periods"] == 2, sh
+    # ... and a float call of it has nothing to launch from that plan: the shape hook answers for int16 calls only
+    assert speexhip.debug_launch_shape(1280, 147, 7, 16, 32, 131072, True)["r"] in (0, 10)
+
+
 def test_device_placement_rule():
     """Round 5: which GPU a new state lives on (csrc/devices.cpp) as a pure function of the device count, the two
     environment variables and the state's number in its process -- SPEEXHIP_DEVICES=all is BASELINE configs[4]'s
