@@ -292,6 +292,7 @@ int speexhip_debug_launch_shape(uint32_t ratio_num, uint32_t ratio_den, int qual
     const size_t lds = speexhip::lds_budget();
     const speexhip::PeriodPlan base = speexhip::plan_period(f, channels, lds);
     if (!base.usable) return SPEEXHIP_ERR_SUCCESS;
+    if (float_io != 0 && !base.float_ok) return SPEEXHIP_ERR_SUCCESS;  // (a plan that stands for its int16 plan alone: float calls run the exact kernel)
     const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, lds, base);
     speexhip::PeriodPlan pp, pp_w16;
     if (speexhip::period_wants_pp_plans(f, channels)) {

@@ -660,7 +660,7 @@ def test_round5_plans_for_wide_frames_and_plans_that_stand_for_their_int16_windo
     sh = speexhip.debug_launch_shape(1280, 147, 7, 16, 32, 131072)
     assert sh["int16_window"] and sh["lane_periods"] == 2, sh
     # ... and a float call of it has nothing to launch from that plan: the shape hook answers for int16 calls only
-    assert speexhip.debug_launch_shape(1280, 147, 7, 16, 32, 131072, True)["r"] in (0, 10)
+    assert speexhip.debug_launch_shape(1280, 147, 7, 16, 32, 131072, True)["r"] == 0
 
 
 def test_device_placement_rule():
