@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 
+#include "diag.h"
+
 namespace speexhip {
 
 // One stream's share of one processing call.  V = history ++ input is the virtual frame
@@ -67,7 +69,9 @@ struct SlideParams {
   uint32_t row_magic;       // ceil(2^32 / floats per row): division-free row index while staging
   uint32_t threads;         // lanes per workgroup (a kernel argument: blockDim.x would be fetched from the
                             // dispatch packet with a vector load that drains the staging loads in flight)
-  uint32_t skip;            // diagnostics only
+#ifdef SPEEXHIP_DIAG
+  uint32_t skip;            // phase-skipping mask (diag.h): the diagnostics build only
+#endif
   uint32_t base_waves;      // waves that carry lane blocks (= threads / 64 / parts)
   uint32_t parts;           // > 1: tap-range parts, sets of base_waves waves each a range of the iterations
 };
@@ -90,7 +94,9 @@ struct PeriodParams {
   uint32_t period_magic;  // ceil(2^32 / (num*channels)): division-free period index in the padded image
   uint32_t threads;       // lanes per workgroup (see SlideParams::threads)
   uint32_t prio;          // bit 0: prologue + staging at raised wave priority; bit 1: the stores too
-  uint32_t skip;          // diagnostics only (env SPEEXHIP_SKIP), 0 in normal operation
+#ifdef SPEEXHIP_DIAG
+  uint32_t skip;          // phase-skipping mask (SPEEXHIP_SKIP, diag.h): the diagnostics build only
+#endif
   uint32_t ksplit;        // > 1: tap-range shares, this many waves per phase group (fir_tile_parts)
   uint32_t touch;         // != 0: every workgroup fetches the tap rows into L2 beside its window (touch_rows)
 };

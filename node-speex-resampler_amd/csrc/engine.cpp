@@ -153,7 +153,7 @@ const size_t kZeroCopyBelow = 720 * 1024;    // ... and calls whose buffers are 
 struct InitTrace {
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   static bool on() {
-    static const bool v = std::getenv("SPEEXHIP_INIT_TRACE") != nullptr;
+    static const bool v = SPEEXHIP_DIAG_ENV("SPEEXHIP_INIT_TRACE") != nullptr;
     return v;
   }
   void step(const char *what) {
@@ -172,7 +172,7 @@ size_t lds_budget() { return kLdsBudget; }
 // (SPEEXHIP_W16_ALWAYS=0: never -- A/B runs)
 static int w16_env() {
   static const int v = [] {
-    const char *e = std::getenv("SPEEXHIP_W16_ALWAYS");
+    const char *e = SPEEXHIP_DIAG_ENV("SPEEXHIP_W16_ALWAYS");
     return e == nullptr ? -1 : (e[0] == '0' && e[1] == '\0' ? 0 : 1);
   }();
   return v;
@@ -348,7 +348,7 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
   if (t->period.usable && t->period.float_ok && t->period.r == 10) {
-    static const bool no_fine = std::getenv("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
+    static const bool no_fine = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
     t->fine = plan_period_r(f, channels, kLdsBudget, 5);
     if (no_fine || t->fine.lane_periods != t->period.lane_periods) t->fine.usable = false;
     if (t->fine.usable) {
@@ -400,7 +400,7 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
         if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
       }
       if (t->period64.usable && t->period64.r == 10) {
-        static const bool no_fine64 = std::getenv("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
+        static const bool no_fine64 = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
         t->fine64 = plan_period_r(f, channels, kLdsBudget, 5, false, true);
         if (no_fine64 || t->fine64.lane_periods != t->period64.lane_periods) t->fine64.usable = false;
         if (t->fine64.usable) {
@@ -1247,7 +1247,7 @@ int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len
   // lets a launch for the outputs that piece completes start while the next piece is still arriving.  No kernel
   // change: a piece is a StreamDesc of the same call that begins o_i outputs later (positions advanced in integers)
   // and only the last one rolls the history.  SPEEXHIP_PIECES=1 turns it off, =n forces n (A/B, tests).
-  static const int env_pieces = std::getenv("SPEEXHIP_PIECES") ? std::atoi(std::getenv("SPEEXHIP_PIECES")) : 0;
+  static const int env_pieces = SPEEXHIP_DIAG_ENV("SPEEXHIP_PIECES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PIECES")) : 0;
   uint32_t pieces = env_pieces > 0 ? static_cast<uint32_t>(env_pieces) : static_cast<uint32_t>(in_bytes / kPieceBytes);
   pieces = std::min<uint32_t>(pieces, kMaxPieces);
   if (split || zero_mode_) {
@@ -1275,7 +1275,7 @@ int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len
     *done = 0;
     rc = process_device(src, 0, in_len, blk, 0, out_len, float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
-    static const bool poll_done = std::getenv("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
+    static const bool poll_done = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
     bool signalled = false;
     if (poll_done && !direct_in && hipStreamWriteValue32(own_stream_, const_cast<uint32_t *>(done), 1u, 0) == hipSuccess) {
       const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
@@ -1340,7 +1340,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
   // 0.18 us per KB against 0.10 for the runtime's own staged copies -- they cross near 740 KB.  (Until late in
   // round 3 the limit was 256 KB, which sent a 65536-frame stereo chunk down the slower way.)
   static const size_t zero_copy_below = [] {
-    const char *e = std::getenv("SPEEXHIP_ZERO_COPY_BELOW");
+    const char *e = SPEEXHIP_DIAG_ENV("SPEEXHIP_ZERO_COPY_BELOW");
     return e != nullptr ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kZeroCopyBelow;
   }();
   if (!split && in_bytes < zero_copy_below && out_bytes < zero_copy_below) {
@@ -1352,7 +1352,7 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     // the kernel (hipStreamWriteValue32: performed once everything before it on the stream has completed) into
     // pinned memory, polled by the caller, 8.8 (tools/ubench_sync.hip).  A launch that has not signalled after
     // 300 us is waited for -- and its error, if that is what happened, reported -- the ordinary way.
-    static const bool poll_done = std::getenv("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
+    static const bool poll_done = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
     volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(h_pin_out_ + ((pin_out_cap_ - 64) & ~static_cast<size_t>(63)));
     const uint32_t seq = ++done_seq_;
     *done = seq - 1;
@@ -1734,7 +1734,7 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     }
     // Large calls in pieces (below): a launch then carries about 16 MB of input, so that the transfer of the next
     // piece and the results of the previous one have something to overlap with.
-    static const int env_pipe = std::getenv("SPEEXHIP_MANY_PIPELINE") ? std::atoi(std::getenv("SPEEXHIP_MANY_PIPELINE")) : -1;  // A/B: 0 off
+    static const int env_pipe = SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_PIPELINE") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_PIPELINE")) : -1;  // A/B: 0 off
     const bool pipelined = !zero_copy && all_big && env_pipe != 0 && total_in >= (static_cast<size_t>(32) << 20);
     for (auto &kv : groups) {
       std::vector<Item *> &g = kv.second;
@@ -1793,7 +1793,7 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     }
   };
 
-  static const int env_pipe2 = std::getenv("SPEEXHIP_MANY_PIPELINE") ? std::atoi(std::getenv("SPEEXHIP_MANY_PIPELINE")) : -1;
+  static const int env_pipe2 = SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_PIPELINE") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_PIPELINE")) : -1;
   if (!zero_copy && all_big && env_pipe2 != 0 && total_in >= (static_cast<size_t>(32) << 20) && launches.size() >= 2) {
     // Large calls, pipelined (round 5).  PCIe is full duplex, but the runtime's pageable copies keep the thread that
     // issues them busy until they are staged, so one thread alone moves inputs, computes, and moves results strictly
@@ -1957,7 +1957,7 @@ int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in
     std::vector<uint32_t> idx;
   };
   std::vector<Unit> units;
-  static const int env_lanes = std::getenv("SPEEXHIP_MANY_LANES") ? std::atoi(std::getenv("SPEEXHIP_MANY_LANES")) : -1;  // A/B: 1 = never split
+  static const int env_lanes = SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_LANES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_LANES")) : -1;  // A/B: 1 = never split
   for (auto &kv : by_device) {
     uint64_t bytes = 0;
     for (uint32_t i : kv.second) bytes += static_cast<uint64_t>(in_len[i]) * st[i]->channels_ * (float_io ? 4 : 2);

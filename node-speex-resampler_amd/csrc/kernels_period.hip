@@ -30,7 +30,7 @@ const size_t kSlack = 16;  // floats: window starts on the input's 16-byte grid,
 // of 44.1k -> 8k stereo q7 193 -> 88 us, 88.2k -> 48k 69 -> 63, 4 channels 44.1k -> 8k 156 -> 127 (same box).
 uint32_t default_r(const FilterSpec &f) {
   static const uint32_t forced = [] {
-    const char *e = std::getenv("SPEEXHIP_R");
+    const char *e = SPEEXHIP_DIAG_ENV("SPEEXHIP_R");
     return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
   }();
   if (forced == 5 || forced == 10) return forced;
@@ -38,7 +38,7 @@ uint32_t default_r(const FilterSpec &f) {
 }
 // ... of a phase-pair plan: a group is 2r phases, so the same reasoning puts the line at den <= 160
 uint32_t default_r_pp(const FilterSpec &f) {
-  const char *e = std::getenv("SPEEXHIP_R");
+  const char *e = SPEEXHIP_DIAG_ENV("SPEEXHIP_R");
   const uint32_t forced = e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : 0u;
   if (forced == 5 || forced == 10) return forced;
   return (f.den + 19) / 20 <= 8 ? 5u : 10u;
@@ -54,10 +54,10 @@ PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget
 
 PeriodPlan plan_period_w16(const FilterSpec &f, uint32_t channels, size_t lds_budget, const PeriodPlan &t) {
   PeriodPlan w;
-  static const bool off = std::getenv("SPEEXHIP_NO_W16") != nullptr;  // diagnostics: A/B
+  static const bool off = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_W16") != nullptr;  // diagnostics: A/B
   if (!t.usable || off) return w;
   w = plan_period_r(f, channels, lds_budget, t.r, true, t.a64, t.pp);
-  static const bool force = std::getenv("SPEEXHIP_FORCE_W16") != nullptr;  // diagnostics: every layout that has one
+  static const bool force = SPEEXHIP_DIAG_ENV("SPEEXHIP_FORCE_W16") != nullptr;  // diagnostics: every layout that has one
   // What the int16 window costs is two conversions per sample read: +20 % vector instructions where a read
   // feeds 10 packed FMAs (R = 10, channel pairs), +40 % at R = 5, and single-channel lanes convert two
   // 2-byte reads per step.  Measured at 32 streams x 2^20 frames (profiles/r03_w16_ab.txt): stereo 48k->11.025k
@@ -140,9 +140,9 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
       }
     }
   }
-  static const bool no_pad = std::getenv("SPEEXHIP_NO_PAD") != nullptr;
+  static const bool no_pad = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_PAD") != nullptr;
   if (no_pad) t.pad = 0;
-  if (std::getenv("SPEEXHIP_PAD")) t.pad = static_cast<uint32_t>(std::atoi(std::getenv("SPEEXHIP_PAD"))) & ((w16 || t.ct == 2) ? ~1u : ~0u);  // diagnostics
+  if (SPEEXHIP_DIAG_ENV("SPEEXHIP_PAD")) t.pad = static_cast<uint32_t>(std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PAD"))) & ((w16 || t.ct == 2) ? ~1u : ~0u);  // diagnostics
   if (t.pad != 0 && t.r != 10) return t;  // (the padded walk below is written for 4-step iterations)
   if (t.pad != 0) {
     // A padded window is only walked cheaply if every period boundary a group's window crosses
@@ -195,7 +195,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
     }
   }
   t.lane_periods = (fit_half != 0 && 5 * fit_half >= 4 * fit_all) ? fit_half : fit_all;
-  static const bool full_tile = std::getenv("SPEEXHIP_FULL_TILE") != nullptr;  // diagnostics: A/B of the rule above
+  static const bool full_tile = SPEEXHIP_DIAG_ENV("SPEEXHIP_FULL_TILE") != nullptr;  // diagnostics: A/B of the rule above
   if (full_tile) t.lane_periods = fit_all;
   t.window_bytes = t.lane_periods ? window_bytes_for(t.lane_periods) : 0;
   // needs enough phases to fill the R-wide register tile and a window that fits one CU's LDS
@@ -207,10 +207,10 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // (a ninth, late in round 5: seven channels at num = 1280 fit 2 of a tile's 18 periods and still ran the exact kernel --
   //  32 x 131 072 frames of 96k / 32k -> 11.025k 1430 / 1400 us there, 387 / 269 here, one stream 361 -> 133 / 98:
   //  tools/r05_minfill9.sh)
-  static const uint32_t min_fill = std::getenv("SPEEXHIP_MIN_FILL") ? std::max(1, std::atoi(std::getenv("SPEEXHIP_MIN_FILL"))) : 9;
+  static const uint32_t min_fill = SPEEXHIP_DIAG_ENV("SPEEXHIP_MIN_FILL") ? std::max(1, std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MIN_FILL"))) : 9;
   // (the fp64 plans keep the quarter: at quality 10 the same two ratios, 32 streams, took 459 / 898 / 429 / 886 us on the
   //  exact kernel -- bit-exact there -- against 643 / 977 / 473 / 998 here; profiles/r05_wide_windows.txt)
-  const uint32_t fill_rule = a64 && !std::getenv("SPEEXHIP_MIN_FILL") ? 4u : min_fill;
+  const uint32_t fill_rule = a64 && !SPEEXHIP_DIAG_ENV("SPEEXHIP_MIN_FILL") ? 4u : min_fill;
   bool filled = fill_rule * t.lane_periods >= full;
   // (... or its int16-window plan does: 8 channels at num = 1280 with 2 232 taps -- 96k -> 11.025k, quality 8-10 -- fit ONE
   //  period of the float window, a sixteenth of a tile, and three of the int16 one.  The float plan then exists for the
@@ -240,7 +240,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   //  plans had one: one stream of 2^20 frames 48k / 32k / 96k -> 11.025k 40.9 / 76.5 / 67.1 -> 25.1 / 40.4 / 35.2 us,
   //  32 such streams 1555 / 1496 -> 822 / 794; +6.9 % in the geometric mean of 40 launches, five of them 5-13 % slower:
   //  profiles/r05_w16_3ch.txt.  SPEEXHIP_W16_3CH=0: as before, A/B)
-  static const bool w16_3ch = !(std::getenv("SPEEXHIP_W16_3CH") && std::atoi(std::getenv("SPEEXHIP_W16_3CH")) == 0);
+  static const bool w16_3ch = !(SPEEXHIP_DIAG_ENV("SPEEXHIP_W16_3CH") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_W16_3CH")) == 0);
   const bool odd_frame = t.ct == 1 && (t.cgroups == 5 || t.cgroups == 7 || (t.cgroups == 3 && (a64 || w16_3ch)));
   // (frames of 10 / 12 / 16 channels -- 5, 6, 8 channel pairs -- have ISA loops of the fp32 chain since late in round 5:
   //  the int16 window, not the fp64 rows)
@@ -293,7 +293,7 @@ void build_period_rows_t(const FilterSpec &f, const PeriodPlan &t, std::vector<E
     tables[g] = delta;
     tables[t.groups + g] = wrap;
   }
-  static const bool no_trim = std::getenv("SPEEXHIP_NO_TRIM") != nullptr;  // diagnostics: A/B of the trimming
+  static const bool no_trim = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_TRIM") != nullptr;  // diagnostics: A/B of the trimming
   std::vector<double> h(f.taps);
   for (uint32_t g = 0; g < t.groups; g++) {
     const uint64_t d0 = (static_cast<uint64_t>(g) * gw * f.num) / f.den - group_shift(f, t, g);
@@ -346,7 +346,7 @@ uint32_t split_count(const PeriodPlan &t, uint32_t tiles, uint32_t n_streams, ui
   //  about one workgroup per CU, not more -- every share re-stages the window.
   //  Also tried: splitting each group's TAP range over the spare waves of a share, partial sums
   //  meeting in LDS -- +1 us, the two extra barriers cost more than the occupancy gains.)
-  static const uint32_t force_splits = std::getenv("SPEEXHIP_SPLITS") ? std::atoi(std::getenv("SPEEXHIP_SPLITS")) : 0;
+  static const uint32_t force_splits = SPEEXHIP_DIAG_ENV("SPEEXHIP_SPLITS") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_SPLITS")) : 0;
   if (force_splits) return std::min<uint32_t>(force_splits, t.groups);
   uint32_t splits = 1;
   while (splits * 2 <= t.groups && static_cast<uint64_t>(tiles) * n_streams * splits * 2 <= resident / 2 &&
@@ -401,7 +401,7 @@ bool period_launch_prefers_w16(const FilterSpec &f, const PeriodPlan &t, bool ha
 // of several generations whose two-period plan fills under three quarters of its lane slots.  SPEEXHIP_PP=0 / 1:
 // never / whenever planned.
 bool period_wants_pp_plans(const FilterSpec &f, uint32_t channels) {
-  static const int env_pp = std::getenv("SPEEXHIP_PP") ? std::atoi(std::getenv("SPEEXHIP_PP")) : -1;
+  static const int env_pp = SPEEXHIP_DIAG_ENV("SPEEXHIP_PP") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PP")) : -1;
   if (channels > 3 || env_pp == 0) return false;
   // (a full tile of the other lanes -- 128 periods of mono, 64 of stereo, 42 of three channels -- is 512 num bytes
   //  of window: from num = 320 it cannot share a CU)
@@ -409,7 +409,7 @@ bool period_wants_pp_plans(const FilterSpec &f, uint32_t channels) {
 }
 bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const PeriodPlan &pp, const StreamDesc *h_descs,
                               uint32_t n_streams) {
-  static const int env_pp = std::getenv("SPEEXHIP_PP") ? std::atoi(std::getenv("SPEEXHIP_PP")) : -1;
+  static const int env_pp = SPEEXHIP_DIAG_ENV("SPEEXHIP_PP") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PP")) : -1;
   if (env_pp >= 0) return env_pp != 0;
   const uint32_t cus = device_compute_units();
   const uint32_t slots = 64 / two.cgroups * (two.ct == 1 ? 2 : 1);  // periods a full tile of the other plan holds
@@ -439,7 +439,7 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
     // (the tap-range shares of an UNSPLIT launch count only against a plan that leaves lanes unused: two half-chains
     //  are not two chains -- stereo 48k->11.025k in phase pairs with them: 90 us against 79 the other way, whose tiles
     //  are full; three channels, 18 of 42 periods per tile the other way: 32 x 2^20 frames 870 -> 400 us)
-    static const bool count_ks = std::getenv("SPEEXHIP_PP_COUNT_KS") && std::atoi(std::getenv("SPEEXHIP_PP_COUNT_KS")) != 0;  // A/B
+    static const bool count_ks = SPEEXHIP_DIAG_ENV("SPEEXHIP_PP_COUNT_KS") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PP_COUNT_KS")) != 0;  // A/B
     return static_cast<double>(std::min(per_cu, fit)) * sh.wave_groups * ((sh.splits > 1 || unfilled || count_ks) ? sh.ksplit : 1u) / 4.0;
   };
   // (Late in round 4: where the other plan has to SPLIT its tiles over two workgroups -- each stages the whole 150 KB window
@@ -447,7 +447,7 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
   //  stereo 48k->11.025k, 32 x 131 072 frames: 76.6 us the other way, 89.6 in phase pairs without the fetch, 46.2 with;
   //  profiles/r04_pp_touch_ab.txt.  Counting the shares in the rule below instead moved six more stereo rows to phase
   //  pairs, +6 % each: profiles/r04_rule3_ab.txt.)
-  static const bool split_rule_off = std::getenv("SPEEXHIP_PP_SPLIT_RULE") && std::atoi(std::getenv("SPEEXHIP_PP_SPLIT_RULE")) == 0;  // A/B
+  static const bool split_rule_off = SPEEXHIP_DIAG_ENV("SPEEXHIP_PP_SPLIT_RULE") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PP_SPLIT_RULE")) == 0;  // A/B
   if (!split_rule_off && so.splits > 1 && sp.splits == 1 && sp.ksplit > 1) return true;
   const double wo = waves_per_simd(two, so), wp = waves_per_simd(pp, sp);
   if (wp < 3.5 || wp < wo) return false;
@@ -532,7 +532,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   //  group's trips instead of leaving: mono one stream 13.22 -> 13.94 us, a 441 000-frame stereo call 8.52 -> 9.02,
   //  float 9.37 -> 10.10; only launches of a few tiles gained (16 384 frames 7.14 -> 6.36 us): the two barriers and
   //  the pass through LDS cost more than the halved loop saves.  Removed; profiles/r03_ab_ksplit.txt.)
-  static const uint32_t max_waves = std::getenv("SPEEXHIP_WAVES") ? std::atoi(std::getenv("SPEEXHIP_WAVES")) : 16;
+  static const uint32_t max_waves = SPEEXHIP_DIAG_ENV("SPEEXHIP_WAVES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_WAVES")) : 16;
   uint32_t splits = split_count(t, tiles, n_streams, resident);
   // split_count doubles the shares by workgroup count alone.  Where that leaves a share more phase groups than a
   // workgroup has waves (8k -> 44.1k: 45 groups in 2 shares, the waves walk two groups each: 29.5 us for one
@@ -540,8 +540,8 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // fitted to the launches of profiles/r03_small_decimators.txt: a wave alone on its SIMD spends ~19 cycles per
   // packed FMA, w of them together 4.75 w; a workgroup takes its window in at ~11 bytes per cycle; workgroups
   // beyond one per CU queue.  A candidate must beat the incumbent by 10 %.
-  static const bool model_off = std::getenv("SPEEXHIP_SPLIT_MODEL") && std::atoi(std::getenv("SPEEXHIP_SPLIT_MODEL")) == 0;  // A/B (0: neither model)
-  if (splits > 1 && !model_off && !std::getenv("SPEEXHIP_SPLITS")) {
+  static const bool model_off = SPEEXHIP_DIAG_ENV("SPEEXHIP_SPLIT_MODEL") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_SPLIT_MODEL")) == 0;  // A/B (0: neither model)
+  if (splits > 1 && !model_off && !SPEEXHIP_DIAG_ENV("SPEEXHIP_SPLITS")) {
     const double cus = device_compute_units();
     auto cost = [&](uint32_t s) {
       const double wg_per_cu = std::ceil(static_cast<double>(tiles) * n_streams * s / cus);
@@ -570,11 +570,11 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // workgroup stages its window at ~5 bytes per cycle (all CUs at once) and then spends 4.75 cycles per packed FMA and
   // SIMD on the groups of its share, its slowest wave at least `walks` chains; within +-15 % of the measured launches,
   // argmin within 6 % of the best measured on 25 of the 27.  A candidate has to beat fewer shares by 10 %.
-  static const bool wide_model_off = std::getenv("SPEEXHIP_SPLIT_MODEL") && std::atoi(std::getenv("SPEEXHIP_SPLIT_MODEL")) <= 1;  // A/B: 1 = rounds 3-4
+  static const bool wide_model_off = SPEEXHIP_DIAG_ENV("SPEEXHIP_SPLIT_MODEL") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_SPLIT_MODEL")) <= 1;  // A/B: 1 = rounds 3-4
   // Only where the count above does not fit one generation: inside one, its shares (and the tap-range shares they allow)
   // are the better-fitted choice -- the model in their place lost 25-40 % on one-stream and mono launches
   // (profiles/r05_ab_split_model.txt, first table).
-  if (t.window_bytes > 80 * 1024 && !wide_model_off && !std::getenv("SPEEXHIP_SPLITS") && max_periods != 0 &&
+  if (t.window_bytes > 80 * 1024 && !wide_model_off && !SPEEXHIP_DIAG_ENV("SPEEXHIP_SPLITS") && max_periods != 0 &&
       !(probe != nullptr && probe->rounds_3_4) &&
       static_cast<uint64_t>(tiles) * n_streams * splits + n_streams > device_compute_units()) {
     // (of the history-roll blocks only those of share 0 do anything; the others leave at once)
@@ -625,10 +625,12 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   p.threads = 0;  // set below
   // bit 0: prologue + staging raised, bit 1: stores raised, bit 2 (measured slower, see set_fir_priority): the two
   // workgroups of a CU at different FIR priorities
-  static const int env_prio = std::getenv("SPEEXHIP_PRIO") ? std::atoi(std::getenv("SPEEXHIP_PRIO")) : 3;
+  static const int env_prio = SPEEXHIP_DIAG_ENV("SPEEXHIP_PRIO") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PRIO")) : 3;
   p.prio = static_cast<uint32_t>(env_prio);
-  static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
+#ifdef SPEEXHIP_DIAG
+  static const uint32_t skip_mask = static_cast<uint32_t>(diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_SKIP"), 0));
   p.skip = skip_mask;
+#endif
   // touch_rows (kernels_period_impl.h): every workgroup fetches the tap rows into L2 once its window is in LDS.  Pays
   // where the rows are NOT in L2 when the FIR loop starts -- a first call, or a launch whose own samples (and the
   // launch before it) replace the L2s' 32 MB -- and the table is large; costs a trip to HBM per workgroup (~2 us,
@@ -643,7 +645,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // generation or more whose rows are >= 256 KB -- those rows never survived from one launch to the next (stereo
   // 48k->11.025k, 415 KB, 20.7 MB moved: 89.6 us without, 46.2 with; at 210 KB, stereo 48k->22.05k: 40.1 -> 42.3, so not
   // there: profiles/r04_pp_touch_ab.txt, r04_rule4_ab.txt).
-  static const int env_touch = std::getenv("SPEEXHIP_TOUCH") ? std::atoi(std::getenv("SPEEXHIP_TOUCH")) : -1;  // A/B
+  static const int env_touch = SPEEXHIP_DIAG_ENV("SPEEXHIP_TOUCH") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_TOUCH")) : -1;  // A/B
   {
     const size_t rows_bytes = t.rows_floats * (t.a64 ? 8 : 4);
     uint64_t moved = 0;  // bytes in + out
@@ -651,9 +653,9 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
       moved += (static_cast<uint64_t>(h_descs[i].in_frames) + h_descs[i].n_out) * channels * (float_io ? 4 : 2);
     // (A/B: SPEEXHIP_TOUCH_RULE=2 fetches in every launch of half a generation or more -- stereo 48k->11.025k the same
     //  46 us, ten more rows of the sweep +3...7 % on warm caches: profiles/r04_rule2_ab.txt)
-    static const bool wide_rule = std::getenv("SPEEXHIP_TOUCH_RULE") && std::atoi(std::getenv("SPEEXHIP_TOUCH_RULE")) == 2;
+    static const bool wide_rule = SPEEXHIP_DIAG_ENV("SPEEXHIP_TOUCH_RULE") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_TOUCH_RULE")) == 2;
     const bool half_generation = 2ull * tiles * n_streams * splits >= device_compute_units();
-    static const bool pp_rule = !(std::getenv("SPEEXHIP_TOUCH_RULE") && std::atoi(std::getenv("SPEEXHIP_TOUCH_RULE")) == 1);  // A/B: 1 = by bytes only
+    static const bool pp_rule = !(SPEEXHIP_DIAG_ENV("SPEEXHIP_TOUCH_RULE") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_TOUCH_RULE")) == 1);  // A/B: 1 = by bytes only
     // (set below: the tap-range shares; an unsplit launch of 8-wave groups takes them whenever its chain is long)
     const bool pp_shares = t.pp && splits == 1 && t.r == 10 && wave_groups * 2 <= max_waves;
     const bool wanted = env_touch >= 0 ? env_touch != 0
@@ -663,7 +665,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   }
   // A workgroup that owns only a share of the groups still stages the whole window: lend it the
   // waves it has no groups for, they leave after the staging barrier.
-  static const int env_helpers = std::getenv("SPEEXHIP_HELPERS") ? std::atoi(std::getenv("SPEEXHIP_HELPERS")) : 1;
+  static const int env_helpers = SPEEXHIP_DIAG_ENV("SPEEXHIP_HELPERS") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_HELPERS")) : 1;
   const bool helpers = env_helpers != 0 && splits > 1;
   // Tap-range shares (fir_tile_parts): a split launch whose waves each carry a long chain -- R x row_len packed
   // FMAs, alone on their SIMD -- gives every group as many waves as the workgroup has room for.  From 1 800 FMAs
@@ -671,7 +673,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   // 8.7; BASELINE configs[1]'s one-generation plan, R = 5 x 140 = 700, lost 0.7 us of 13.2 with the same scheme), with
   // at least 4 trips per part, the partial sums inside the window, an ISA loop for the layout (frames of 1, 2,
   // 4, 6, 8 channels) and one group per wave-set.  SPEEXHIP_KSPLIT=0 turns it off, =n forces n parts (A/B, tests).
-  static const int env_ksplit = std::getenv("SPEEXHIP_KSPLIT") ? std::atoi(std::getenv("SPEEXHIP_KSPLIT")) : -1;
+  static const int env_ksplit = SPEEXHIP_DIAG_ENV("SPEEXHIP_KSPLIT") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_KSPLIT")) : -1;
   p.ksplit = 1;
 #ifdef SPEEXHIP_CXX_FIR_LOOP
   const bool isa_layout = false;  // (the A/B library without the ISA loop has no tap-range shares either)
@@ -684,7 +686,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   //  wave spends 355 000 cycles on 6 480 packed FMAs, 55 cycles each, whether it shares its CU or not
   //  (profiles/r04_stamps_3ch_pp.txt).  Two waves per group: 157 -> 92 us; mono 48k -> 22.05k 35.5 -> 26.2,
   //  3 channels 44.1k -> 16k 89 -> 61: profiles/r04_ks_ab.txt.)
-  static const bool unsplit_ks_off = std::getenv("SPEEXHIP_KS_UNSPLIT") && std::atoi(std::getenv("SPEEXHIP_KS_UNSPLIT")) == 0;  // A/B
+  static const bool unsplit_ks_off = SPEEXHIP_DIAG_ENV("SPEEXHIP_KS_UNSPLIT") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_KS_UNSPLIT")) == 0;  // A/B
   // (R = 10 only: the R = 5 instances with shares take 76 VGPRs -- one 16-wave workgroup per CU where two of 8 waves
   //  ran: stereo 44.1k->8k in phase pairs 52.5 -> 57 us)
   const bool unsplit_ks = splits == 1 && t.r == 10 && !unsplit_ks_off;
@@ -698,7 +700,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
       parts--;
     // (two parts on a chip already more than half full buy nothing: there the launch is throughput, not one
     //  wave's latency -- 32 mono streams x 131 072 frames of 48k -> 22.05k in 2 shares: 44.8 us without, 48.7 with)
-    static const bool crowded_off = std::getenv("SPEEXHIP_KS_CROWDED") && std::atoi(std::getenv("SPEEXHIP_KS_CROWDED")) == 0;  // A/B
+    static const bool crowded_off = SPEEXHIP_DIAG_ENV("SPEEXHIP_KS_CROWDED") && std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_KS_CROWDED")) == 0;  // A/B
     const bool crowded = !crowded_off && static_cast<uint64_t>(tiles) * n_streams * splits * 2 > device_compute_units();
     // (a wave's chain in vector instructions: one packed FMA per tap, two v_fma_f64 with an fp64 accumulator)
     if (parts > 1 && (env_ksplit > 0 || (static_cast<uint64_t>(t.r) * t.row_len * (t.a64 ? 2 : 1) >= 1800 && (unsplit_ks || !(crowded && parts < 3)))))
@@ -719,7 +721,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
   if (splits > 1 && n_streams == 1) grid_x = (grid_x + 7) / 8 * 8;
   const dim3 grid(grid_x, n_streams, splits);
   // diagnostics: one line per launch shape on stderr
-  static const bool verbose = std::getenv("SPEEXHIP_PLAN_VERBOSE") != nullptr;
+  static const bool verbose = SPEEXHIP_DIAG_ENV("SPEEXHIP_PLAN_VERBOSE") != nullptr;
   if (verbose) {
     static uint64_t last = 0;
     const uint64_t key = (static_cast<uint64_t>(tiles) << 40) ^ (static_cast<uint64_t>(n_streams) << 24) ^ (splits << 16) ^ (t.r << 8) ^ p.ksplit ^ (t.w16 ? 1u << 31 : 0u);

@@ -831,18 +831,18 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
     const unsigned long long fir_t0 = __builtin_amdgcn_s_memtime(), fir_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if constexpr (AM == 2) {
-      fir_group_pp<R, ONE_GROUP ? 1 : CGF, PADDED, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, 0u, 1u, acc);
+      fir_group_pp<R, ONE_GROUP ? 1 : CGF, PADDED, W16>(p, rows, xs, c, g, SPEEXHIP_DIAG_SKIP(p, 4u), 0u, 1u, acc);
     } else if constexpr (AM == 1) {
       // fp64 sums, then the reference's store of its double sum into a float (resample.c:417, :544)
       double acc64[R][2];
 #pragma unroll
       for (int i = 0; i < R; i++) acc64[i][0] = acc64[i][1] = 0.0;
       fir_group64<R, CT, PADDED, ONE_GROUP ? CT : CT * CGF, W16>(p, reinterpret_cast<const double *>(rows), xs, c, g,
-                                                                (p.skip & 4u) != 0, 0u, 1u, acc64);
+                                                                SPEEXHIP_DIAG_SKIP(p, 4u), 0u, 1u, acc64);
 #pragma unroll
       for (int i = 0; i < R; i++) acc[i] = f32x2{static_cast<float>(acc64[i][0]), static_cast<float>(acc64[i][1])};
     } else {
-      fir_group<R, CT, PADDED, ONE_GROUP ? CT : CT * CGF, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, acc);
+      fir_group<R, CT, PADDED, ONE_GROUP ? CT : CT * CGF, W16>(p, rows, xs, c, g, SPEEXHIP_DIAG_SKIP(p, 4u), acc);
     }
 #ifdef SPEEXHIP_STAMPS
     {
@@ -859,7 +859,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
     STAMP(5);
     const PeriodParams q = params();  // (... and the far side)
     if constexpr (kRows && sizeof(T) == 2 && R == 10) {
-      if (!(q.skip & 8u)) {  // (every lane: the transposes exchange data between the rows of the wave)
+      if (!SPEEXHIP_DIAG_SKIP(q, 8u)) {  // (every lane: the transposes exchange data between the rows of the wave)
         StreamDesc d;
         if constexpr (kReload)
           d = load_k(dp);
@@ -870,7 +870,7 @@ __device__ __forceinline__ void fir_tile(const PeriodParams &p0, const StreamDes
         if (q.prio & 2u) set_fir_priority(q);
         STAMP(6);
       }
-    } else if (!(q.skip & 8u) && c.live) {
+    } else if (!SPEEXHIP_DIAG_SKIP(q, 8u) && c.live) {
       StreamDesc d;
       if constexpr (kReload)
         d = load_k(dp);
@@ -910,7 +910,7 @@ __device__ __forceinline__ void fir_group_part(const PeriodParams &p, const floa
   constexpr uint32_t EB = W16 ? 2u : 4u;  // bytes per window element
   auto sgpr = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
   const uint32_t delta_g = p.delta[g];
-  const uint32_t trips = (p.skip & 4u) ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
+  const uint32_t trips = SPEEXHIP_DIAG_SKIP(p, 4u) ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
   const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u, total = trips >> 8;
   const uint32_t t0 = sgpr(total * part / parts), t1 = sgpr(total * (part + 1) / parts);
   auto overlap = [&](uint32_t lo, uint32_t hi) {  // trips of [t0, t1) inside [lo, hi)
@@ -968,7 +968,7 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
     g = zsplit * wg + gw;
     valid = g < p.groups;
     if constexpr (PP) {
-      if (valid) fir_group_pp<R, ONE_GROUP ? 1 : CGF, PADDED, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, part, parts, acc);
+      if (valid) fir_group_pp<R, ONE_GROUP ? 1 : CGF, PADDED, W16>(p, rows, xs, c, g, SPEEXHIP_DIAG_SKIP(p, 4u), part, parts, acc);
     } else {
       if (valid) fir_group_part<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, part, parts, acc);
     }
@@ -997,13 +997,13 @@ __device__ __forceinline__ void fir_tile_parts(KParams pp, const float *__restri
   STAMP(12);  // (partial sums added)
   const PeriodParams q = load_k(pp);
   if constexpr (PADDED && CGF == 4 && !W16 && !PP && sizeof(T) == 2 && R == 10) {
-    if (q.skip & 8u) return;
+    if (SPEEXHIP_DIAG_SKIP(q, 8u)) return;
     const StreamDesc d = load_k(dp);
     store_group_rows<R>(q, d, c, g, c.live, acc);  // (every lane of the wave: see there)
     STAMP(6);
     return;
   }
-  if ((q.skip & 8u) || !c.live) return;
+  if (SPEEXHIP_DIAG_SKIP(q, 8u) || !c.live) return;
   const StreamDesc d = load_k(dp);
   if constexpr (PP)
     store_group_pp<R, ONE_GROUP ? 1 : CGF, T>(q, d, c, g, acc);
@@ -1036,7 +1036,7 @@ __device__ __forceinline__ void fir_tile_parts64(KParams pp, const double *__res
     }
     g = zsplit * wg + gw;
     valid = g < p.groups;
-    if (valid) fir_group64<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, (p.skip & 4u) != 0, part, parts, acc);
+    if (valid) fir_group64<R, CT, PADDED, CF, W16>(p, rows, xs, c, g, SPEEXHIP_DIAG_SKIP(p, 4u), part, parts, acc);
   }
   __syncthreads();  // every wave is done with the window
   double *sums = reinterpret_cast<double *>(xs);
@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void fir_tile_parts64(KParams pp, const double *__res
     }
   }
   const PeriodParams q = load_k(pp);
-  if ((q.skip & 8u) || !c.live) return;
+  if (SPEEXHIP_DIAG_SKIP(q, 8u) || !c.live) return;
   const StreamDesc d = load_k(dp);
   f32x2 out[R];
 #pragma unroll
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
                             PADDED ? p.period_magic : 0u, &wg))
     wg = window_geom<T>(d, p.channels, p.num, p.tail_frames, m_lo, m_cnt, p.threads, PADDED ? p.pad : 0u,
                         PADDED ? p.period_magic : 0u);
-  if (p.skip & 64u) return;  // diagnostics: bare dispatch cost
+  if (SPEEXHIP_DIAG_SKIP(p, 64u)) return;  // diagnostics: bare dispatch cost
   if (blockIdx.x == p.history_block) {
     if (blockIdx.z == 0) roll_history<T>(p.channels, d, p.threads);
     return;
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
   if (d.n_out == 0 || blockIdx.x > p.history_block || m_lo >= m_total) return;
   STAMP(1);
   uint32_t row_sink = 0;
-  if (!(p.skip & 2u)) {
+  if (!SPEEXHIP_DIAG_SKIP(p, 2u)) {
     // 5 x 16 bytes per lane in flight: a 76 KB window staged by 1024 lanes in one round of loads
     // (the padded commit needs more registers per group: 3 there keeps the kernel at 8 waves per SIMD)
     // (float samples: 4 -- five float groups in flight spill at the 64 VGPRs of 8 waves per SIMD)
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(1024, (R == 10 && !KS) ? 8 : 4) __attribute__((amdg
   __syncthreads();
   if (p.prio & 7u) set_fir_priority(p);
   STAMP(4);
-  if (p.skip & 128u) return;  // diagnostics: prologue + staging only
+  if (SPEEXHIP_DIAG_SKIP(p, 128u)) return;  // diagnostics: prologue + staging only
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // (KS: the instances of tap-range shares are kernels of their own -- as a run-time branch of the one kernel the
   //  second path cost the first its registers: 64 VGPRs and 28 bytes of scratch in the BASELINE configs[1] instance)

@@ -94,7 +94,7 @@ SlidePlan plan_slide(const FilterSpec &f, uint32_t channels) {
   } else {
     if (t.row_stride % 2 == 0) t.row_stride += 1;
   }
-  if (const char *e = std::getenv("SPEEXHIP_SLIDE_PAD")) t.row_stride = row_elems + static_cast<uint32_t>(std::atoi(e));  // diagnostics
+  if (const char *e = SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_PAD")) t.row_stride = row_elems + static_cast<uint32_t>(std::atoi(e));  // diagnostics
   // a long filter on many channels (12:1 q10 on 8 channels: 200 KB with 8 waves) runs smaller workgroups
   // (launch_slide); one that does not even fit two waves runs the exact kernel
   if (slide_lds_bytes(t, 2) > kSlideLdsLimit) t.usable = false;
@@ -131,7 +131,7 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   // (8 waves per workgroup: the kernel's 96 SGPRs admit 7 waves per SIMD, i.e. three such
   //  workgroups per CU but only one of 16 waves; measured 16 -> 8: 2:1 decimation 241 -> 205 us,
   //  16k->48k mono 463 -> 425 us, the rest within 2 %)
-  static const uint32_t max_waves = std::getenv("SPEEXHIP_SLIDE_WAVES") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_WAVES")) : 8;
+  static const uint32_t max_waves = SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_WAVES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_WAVES")) : 8;
   uint32_t waves = max_waves;
   while (waves > 2 && static_cast<uint64_t>(max_periods) * n_streams < 512ull * waves * blocks_per_wave * t.p)
     waves /= 2;
@@ -147,8 +147,10 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   p.blocks_per_tile = blocks_per_wave * waves;
   p.row_stride = t.row_stride;
   p.row_magic = period_magic_of(t.p * f.num * channels);
-  static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
+#ifdef SPEEXHIP_DIAG
+  static const uint32_t skip_mask = static_cast<uint32_t>(diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_SKIP"), 0));
   p.skip = skip_mask;
+#endif
   const uint32_t tile_periods = p.blocks_per_tile * t.p;
   const uint32_t tiles = (max_periods + tile_periods - 1) / tile_periods;
   // LDS: one row per lane block, + the rows the last lane's window runs into
@@ -159,7 +161,7 @@ hipError_t launch_slide(const FilterSpec &f, const SlidePlan &t, const float *d_
   // frames as for 441 000).  Such a launch gives each wave's lane blocks to `parts` waves, a range of the
   // iterations each; the sums meet in LDS behind a barrier (kernels_slide_impl.h).  SPEEXHIP_SLIDE_PARTS=0 turns
   // it off, =n forces n (A/B, tests).
-  static const int env_parts = std::getenv("SPEEXHIP_SLIDE_PARTS") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_PARTS")) : -1;
+  static const int env_parts = SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_PARTS") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_PARTS")) : -1;
   p.base_waves = waves;
   p.parts = 1;
   {
@@ -262,7 +264,7 @@ hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double 
     max_periods = std::max<uint32_t>(max_periods, static_cast<uint32_t>((k_end + f.den - 1) / f.den));
   }
   const uint32_t blocks_per_wave = 64 / t.cgroups;
-  static const uint32_t max_waves = std::getenv("SPEEXHIP_SLIDE_WAVES") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_WAVES")) : 8;
+  static const uint32_t max_waves = SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_WAVES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_WAVES")) : 8;
   uint32_t waves = max_waves;
   while (waves > 2 && static_cast<uint64_t>(max_periods) * n_streams < 512ull * waves * blocks_per_wave * t.p)
     waves /= 2;
@@ -279,14 +281,16 @@ hipError_t launch_slide64(const FilterSpec &f, const SlidePlan &t, const double 
   p.blocks_per_tile = blocks_per_wave * waves;
   p.row_stride = t.row_stride;
   p.row_magic = period_magic_of(t.p * f.num * channels);
-  static const uint32_t skip_mask = std::getenv("SPEEXHIP_SKIP") ? std::atoi(std::getenv("SPEEXHIP_SKIP")) : 0;
+#ifdef SPEEXHIP_DIAG
+  static const uint32_t skip_mask = static_cast<uint32_t>(diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_SKIP"), 0));
   p.skip = skip_mask;
+#endif
   const uint32_t tile_periods = p.blocks_per_tile * t.p;
   const uint32_t tiles = (max_periods + tile_periods - 1) / tile_periods;
   size_t lds = slide_lds_bytes(t, waves) * eb;
   dim3 grid((max_periods == 0 ? 0 : tiles) + 1, n_streams, 1);
   // tap-range parts, by the slide kernel's rule (a wave's chain here: P x den x row_len fp64 FMAs)
-  static const int env_parts = std::getenv("SPEEXHIP_SLIDE_PARTS") ? std::atoi(std::getenv("SPEEXHIP_SLIDE_PARTS")) : -1;
+  static const int env_parts = SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_PARTS") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_SLIDE_PARTS")) : -1;
   p.base_waves = waves;
   p.parts = 1;
   {

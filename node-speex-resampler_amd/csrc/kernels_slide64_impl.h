@@ -98,7 +98,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
                             p.row_magic, &wg, P * NUM * C))
     wg = window_geom<T>(d, C, NUM, NUM + p.row_len + P * NUM, m_lo, m_cnt, p.threads, p.row_stride - P * NUM * C,
                         p.row_magic, P * NUM * C);
-  if (!(p.skip & 2u)) {
+  if (!SPEEXHIP_DIAG_SKIP(p, 2u)) {
     u32x4 w[4];
     window_fetch<4, T>(wg, w);
     window_commit<4, T, E>(xs, d, wg, w);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
 #pragma unroll
   for (int j = 0; j < RING; j++) ring[j] = 0.0;
   const double *__restrict__ trow = rows;  // wave-uniform, __restrict__ kernel argument -> s_load
-  uint32_t n_it = (p.skip & 4u) ? 0 : p.row_len / U;  // even (plan_slide64)
+  uint32_t n_it = SPEEXHIP_DIAG_SKIP(p, 4u) ? 0 : p.row_len / U;  // even (plan_slide64)
   if (p.parts > 1) {
     const uint32_t pairs = n_it / 2;
     const uint32_t it0 = pairs * part / p.parts * 2, it1 = pairs * (part + 1) / p.parts * 2;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
         for (int r = 0; r < DEN; r++) acc[pp][r] += theirs[(pp * DEN + r) * 64];
     }
   }
-  if (p.skip & 8u) return;
+  if (SPEEXHIP_DIAG_SKIP(p, 8u)) return;
 
   // ---- fp64 -> fp32 (the reference stores its double sum into a float, resample.c:417 / :544) -> round,
   //      interleave, store: N = P*DEN consecutive output frames of this lane's channel --------------------

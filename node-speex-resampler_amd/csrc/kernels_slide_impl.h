@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
                             p.row_magic, &wg, P * NUM * C))
     wg = window_geom<T>(d, C, NUM, NUM + p.row_len + P * NUM, m_lo, m_cnt, p.threads, p.row_stride - P * NUM * C,
                         p.row_magic, P * NUM * C);
-  if (!(p.skip & 2u)) {
+  if (!SPEEXHIP_DIAG_SKIP(p, 2u)) {
     u32x4 w[4];
     window_fetch<4, T>(wg, w);
     window_commit<4, T>(xs, d, wg, w);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
       win[IDX / 2].y = *px;
   };
   const float *__restrict__ trow = rows;  // wave-uniform, __restrict__ kernel argument -> s_load
-  uint32_t n_it = (p.skip & 4u) ? 0 : p.row_len / U;  // even
+  uint32_t n_it = SPEEXHIP_DIAG_SKIP(p, 4u) ? 0 : p.row_len / U;  // even
   if (p.parts > 1) {  // this set's range of iterations, on even bounds (the loop runs them in pairs)
     const uint32_t pairs = n_it / 2;
     const uint32_t it0 = pairs * part / p.parts * 2, it1 = pairs * (part + 1) / p.parts * 2;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(96))) void res
         for (int r = 0; r < NP; r++) acc[pp][r] += theirs[(pp * NP + r) * 64];
     }
   }
-  if (!lane_live || (p.skip & 8u)) return;
+  if (!lane_live || SPEEXHIP_DIAG_SKIP(p, 8u)) return;
 
   // ---- round, interleave, store: P*den consecutive output frames of this lane -----------------
   const uint64_t K0 = static_cast<uint64_t>(m_lo + lb * P) * p.den;

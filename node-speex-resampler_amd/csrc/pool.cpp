@@ -1,6 +1,8 @@
 // pool.cpp -- see pool.h.
 #include "pool.h"
 
+#include "diag.h"
+
 #include <algorithm>
 #include <chrono>
 #include <iterator>
@@ -54,7 +56,7 @@ struct MissTimer {
   size_t bytes;
   std::chrono::steady_clock::time_point t0;
   static bool on() {
-    static const bool v = std::getenv("SPEEXHIP_POOL_TRACE") != nullptr;
+    static const bool v = SPEEXHIP_DIAG_ENV("SPEEXHIP_POOL_TRACE") != nullptr;
     return v;
   }
   MissTimer(const char *w, size_t b) : what(w), bytes(b), t0(std::chrono::steady_clock::now()) {}

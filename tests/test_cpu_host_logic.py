@@ -742,3 +742,30 @@ R.default.initPromise.then(async () => {
     assert out["manyEmpty"] == 0 and out["deviceCount"] == "number"
     assert "mode must be" in out["mode"]
     assert out["worker"] == "Chunk length should be a multiple of channels * 2 bytes"
+
+
+def test_product_library_reads_only_the_documented_environment():
+    """a stray environment variable must not be able to change a drop-in's bytes.  The experiment
+    switches of rounds 2-5 (SPEEXHIP_R, _KSPLIT, _SKIP, _PIECES ...) exist only in the diagnostics build
+    (csrc/diag.h, ab/libspeexhip_diag.so); the shipped library, the addon and index.js read exactly the list below --
+    placement, memory limits, start-up: nothing that changes a sample except SPEEXHIP_MODE, which is the documented
+    way to pick the numerical contract."""
+    pkg = os.path.join(ROOT, "node-speex-resampler_amd")
+
+    def names(path):
+        return set(m.decode() for m in re.findall(rb"SPEEXHIP_[A-Z0-9_]+", open(path, "rb").read()))
+
+    constants = re.compile(r"SPEEXHIP_(ERR|MODE|KERNEL)_\w+|SPEEXHIP_API|SPEEXHIP_RESAMPLER_H")
+    lib = {n for n in names(os.path.join(pkg, "libspeexhip.so")) if not constants.fullmatch(n)}
+    assert lib == {"SPEEXHIP_DEVICE", "SPEEXHIP_DEVICES", "SPEEXHIP_ALIAS_DEVICES", "SPEEXHIP_MODE", "SPEEXHIP_POOL_MB",
+                   "SPEEXHIP_TAKE_MB", "SPEEXHIP_TAKE_MAX_MB"}, sorted(lib)
+    getenv = re.compile(r'getenv\("(SPEEXHIP_\w+)"\)|process\.env\.(SPEEXHIP_\w+)')
+    read = set()
+    for rel in ("napi/speex_hip_napi.c", "index.js"):
+        for m in getenv.finditer(open(os.path.join(pkg, rel)).read()):
+            read.add(m.group(1) or m.group(2))
+    assert read <= {"SPEEXHIP_NAPI_COPY", "SPEEXHIP_NO_WARMUP", "SPEEXHIP_MODE", "SPEEXHIP_DEVICES"}, sorted(read)
+    # ... and the diagnostics build is where the switches went
+    diag = os.path.join(pkg, "ab", "libspeexhip_diag.so")
+    assert os.path.exists(diag), "make diag"
+    assert {"SPEEXHIP_SKIP", "SPEEXHIP_KSPLIT", "SPEEXHIP_PIECES", "SPEEXHIP_R"} <= names(diag)

@@ -27,6 +27,17 @@ MISMATCH_RATE = 5e-3   # measured (tools/num_check.py, cfg2, 2^20 frames): 4.4e-
                        # re-association error| in LSB; every differing sample differs by exactly 1
 
 
+DIAG_LIB = os.path.join(ROOT, "node-speex-resampler_amd", "ab", "libspeexhip_diag.so")
+
+
+def diag_env(**switches):
+    """Environment of a child process that runs on the DIAGNOSTICS build of the library (csrc/diag.h: `make diag`,
+    -DSPEEXHIP_DIAG): the experiment switches that force a launch shape exist only there -- libspeexhip.so reads
+    none of them -- and the bindings load it through SPEEXHIP_LIB_PATH."""
+    assert os.path.exists(DIAG_LIB), "ab/libspeexhip_diag.so not built (make -C node-speex-resampler_amd diag)"
+    return dict(os.environ, SPEEXHIP_LIB_PATH=DIAG_LIB, **switches)
+
+
 def assert_close(got, want, name, tol=TOL_LSB, rate=MISMATCH_RATE):
     assert got.shape == want.shape, (name, got.shape, want.shape)
     if got.size == 0:
@@ -718,7 +729,7 @@ def test_int16_window_on_small_launches_too():
     so that the small multi-call cases of the layout and mixed int16 / float tests run over it as well."""
     import subprocess
     import sys
-    env = dict(os.environ, SPEEXHIP_W16_ALWAYS="1")
+    env = diag_env(SPEEXHIP_W16_ALWAYS="1")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                           "window_layout_variants or int16_window_plan_serves or edge_cases"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
@@ -733,7 +744,7 @@ def test_tap_range_shares_on_every_layout():
     phase-group sizes -- over the small multi-call cases."""
     import subprocess
     import sys
-    env = dict(os.environ, SPEEXHIP_KSPLIT="3")
+    env = diag_env(SPEEXHIP_KSPLIT="3")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                           "window_layout_variants or every_golden_case or edge_cases or many_rates or mono_packed "
                           "or float_entry or mid_stream_control_scripts_fast or fp64_accumulate_period"],   # (round 4: the
@@ -749,7 +760,7 @@ def test_slide_kernel_tap_range_parts_on_every_shape():
     every launch of every shape."""
     import subprocess
     import sys
-    env = dict(os.environ, SPEEXHIP_SLIDE_PARTS="3")
+    env = diag_env(SPEEXHIP_SLIDE_PARTS="3")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                           "small_ratio or n_to_one or slide_kernel_workgroups or every_golden_case or edge_cases "
                           "or many_rates or mono_packed or float_entry"],
@@ -1744,7 +1755,7 @@ def test_phase_pair_plans_for_mono_on_every_launch():
     window, packed-store and control tests (stereo frames leave through a DPP swap of lane pairs), +-1 LSB."""
     import subprocess
     import sys
-    env = dict(os.environ, SPEEXHIP_PP="1")
+    env = diag_env(SPEEXHIP_PP="1")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                           "(mono or every_golden_case or many_rates or window_layout_variants or edge_cases or tap_range_shares "
                           "or int16_window_plan_serves or history_after or float_entry or control_scripts_fast or many_generation) "
@@ -1792,7 +1803,7 @@ def test_tap_rows_fetched_behind_the_window_and_shares_on_unsplit_launches():
             "ragged or float_entry) and not phase_pair and not tap_rows_fetched")
     for extra in ({"SPEEXHIP_TOUCH": "1"}, {"SPEEXHIP_TOUCH": "1", "SPEEXHIP_PP": "1"}, {"SPEEXHIP_KS_UNSPLIT": "0"}):
         res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", pick],
-                             env=dict(os.environ, **extra), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+                             env=diag_env(**extra), capture_output=True, text=True, timeout=1500, cwd=ROOT)
         assert res.returncode == 0, str(extra) + res.stdout[-3000:] + res.stderr[-2000:]
     # by the rules: shares on an unsplit launch (three channels, 8 groups of 20 phases), the fetch by bytes moved
     # (4 channels, 33 MB), stereo in phase pairs because the other plan splits -- all through the default environment
@@ -1835,7 +1846,7 @@ def test_large_owned_block_calls_run_in_pieces_and_match_the_oracle():
     if os.environ.get("SPEEXHIP_PIECES") is None:
         import subprocess
         import sys
-        env = dict(os.environ, SPEEXHIP_PIECES="3")
+        env = diag_env(SPEEXHIP_PIECES="3")
         res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                               "large_owned_block_calls or owned_block_calls_return"],
                              env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -2004,7 +2015,7 @@ for (ch, i, o, q) in [(2, 44100, 48000, 7), (1, 24000, 48000, 5), (2, 48000, 110
     r.close()
 print("PIECES OK")
 """
-    env = dict(os.environ, SPEEXHIP_PIECES="3")
+    env = diag_env(SPEEXHIP_PIECES="3")
     res = subprocess.run([sys.executable, "-c", child, ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "PIECES OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
@@ -2086,7 +2097,7 @@ def test_large_many_states_call_runs_pipelined_and_matches():
     for r in many + apart:
         r.close()
     if os.environ.get("SPEEXHIP_MANY_PIPELINE") is None:
-        env = dict(os.environ, SPEEXHIP_MANY_PIPELINE="0")
+        env = diag_env(SPEEXHIP_MANY_PIPELINE="0")
         res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                               "large_many_states_call"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
