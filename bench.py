@@ -125,7 +125,49 @@ def parity_block(cfg, frames, first_chunks, float_io):
     return blk, ok
 
 
-def end_to_end(speexhip, cfg, frames, mode, float_io, base_stream, calls=30):
+def pcie_peak(torch, mb=64, reps=6):
+    """The PCIe link's own rate, measured in this run on this box: a plain pinned copy of `mb` MiB host -> device,
+    device -> host, and both at once on two streams (hipMemcpyAsync through torch; best of `reps`).  The roofline of the
+    host-fed legs (end_to_end*, never of `value`)."""
+    n = mb << 20
+    h_in = torch.empty(n, dtype=torch.uint8).pin_memory()
+    h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+    d_a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_b = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run(h2d, d2h):
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if h2d:
+                with torch.cuda.stream(s1):
+                    d_a.copy_(h_in, non_blocking=True)
+            if d2h:
+                with torch.cuda.stream(s2):
+                    h_out.copy_(d_b, non_blocking=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return n / best / 1e9
+
+    h2d, d2h, both = run(True, False), run(False, True), run(True, True)
+    return {"h2d_GBs": round(h2d, 2), "d2h_GBs": round(d2h, 2), "both_ways_each_GBs": round(both, 2),
+            "peak": round(2 * both, 2), "unit": "GB/s",
+            "what": "plain pinned hipMemcpyAsync of %d MiB measured in this run: one way each, and both ways at once on "
+                    "two streams; peak = in + out with both directions busy" % mb}
+
+
+def pcie_block(peak, bytes_in, bytes_out, seconds):
+    """{achieved_in_GBs, achieved_out_GBs, peak, frac} of one host-fed call against pcie_peak()"""
+    ain, aout = bytes_in / seconds / 1e9, bytes_out / seconds / 1e9
+    return {"achieved_in_GBs": round(ain, 2), "achieved_out_GBs": round(aout, 2), "peak": peak["peak"], "unit": "GB/s",
+            "frac": round((ain + aout) / peak["peak"], 4),
+            "h2d_GBs": peak["h2d_GBs"], "d2h_GBs": peak["d2h_GBs"], "both_ways_each_GBs": peak["both_ways_each_GBs"]}
+
+
+def end_to_end(speexhip, cfg, frames, mode, float_io, base_stream, calls=30, peak=None):
     """The call a host-buffer caller makes (speexhip_resampler_process_interleaved_*: what index.js's
     processChunk runs): pageable buffers in and out, synchronous, PCIe both ways inside the timed call.
     Reported beside the kernel-resident `value`, never as it."""
@@ -176,19 +218,63 @@ def end_to_end(speexhip, cfg, frames, mode, float_io, base_stream, calls=30):
         call_take()
         tt.append(time.perf_counter() - t0)
     tt.sort()
+    # ... and (round 6) the same call on a chunk the caller left in a pinned block of the library (speexhip_block_acquire:
+    # SpeexResampler.allocChunk in JavaScript): the kernel reads it through PCIe while it writes the result block through
+    # PCIe -- one launch, both directions of the link at once
+    made = [0]
+    tp = []
+    blk_in = lib_block = None
+    try:
+        lib_block = speexhip.PinnedBlock(x.nbytes)
+        blk_in = lib_block.array(x.dtype, x.shape)
+        blk_in[...] = x
+        pin_ptr = C.c_void_p(blk_in.ctypes.data)
+
+        def call_pinned():
+            il, ol, blk = C.c_uint32(frames), C.c_uint32(cap), C.POINTER(ctype)()
+            rc = take(r._h, pin_ptr, C.byref(il), C.byref(ol), C.byref(blk))
+            assert rc == 0 and blk, rc
+            made[0] = ol.value
+            speexhip.lib().speexhip_block_release(C.cast(blk, C.c_void_p))
+
+        for _ in range(3):
+            call_pinned()
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            call_pinned()
+            tp.append(time.perf_counter() - t0)
+        tp.sort()
+    except MemoryError:
+        tp = []
+    finally:
+        if lib_block is not None:
+            lib_block.close()
     r.close()
     ts.sort()
     med = ts[len(ts) // 2]
-    return {"ms_per_chunk": round(min(med, tt[len(tt) // 2]) * 1e3, 4), "ms_min": round(min(ts[0], tt[0]) * 1e3, 4),
-            "ms_per_chunk_copy_out": round(med * 1e3, 4), "ms_per_chunk_owned_block": round(tt[len(tt) // 2] * 1e3, 4),
-            "input_msamples_per_s": round(used * ch / med / 1e6, 1), "calls": calls,
-            "what": "one stream, a host (pageable) buffer in through the C ABI's synchronous calls, %d-frame chunk, "
-                    "PCIe-inclusive (not `value`): copy_out = ..._process_interleaved_* into the caller's pageable buffer "
-                    "(H2D + kernel + D2H + wait), owned_block = ..._take (the kernel writes a pinned block the caller "
-                    "then owns: what processChunk returns as an external Buffer); ms_per_chunk = the faster" % frames}
+    res = {"ms_per_chunk": round(min(med, tt[len(tt) // 2]) * 1e3, 4), "ms_min": round(min(ts[0], tt[0]) * 1e3, 4),
+           "ms_per_chunk_copy_out": round(med * 1e3, 4), "ms_per_chunk_owned_block": round(tt[len(tt) // 2] * 1e3, 4),
+           "input_msamples_per_s": round(used * ch / med / 1e6, 1), "calls": calls,
+           "what": "one stream, a host buffer in through the C ABI's synchronous calls, %d-frame chunk, "
+                   "PCIe-inclusive (not `value`): copy_out = ..._process_interleaved_* from and into the caller's pageable "
+                   "buffers (H2D + kernel + D2H + wait), owned_block = ..._take (the kernel writes a pinned block the caller "
+                   "then owns: what processChunk returns as an external Buffer); ms_per_chunk = the faster of the two, "
+                   "both on a PAGEABLE input; pinned_in = ..._take on a chunk in a pinned block of the library "
+                   "(speexhip_block_acquire / SpeexResampler.allocChunk): read in place, one launch" % frames}
+    if tp:
+        pin = tp[len(tp) // 2]
+        res["ms_per_chunk_pinned_in"] = round(pin * 1e3, 4)
+        res["ms_min_pinned_in"] = round(tp[0] * 1e3, 4)
+        res["input_msamples_per_s_pinned_in"] = round(used * ch / pin / 1e6, 1)
+        if peak is not None:
+            es = 4 if float_io else 2
+            res["pcie"] = dict(pcie_block(peak, frames * ch * es, made[0] * ch * es, pin), leg="pinned_in")
+            res["pcie_pageable"] = dict(pcie_block(peak, frames * ch * es, made[0] * ch * es, min(med, tt[len(tt) // 2])),
+                                        leg="ms_per_chunk")
+    return res
 
 
-def end_to_end_streams(speexhip, cfg, frames, mode, streams=32, calls=8):
+def end_to_end_streams(speexhip, cfg, frames, mode, streams=32, calls=8, peak=None):
     """BASELINE configs[4]'s per-GPU share as a HOST caller reaches it (round 5): `streams` independent states -- what
     `streams` SpeexResampler instances of one Node process hold -- fed pageable host buffers through ONE
     speexhip_resampler_process_many_int call per step (per GPU one transfer in, one launch per <= 32 states, one
@@ -228,8 +314,32 @@ def end_to_end_streams(speexhip, cfg, frames, mode, streams=32, calls=8):
                         ys[i].ctypes.data_as(C.POINTER(C.c_int16)), C.byref(b))
                 assert rc == 0, rc
 
+        # round 6: the chunks in pinned blocks of the library (read in place), results into pageable buffers or into
+        # pinned blocks as well (what the addon's external Buffers are)
+        legs = [("many", many), ("separate_calls", apart)]
+        blocks = []
+        try:
+            bis = [speexhip.PinnedBlock(xs[0].nbytes) for _ in range(streams)]
+            blocks += bis
+            bos = [speexhip.PinnedBlock(cap * ch * 2) for _ in range(streams)]
+            blocks += bos
+            for s_ in range(streams):
+                bis[s_].array(np.int16, xs[s_].shape)[...] = xs[s_]
+            pin_ins = (C.c_void_p * n)(*[b.ptr for b in bis])
+            pin_outs = (C.c_void_p * n)(*[b.ptr for b in bos])
+
+            def many_with(a, b):
+                def f():
+                    for i in range(n):
+                        il[i], ol[i] = F, cap
+                    rc = lib.speexhip_resampler_process_many_int(n, hs, a, il, b, ol, codes)
+                    assert rc == 0, rc
+                return f
+            legs += [("pinned_in", many_with(pin_ins, outs)), ("pinned_in_pinned_out", many_with(pin_ins, pin_outs))]
+        except MemoryError:
+            pass
         res = {}
-        for name, fn in (("many", many), ("separate_calls", apart)):
+        for name, fn in legs:
             for _ in range(2):
                 fn()
             ts = []
@@ -239,11 +349,24 @@ def end_to_end_streams(speexhip, cfg, frames, mode, streams=32, calls=8):
                 ts.append(time.perf_counter() - t0)
             ts.sort()
             res[name] = ts[len(ts) // 2]
+        made_bytes = sum(int(ol[i]) for i in range(n)) * ch * 2
         for st in states:
             st.close()
+        for b in blocks:
+            b.close()
         out[label] = {"frames_per_stream": F, "ms_per_step": round(res["many"] * 1e3, 4),
                       "ms_per_step_separate_calls": round(res["separate_calls"] * 1e3, 4),
                       "input_msamples_per_s": round(streams * F * ch / res["many"] / 1e6, 1)}
+        if "pinned_in_pinned_out" in res:
+            out[label]["ms_per_step_pinned_in"] = round(res["pinned_in"] * 1e3, 4)
+            out[label]["ms_per_step_pinned_in_pinned_out"] = round(res["pinned_in_pinned_out"] * 1e3, 4)
+            out[label]["input_msamples_per_s_pinned"] = round(streams * F * ch / res["pinned_in_pinned_out"] / 1e6, 1)
+            if peak is not None:
+                out[label]["pcie"] = dict(pcie_block(peak, streams * F * ch * 2, made_bytes, res["pinned_in_pinned_out"]),
+                                          leg="pinned_in_pinned_out")
+                out[label]["pcie_pageable"] = dict(pcie_block(peak, streams * F * ch * 2, made_bytes, res["many"]), leg="ms_per_step")
+    out["what"] += ("; pinned_in = the chunks in pinned blocks of the library (speexhip_block_acquire), read in place; "
+                    "pinned_in_pinned_out = the results into such blocks as well (one launch per 32 states, no copy)")
     return out
 
 
@@ -632,9 +755,11 @@ def main():
             if not ok:
                 rc = 3
         if world == 1 and not args.no_cpu_baseline:
-            line["end_to_end"] = end_to_end(speexhip, cfg, F, mode, fio, base[0])
+            peak = pcie_peak(torch)
+            line["pcie_peak"] = peak
+            line["end_to_end"] = end_to_end(speexhip, cfg, F, mode, fio, base[0], peak=peak)
             if not fio:
-                line["end_to_end_streams"] = end_to_end_streams(speexhip, cfg, F, mode)
+                line["end_to_end_streams"] = end_to_end_streams(speexhip, cfg, F, mode, peak=peak)
             line["cpu_baseline"] = cpu_baseline(cfg, F)
             if cpu_many is not None:
                 # the strong-scaling line: T streams against min(cores, T) CPU workers; the 1-core figure stays beside it

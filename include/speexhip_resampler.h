@@ -233,6 +233,19 @@ SPEEXHIP_API int speexhip_resampler_process_interleaved_float_take(SpeexHipResam
                                                                    float **out_block);
 SPEEXHIP_API void speexhip_block_release(void *block);
 
+/* Pinned blocks for INPUT (round 6) -- the mirror of the ..._take calls.  speexhip_block_acquire(bytes) hands the caller a
+ * block of the same pinned slabs to FILL (NULL: none free right now, or SPEEXHIP_TAKE_MB=0; use an ordinary buffer then);
+ * speexhip_block_release gives it back, any time after the calls that read it have returned.  Every host-buffer entry
+ * point -- process_interleaved_int / _float, the ..._take forms, process_chunks_*, process_many_* -- recognises such a
+ * block (and, for buffers of 256 KB and more, memory the caller pinned itself with hipHostMalloc / hipHostRegister) as
+ * its input or output and uses it IN PLACE: the kernel reads the chunk through PCIe while it writes the result through
+ * PCIe -- both directions of the link at once, one launch, no staging copy -- where a pageable buffer goes through the
+ * runtime's staged copy first.  Bytes and counters are those of the same call on pageable buffers.  In the reference this
+ * is the copy of the chunk into the WASM module's heap (src/index.ts:71-92) that a caller avoids by decoding straight
+ * into the block.  A block may be refilled as soon as the call that read it has returned (the host-buffer calls are
+ * synchronous). */
+SPEEXHIP_API void *speexhip_block_acquire(uint64_t bytes);
+
 /* The caller is about to destroy the stream of this state's last device-pointer call (one stream per
  * request, say): what that call still has in flight is ordered behind an event of the state's own and
  * the stream is forgotten -- later calls, control calls and destroy wait for the event instead.  Costs one

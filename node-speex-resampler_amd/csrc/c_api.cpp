@@ -169,6 +169,14 @@ void speexhip_block_release(void *block) {
   if (block != nullptr) speexhip::Batch::release_block(block);
 }
 
+void *speexhip_block_acquire(uint64_t bytes) {
+  void *p = nullptr;
+  const int rc = guarded([&] {
+    return speexhip::pool::block_get(&p, static_cast<size_t>(bytes)) ? SPEEXHIP_ERR_SUCCESS : SPEEXHIP_ERR_NO_BLOCK;
+  });
+  return rc == SPEEXHIP_ERR_SUCCESS ? p : nullptr;
+}
+
 int speexhip_resampler_process_interleaved_float(SpeexHipResamplerState *st, const float *in,
                                                  uint32_t *in_len, float *out, uint32_t *out_len) {
   if (st == nullptr || in_len == nullptr || out_len == nullptr || (out == nullptr && *out_len != 0))

@@ -147,6 +147,57 @@ const size_t kDirectCopyBytes = 256 * 1024;  // host buffers at least this big s
 // channels (16.8 MB in), four pieces: 0.617 -> 0.517 ms.
 const size_t kPieceBytes = static_cast<size_t>(2) << 20;
 const size_t kZeroCopyBelow = 720 * 1024;    // ... and calls whose buffers are smaller than this run on pinned memory alone
+
+// Round 6 -- pinned host buffers are used in place.  Where the kernels reach a HOST buffer directly: the address the
+// device sees when all of [p, p + bytes) is pinned memory -- a block of the library's slabs (speexhip_block_acquire, a
+// result block of ..._take: a range check, no runtime call), or, for buffers of kDirectCopyBytes and more, memory the
+// caller pinned itself (hipHostMalloc / hipHostRegister: asked of the runtime at both ends of the buffer) -- else nullptr.
+// Such a buffer needs no staging: the kernel that reads it through PCIe can write its result block through PCIe at the
+// same time (the link is full duplex), where copy -> launch -> copy takes the two crossings one after the other; for the
+// Node wrapper this replaces the copy into the module's heap, src/index.ts:71-92.
+void *pinned_view(const void *p, size_t bytes) {
+  if (p == nullptr || bytes == 0) return nullptr;
+  if (pool::block_owns(p, bytes)) return const_cast<void *>(p);
+  if (bytes < kDirectCopyBytes) return nullptr;
+  auto device_side = [](const void *q) -> char * {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+      (void)hipGetLastError();  // (an ordinary malloc'ed pointer is an "invalid value" to older runtimes)
+      return nullptr;
+    }
+    return a.type == hipMemoryTypeHost ? static_cast<char *>(a.devicePointer) : nullptr;
+  };
+  char *first = device_side(p);
+  if (first == nullptr) return nullptr;
+  char *last = device_side(static_cast<const char *>(p) + bytes - 1);
+  return last != nullptr && static_cast<size_t>(last - first) == bytes - 1 ? first : nullptr;
+}
+
+// The wait of a host-buffer call whose kernels read and write pinned memory: hipStreamSynchronize after a small launch
+// costs 11-12 us on this stack; a 32-bit stream write behind the kernel (hipStreamWriteValue32: performed once
+// everything before it on the stream has completed) into pinned memory, polled by the caller, 8.8 (tools/ubench_sync.hip).
+// The pool's streams are shared by all states -- behind another state's long launch the word will not come soon -- so the
+// spin is bounded (`spin_us`, `pause` between the reads) and then the thread sleeps in the runtime, which also reports
+// the error if that is what happened.  *word must not equal seq when the call is made.
+int wait_done(hipStream_t stream, volatile uint32_t *word, uint32_t seq, uint32_t spin_us) {
+  static const bool poll_done = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
+  bool signalled = false;
+  if (poll_done && hipStreamWriteValue32(stream, const_cast<uint32_t *>(word), seq, 0) == hipSuccess) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+    for (uint32_t spins = 0; !signalled; spins++) {
+      signalled = __atomic_load_n(const_cast<const uint32_t *>(word), __ATOMIC_ACQUIRE) == seq;
+      if (signalled) break;
+      __builtin_ia32_pause();
+      if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
+    }
+  } else {
+    (void)hipGetLastError();
+  }
+  if (!signalled) HIP_TRY(hipStreamSynchronize(stream));
+  return SPEEXHIP_ERR_SUCCESS;
+}
+// how long such a call may spin: 300 us for the launch itself plus what `bytes` take to cross PCIe (~40 GB/s), 2 ms at most
+uint32_t spin_budget_us(size_t bytes) { return static_cast<uint32_t>(std::min<size_t>(2000, 300 + bytes / 40000)); }
 }  // namespace
 
 // SPEEXHIP_INIT_TRACE=1: where a state's creation goes, step by step (stderr; tools/first_call.py)
@@ -1247,22 +1298,28 @@ int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len
   // lets a launch for the outputs that piece completes start while the next piece is still arriving.  No kernel
   // change: a piece is a StreamDesc of the same call that begins o_i outputs later (positions advanced in integers)
   // and only the last one rolls the history.  SPEEXHIP_PIECES=1 turns it off, =n forces n (A/B, tests).
-  static const int env_pieces = SPEEXHIP_DIAG_ENV("SPEEXHIP_PIECES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PIECES")) : 0;
-  uint32_t pieces = env_pieces > 0 ? static_cast<uint32_t>(env_pieces) : static_cast<uint32_t>(in_bytes / kPieceBytes);
+  const uint32_t env_pieces = static_cast<uint32_t>(std::max(0, diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_PIECES"), 0)));
+  uint32_t pieces = env_pieces > 0 ? env_pieces : static_cast<uint32_t>(in_bytes / kPieceBytes);
   pieces = std::min<uint32_t>(pieces, kMaxPieces);
+  // Round 6: an input the caller left in pinned memory (speexhip_block_acquire, or memory it pinned itself) is read where
+  // it lies -- ONE launch whose loads and stores cross PCIe in opposite directions at the same time, no staging copy, no
+  // second stream (the pieces above overlap the two directions only partly and pay ~15 us per piece for it).
+  const void *pin_in = (split || zero_mode_ || in == nullptr) ? nullptr : pinned_view(in, in_bytes);
   if (split || zero_mode_) {
     rc = process_host(in, in_len, blk, out_len, float_io);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
-  } else if (pieces >= 2 && in != nullptr && in_bytes >= kZeroCopyBelow && frames < 0x40000000u && have_copy_stream()) {
+  } else if (pin_in == nullptr && pieces >= 2 && in != nullptr && in_bytes >= kZeroCopyBelow && frames < 0x40000000u && have_copy_stream()) {
     rc = take_in_pieces(in, in_len, out_len, float_io, blk, pieces);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   } else {
     DrainOnExit drain(&own_stream_);
-    const bool direct_in = in_bytes >= kZeroCopyBelow;
-    rc = ensure_stage(direct_in ? in_bytes : 0, 0, direct_in ? 0 : in_bytes, 0);
+    const bool direct_in = pin_in == nullptr && in_bytes >= kZeroCopyBelow;
+    rc = ensure_stage(direct_in ? in_bytes : 0, 0, (direct_in || pin_in != nullptr) ? 0 : in_bytes, 0);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     const void *src = nullptr;
-    if (in != nullptr && in_bytes != 0) {
+    if (pin_in != nullptr) {
+      src = pin_in;
+    } else if (in != nullptr && in_bytes != 0) {
       if (direct_in) {
         HIP_TRY(hipMemcpyAsync(d_stage_in_, in, in_bytes, hipMemcpyHostToDevice, own_stream_));
         src = d_stage_in_;
@@ -1275,20 +1332,12 @@ int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len
     *done = 0;
     rc = process_device(src, 0, in_len, blk, 0, out_len, float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
-    static const bool poll_done = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
-    bool signalled = false;
-    if (poll_done && !direct_in && hipStreamWriteValue32(own_stream_, const_cast<uint32_t *>(done), 1u, 0) == hipSuccess) {
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
-      for (uint32_t spins = 0; !signalled; spins++) {
-        signalled = __atomic_load_n(const_cast<const uint32_t *>(done), __ATOMIC_ACQUIRE) == 1u;
-        if (signalled) break;
-        __builtin_ia32_pause();
-        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
-      }
+    if (direct_in) {
+      HIP_TRY(hipStreamSynchronize(own_stream_));
     } else {
-      (void)hipGetLastError();
+      const int wrc = wait_done(own_stream_, done, 1u, spin_budget_us(pin_in != nullptr ? in_bytes + out_bytes : 0));
+      if (wrc != SPEEXHIP_ERR_SUCCESS) return wrc;
     }
-    if (!signalled) HIP_TRY(hipStreamSynchronize(own_stream_));
     drain.armed = false;
   }
   if (*out_len == 0) return rc;  // (the guard returns the block)
@@ -1343,6 +1392,52 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     const char *e = SPEEXHIP_DIAG_ENV("SPEEXHIP_ZERO_COPY_BELOW");
     return e != nullptr ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kZeroCopyBelow;
   }();
+  // Round 6: buffers the caller keeps in pinned memory (speexhip_block_acquire, hipHostMalloc, hipHostRegister) are used
+  // where they lie (pinned_view): a pinned input is read by the kernel through PCIe, a pinned output written by it -- with
+  // both pinned the call is one launch and one wait, the two crossings side by side.  The other side, if pageable, keeps its
+  // own rule: small through the bounce buffer, large by the runtime's staged copy.
+  if (!split) {
+    const void *pin_in = in != nullptr ? pinned_view(in, in_bytes) : nullptr;
+    void *pin_out = pinned_view(out, out_bytes);
+    if (pin_in != nullptr || pin_out != nullptr) {
+      const bool have_in = in != nullptr && in_bytes != 0;
+      const bool bounce_in = have_in && pin_in == nullptr && in_bytes < zero_copy_below;
+      const bool copy_in = have_in && pin_in == nullptr && !bounce_in;
+      const bool bounce_out = pin_out == nullptr && out_bytes < zero_copy_below;
+      const bool copy_out = pin_out == nullptr && !bounce_out;
+      rc = ensure_stage(copy_in ? in_bytes : 0, copy_out ? out_bytes : 0, bounce_in ? in_bytes : 0, (bounce_out ? out_bytes : 0) + 64);
+      if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+      const void *src = nullptr;
+      if (pin_in != nullptr) {
+        src = pin_in;
+      } else if (bounce_in) {
+        std::memcpy(h_pin_in_, in, in_bytes);
+        src = h_pin_in_;
+      } else if (copy_in) {
+        HIP_TRY(hipMemcpyAsync(d_stage_in_, in, in_bytes, hipMemcpyHostToDevice, own_stream_));
+        src = d_stage_in_;
+      } else if (in != nullptr) {
+        src = h_pin_out_;  // (an empty chunk, not silence: no frame is read, any non-null address serves)
+      }
+      void *dst = pin_out != nullptr ? pin_out : bounce_out ? static_cast<void *>(h_pin_out_) : static_cast<void *>(d_stage_out_);
+      volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(h_pin_out_ + ((pin_out_cap_ - 64) & ~static_cast<size_t>(63)));
+      const uint32_t seq = ++done_seq_;
+      *done = seq - 1;
+      rc = process_device(src, 0, in_len, dst, 0, out_len, float_io, own_stream_);
+      if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
+      const size_t made = static_cast<size_t>(*out_len) * channels_ * es;
+      if (copy_in || copy_out) {
+        if (copy_out && made != 0) HIP_TRY(hipMemcpyAsync(out, d_stage_out_, made, hipMemcpyDeviceToHost, own_stream_));
+        HIP_TRY(hipStreamSynchronize(own_stream_));
+      } else {
+        const int wrc = wait_done(own_stream_, done, seq, spin_budget_us((pin_in != nullptr ? in_bytes : 0) + (pin_out != nullptr ? out_bytes : 0)));
+        if (wrc != SPEEXHIP_ERR_SUCCESS) return wrc;
+      }
+      drain.armed = false;
+      if (bounce_out && made != 0) std::memcpy(out, h_pin_out_, made);
+      return rc;
+    }
+  }
   if (!split && in_bytes < zero_copy_below && out_bytes < zero_copy_below) {
     // (+ 64 bytes: the completion word below lives behind the samples, in the same pinned block)
     rc = ensure_stage(0, 0, in_bytes, out_bytes + 64);
@@ -1352,27 +1447,13 @@ int Batch::process_host(const void *in, uint32_t *in_len, void *out, uint32_t *o
     // the kernel (hipStreamWriteValue32: performed once everything before it on the stream has completed) into
     // pinned memory, polled by the caller, 8.8 (tools/ubench_sync.hip).  A launch that has not signalled after
     // 300 us is waited for -- and its error, if that is what happened, reported -- the ordinary way.
-    static const bool poll_done = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_POLL") == nullptr;  // (A/B)
     volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(h_pin_out_ + ((pin_out_cap_ - 64) & ~static_cast<size_t>(63)));
     const uint32_t seq = ++done_seq_;
     *done = seq - 1;
     rc = process_device(in != nullptr ? h_pin_in_ : nullptr, 0, in_len, h_pin_out_, 0, out_len, float_io, own_stream_);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
-    bool signalled = false;
-    if (poll_done && hipStreamWriteValue32(own_stream_, const_cast<uint32_t *>(done), seq, 0) == hipSuccess) {
-      // (the pool's streams are shared by all states: behind another state's long launch the word will not come
-      //  soon, so the spin is short -- 300 us, `pause` between the reads -- and then the thread sleeps in the runtime)
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
-      for (uint32_t spins = 0; !signalled; spins++) {
-        signalled = __atomic_load_n(const_cast<const uint32_t *>(done), __ATOMIC_ACQUIRE) == seq;
-        if (signalled) break;
-        __builtin_ia32_pause();
-        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
-      }
-    } else {
-      (void)hipGetLastError();
-    }
-    if (!signalled) HIP_TRY(hipStreamSynchronize(own_stream_));
+    const int wrc = wait_done(own_stream_, done, seq, 300);  // (the word: see wait_done)
+    if (wrc != SPEEXHIP_ERR_SUCCESS) return wrc;
     drain.armed = false;
     const size_t made = static_cast<size_t>(*out_len) * channels_ * es;
     if (made != 0) std::memcpy(out, h_pin_out_, made);
@@ -1673,11 +1754,13 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     uint32_t i;
     Batch *b;
     CallPlan plan;
-    size_t in_bytes, out_bytes, in_off, out_off;
+    size_t in_bytes, out_bytes, in_off, out_off;  // bytes that travel through the stage (0: a pinned buffer, used in place)
+    const void *pin_in;                           // round 6: the caller's own buffers where they are pinned memory
+    void *pin_out;                                // (pinned_view): the kernels read / write them directly
     bool work;
   };
   std::vector<Item> items(idx.size());
-  size_t total_in = 0, total_out = 0;
+  size_t total_in = 0, total_out = 0, pinned_bytes = 0;
   bool all_big = true;
   for (size_t k = 0; k < idx.size(); k++) {
     Item &it = items[k];
@@ -1689,6 +1772,10 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     it.plan = plan_call(it.b->filter_.num, it.b->filter_.den, in_len[it.i], out_len[it.i], it.b->P(0, 0), rules);
     it.in_bytes = in[it.i] != nullptr ? static_cast<size_t>(in_len[it.i]) * it.b->channels_ * es : 0;
     it.out_bytes = static_cast<size_t>(it.plan.produced) * it.b->channels_ * es;
+    it.pin_in = pinned_view(in[it.i], it.in_bytes);
+    it.pin_out = pinned_view(out[it.i], it.out_bytes);
+    if (it.pin_in != nullptr) pinned_bytes += it.in_bytes, it.in_bytes = 0;
+    if (it.pin_out != nullptr) pinned_bytes += it.out_bytes, it.out_bytes = 0;
     it.work = it.plan.produced != 0 || it.plan.magic_used + it.plan.consumed != 0;
     total_in += align64(it.in_bytes);
     total_out += align64(it.out_bytes);
@@ -1762,9 +1849,9 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
       if (crc != SPEEXHIP_ERR_SUCCESS) return crc;
       StreamDesc &d = pack.d[j];
       const FilterSpec &f = b->filter_;
-      d.in = in[it.i] != nullptr ? src_base + it.in_off : nullptr;
+      d.in = in[it.i] == nullptr ? nullptr : it.pin_in != nullptr ? it.pin_in : src_base + it.in_off;
       d.hist = b->d_hist_[b->hist_cur_];
-      d.out = dst_base + it.out_off;
+      d.out = it.pin_out != nullptr ? it.pin_out : dst_base + it.out_off;
       d.hist_next = b->d_hist_[b->hist_cur_ ^ 1];
       d.in_frames = in_len[it.i];
       d.n_out = it.plan.produced;
@@ -1900,19 +1987,10 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     volatile uint32_t *done = reinterpret_cast<volatile uint32_t *>(ms.h_out + ((ms.h_out_cap - 64) & ~static_cast<size_t>(63)));
     const uint32_t seq = ++ms.seq;
     *done = seq - 1;
-    bool signalled = false;
-    if (!launches.empty() && hipStreamWriteValue32(ms.stream, const_cast<uint32_t *>(done), seq, 0) == hipSuccess) {
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
-      for (uint32_t spins = 0; !signalled; spins++) {
-        signalled = __atomic_load_n(const_cast<const uint32_t *>(done), __ATOMIC_ACQUIRE) == seq;
-        if (signalled) break;
-        __builtin_ia32_pause();
-        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
-      }
-    } else {
-      (void)hipGetLastError();
+    if (!launches.empty()) {
+      const int wrc = wait_done(ms.stream, done, seq, spin_budget_us(pinned_bytes));
+      if (wrc != SPEEXHIP_ERR_SUCCESS) return wrc;
     }
-    if (!signalled) HIP_TRY(hipStreamSynchronize(ms.stream));
     drain.armed = false;
     for (const Item &it : items)
       if (it.out_bytes != 0) std::memcpy(out[it.i], ms.h_out + it.out_off, it.out_bytes);
@@ -1960,7 +2038,10 @@ int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in
   static const int env_lanes = SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_LANES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_LANES")) : -1;  // A/B: 1 = never split
   for (auto &kv : by_device) {
     uint64_t bytes = 0;
-    for (uint32_t i : kv.second) bytes += static_cast<uint64_t>(in_len[i]) * st[i]->channels_ * (float_io ? 4 : 2);
+    for (uint32_t i : kv.second) {  // (inputs in the library's pinned blocks are read in place: nothing to stage, no second lane)
+      const uint64_t b = static_cast<uint64_t>(in_len[i]) * st[i]->channels_ * (float_io ? 4 : 2);
+      if (!pool::block_owns(in[i], b)) bytes += b;
+    }
     // (from 128 MB of input: 32 x 2^20 stereo frames 4.11 -> 4.00 ms, 64 states 7.90 -> 7.14; at 67 MB nothing, 2.26 / 2.44)
     const bool split = env_lanes != 1 && kv.second.size() >= 8 && bytes >= (static_cast<uint64_t>(128) << 20);
     if (!split) {

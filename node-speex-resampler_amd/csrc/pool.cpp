@@ -98,7 +98,12 @@ struct Slabs {
   std::vector<Slab> all;
   size_t slab_bytes = 0, max_bytes = 0, total = 0;
   bool configured = false;
+  // A slab the driver refused (the pinned-memory limit of the container, say) is not asked for again at once: every
+  // ..._take call would pay a failing hipHostMalloc before it falls back to the copying path.  The next
+  // attempt waits until a block has come back or the idle memory has been released, or for kRetryCalls requests.
+  uint32_t refused_for = 0;
 };
+const uint32_t kRetryCalls = 256;
 Slabs &slabs() {
   static Slabs *s = new Slabs();  // never destroyed, like the pool
   return *s;
@@ -136,11 +141,16 @@ bool block_get(void **ptr, size_t bytes) {
   // every slab is full (or there is none yet): one more, while the total stays under the cap
   const size_t size = std::max(ss.slab_bytes, want);
   if (ss.total + size > ss.max_bytes && !(ss.all.empty() && size <= ss.max_bytes)) return false;
+  if (ss.refused_for != 0) {
+    ss.refused_for--;
+    return false;
+  }
   void *p = nullptr;
   {
     MissTimer timer("hipHostMalloc (slab of result blocks)", size);
     if (hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
+      ss.refused_for = kRetryCalls;
       return false;
     }
   }
@@ -177,8 +187,19 @@ bool block_put(void *ptr) {
       }
     }
     sl.free_at[start] = len;
+    ss.refused_for = 0;  // (memory came back: a refused slab may be asked for again)
     return true;
   }
+  return false;
+}
+
+bool block_owns(const void *ptr, size_t bytes) {
+  if (ptr == nullptr) return false;
+  Slabs &ss = slabs();
+  std::lock_guard<std::mutex> lock(ss.mu);
+  const char *p = static_cast<const char *>(ptr);
+  for (const Slab &sl : ss.all)
+    if (p >= sl.base && p < sl.base + sl.bytes) return bytes <= static_cast<size_t>(sl.base + sl.bytes - p);
   return false;
 }
 
@@ -383,6 +404,7 @@ size_t release_idle() {
   {  // the slabs of result blocks nobody holds a block of (the next ..._take call makes one again)
     Slabs &ss = slabs();
     std::lock_guard<std::mutex> lock(ss.mu);
+    ss.refused_for = 0;
     for (auto it = ss.all.begin(); it != ss.all.end();) {
       if (it->taken.empty()) {
         pin.push_back(it->base);

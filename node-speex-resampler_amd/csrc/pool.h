@@ -47,6 +47,10 @@ void event_put(int device, hipEvent_t e);
 // caller falls back to the copying call).  block_put: false = not one of these blocks.
 bool block_get(void **ptr, size_t bytes);
 bool block_put(void *ptr);
+// Round 6: the same blocks serve as INPUT buffers a caller fills (speexhip_block_acquire), and the host-buffer calls
+// recognise them: true when [ptr, ptr + bytes) lies inside one slab -- pinned memory the kernels read and write
+// straight through PCIe, so no staging copy is made for it.  A range check under the slabs' lock, no runtime call.
+bool block_owns(const void *ptr, size_t bytes);
 
 // Returns everything idle to the driver; the number of bytes released.
 size_t release_idle();

@@ -55,6 +55,8 @@ EXPORTS = [
     "speexhip_device_count", "speexhip_resampler_init_on", "speexhip_batch_init_on",
     "speexhip_resampler_process_many_int", "speexhip_resampler_process_many_float",
     "speexhip_resampler_get_info2", "speexhip_debug_placement", "speexhip_warmup",
+    # round 6: pinned blocks the caller fills (inputs used in place)
+    "speexhip_block_acquire",
 ]
 
 
@@ -208,6 +210,9 @@ def lib():
             L.speexhip_warmup.argtypes = [i32]
             L.speexhip_debug_placement.restype = i32
             L.speexhip_debug_placement.argtypes = [i32, C.c_char_p, C.c_char_p, C.c_uint64, i32]
+        if hasattr(L, "speexhip_block_acquire") or "SPEEXHIP_LIB_PATH" not in os.environ:
+            L.speexhip_block_acquire.restype = C.c_void_p
+            L.speexhip_block_acquire.argtypes = [C.c_uint64]
         _lib = L
     return _lib
 
@@ -318,6 +323,35 @@ def process_many(states, chunks, capacities, dtype=np.int16):
     if rc not in (0, ERR_ALLOC_FAILED):
         raise RuntimeError(strerror(rc))
     return [bufs[i][: ol[i]].copy() for i in range(n)], list(il), list(codes)
+
+
+class PinnedBlock:
+    """A pinned block of the library the caller fills (speexhip_block_acquire, round 6): `.array(dtype, shape)` is a
+    numpy view of it; the host-buffer calls use such memory in place -- the kernel reads it through PCIe.  Raises
+    MemoryError when no block is free.  close() (or the context manager) gives it back."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().speexhip_block_acquire(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("speexhip_block_acquire(%d): no pinned block free" % self.nbytes)
+
+    def array(self, dtype, shape):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        assert n <= self.nbytes
+        buf = (C.c_char * n).from_address(self.ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            lib().speexhip_block_release(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def device_clock():
@@ -550,6 +584,24 @@ class Resampler:
         if rc:
             raise RuntimeError(strerror(rc))
         return out[: ol.value].copy(), il.value
+
+    def process_into(self, x, out, float_io=False):
+        """The C call itself on the caller's own buffers, no copy on either side: x (frames x channels) in, `out`
+        (capacity x channels) written in place -- either may be a view of a PinnedBlock, which the library then uses
+        where it lies (round 6).  Returns (consumed, produced)."""
+        assert x.flags["C_CONTIGUOUS"] and out.flags["C_CONTIGUOUS"] and x.dtype == out.dtype
+        il, ol = C.c_uint32(x.shape[0]), C.c_uint32(out.shape[0])
+        if float_io:
+            rc = lib().speexhip_resampler_process_interleaved_float(
+                self._h, C.cast(x.ctypes.data, C.POINTER(C.c_float)), C.byref(il),
+                C.cast(out.ctypes.data, C.POINTER(C.c_float)), C.byref(ol))
+        else:
+            rc = lib().speexhip_resampler_process_interleaved_int(
+                self._h, C.cast(x.ctypes.data, C.POINTER(C.c_int16)), C.byref(il),
+                C.cast(out.ctypes.data, C.POINTER(C.c_int16)), C.byref(ol))
+        if rc:
+            raise RuntimeError(strerror(rc))
+        return il.value, ol.value
 
     def process_float(self, frames, out_capacity, null_frames=0):
         """speexhip_resampler_process_interleaved_float with host buffers (float32 in / out)."""
