@@ -40,6 +40,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "node-speex-resampler_amd", "python"))
+# (the 32-stream pinned legs of end_to_end_streams hold 32 x (4.2 + 4.6) MB of the library's pinned blocks at once: more
+#  than the default cap of 256 MiB on its slabs -- a documented limit of the library, include/speexhip_resampler.h)
+os.environ.setdefault("SPEEXHIP_TAKE_MAX_MB", "1024")
 
 CONFIGS = {
     # name: (channels, in_rate, out_rate, quality) -- BASELINE.json configs[1..3] (+ SURVEY F3)
@@ -125,46 +128,30 @@ def parity_block(cfg, frames, first_chunks, float_io):
     return blk, ok
 
 
-def pcie_peak(torch, mb=64, reps=6):
-    """The PCIe link's own rate, measured in this run on this box: a plain pinned copy of `mb` MiB host -> device,
-    device -> host, and both at once on two streams (hipMemcpyAsync through torch; best of `reps`).  The roofline of the
-    host-fed legs (end_to_end*, never of `value`)."""
-    n = mb << 20
-    h_in = torch.empty(n, dtype=torch.uint8).pin_memory()
-    h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
-    d_a = torch.empty(n, dtype=torch.uint8, device="cuda")
-    d_b = torch.empty(n, dtype=torch.uint8, device="cuda")
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-
-    def run(h2d, d2h):
-        best = None
-        for _ in range(reps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            if h2d:
-                with torch.cuda.stream(s1):
-                    d_a.copy_(h_in, non_blocking=True)
-            if d2h:
-                with torch.cuda.stream(s2):
-                    h_out.copy_(d_b, non_blocking=True)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        return n / best / 1e9
-
-    h2d, d2h, both = run(True, False), run(False, True), run(True, True)
-    return {"h2d_GBs": round(h2d, 2), "d2h_GBs": round(d2h, 2), "both_ways_each_GBs": round(both, 2),
-            "peak": round(2 * both, 2), "unit": "GB/s",
-            "what": "plain pinned hipMemcpyAsync of %d MiB measured in this run: one way each, and both ways at once on "
-                    "two streams; peak = in + out with both directions busy" % mb}
+def pcie_peak(speexhip, chunk_bytes):
+    """The PCIe link's own rate, measured in this run on this box by the library's probe (plain pinned hipMemcpyAsync, one
+    way each and both ways at once on two streams): at 64 MiB -- the link -- and at the size of the chunk the host-fed
+    legs move, where a copy's fixed cost shows.  The roofline of end_to_end* (never of `value`): `peak` = bytes in + out per
+    second with both directions busy, at the chunk's size."""
+    big = speexhip.pcie_peak(64 << 20)
+    at = speexhip.pcie_peak(max(int(chunk_bytes), 1 << 16))
+    return {"h2d_GBs": round(at[0], 2), "d2h_GBs": round(at[1], 2), "both_ways_each_GBs": round(at[2], 2),
+            "peak": round(2 * at[2], 2), "unit": "GB/s", "copy_bytes": int(chunk_bytes),
+            "at_64MiB": {"h2d_GBs": round(big[0], 2), "d2h_GBs": round(big[1], 2), "both_ways_each_GBs": round(big[2], 2)},
+            "what": "plain pinned hipMemcpyAsync measured in this run (speexhip_debug_pcie_peak): one way each, and both ways "
+                    "at once on two streams, of %d bytes (one chunk of the workload) and of 64 MiB; peak = in + out with both "
+                    "directions busy at the chunk's size" % chunk_bytes}
 
 
-def pcie_block(peak, bytes_in, bytes_out, seconds):
-    """{achieved_in_GBs, achieved_out_GBs, peak, frac} of one host-fed call against pcie_peak()"""
+def pcie_block(peak, bytes_in, bytes_out, seconds, big=False):
+    """{achieved_in_GBs, achieved_out_GBs, peak, frac} of one host-fed call against pcie_peak(): the rates at the chunk's
+    size, or (big) at 64 MiB for the legs that move hundreds of MB per step"""
+    ref = peak["at_64MiB"] if big else peak
+    both = 2 * ref["both_ways_each_GBs"]
     ain, aout = bytes_in / seconds / 1e9, bytes_out / seconds / 1e9
-    return {"achieved_in_GBs": round(ain, 2), "achieved_out_GBs": round(aout, 2), "peak": peak["peak"], "unit": "GB/s",
-            "frac": round((ain + aout) / peak["peak"], 4),
-            "h2d_GBs": peak["h2d_GBs"], "d2h_GBs": peak["d2h_GBs"], "both_ways_each_GBs": peak["both_ways_each_GBs"]}
+    return {"achieved_in_GBs": round(ain, 2), "achieved_out_GBs": round(aout, 2), "peak": round(both, 2), "unit": "GB/s",
+            "frac": round((ain + aout) / both, 4), "peak_at": "64 MiB copies" if big else "%d-byte copies" % peak["copy_bytes"],
+            "h2d_GBs": ref["h2d_GBs"], "d2h_GBs": ref["d2h_GBs"], "both_ways_each_GBs": ref["both_ways_each_GBs"]}
 
 
 def end_to_end(speexhip, cfg, frames, mode, float_io, base_stream, calls=30, peak=None):
@@ -362,9 +349,10 @@ def end_to_end_streams(speexhip, cfg, frames, mode, streams=32, calls=8, peak=No
             out[label]["ms_per_step_pinned_in_pinned_out"] = round(res["pinned_in_pinned_out"] * 1e3, 4)
             out[label]["input_msamples_per_s_pinned"] = round(streams * F * ch / res["pinned_in_pinned_out"] / 1e6, 1)
             if peak is not None:
-                out[label]["pcie"] = dict(pcie_block(peak, streams * F * ch * 2, made_bytes, res["pinned_in_pinned_out"]),
+                big = streams * F * ch * 2 >= (32 << 20)
+                out[label]["pcie"] = dict(pcie_block(peak, streams * F * ch * 2, made_bytes, res["pinned_in_pinned_out"], big),
                                           leg="pinned_in_pinned_out")
-                out[label]["pcie_pageable"] = dict(pcie_block(peak, streams * F * ch * 2, made_bytes, res["many"]), leg="ms_per_step")
+                out[label]["pcie_pageable"] = dict(pcie_block(peak, streams * F * ch * 2, made_bytes, res["many"], big), leg="ms_per_step")
     out["what"] += ("; pinned_in = the chunks in pinned blocks of the library (speexhip_block_acquire), read in place; "
                     "pinned_in_pinned_out = the results into such blocks as well (one launch per 32 states, no copy)")
     return out
@@ -755,7 +743,7 @@ def main():
             if not ok:
                 rc = 3
         if world == 1 and not args.no_cpu_baseline:
-            peak = pcie_peak(torch)
+            peak = pcie_peak(speexhip, F * ch * es)
             line["pcie_peak"] = peak
             line["end_to_end"] = end_to_end(speexhip, cfg, F, mode, fio, base[0], peak=peak)
             if not fio:

@@ -81,7 +81,8 @@ SPEEXHIP_API SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channel
  * (src/index.ts:18-45: one shared module, one state per instance); on a node with several MI355X the states of
  * one process spread over them by a process-wide rule read from the environment when a state is made:
  *   SPEEXHIP_DEVICE=k         every state on device k
- *   SPEEXHIP_DEVICES=all      state number k of the process on device k mod speexhip_device_count()
+ *   SPEEXHIP_DEVICES=all      every new state on the device with the fewest live states (round 6; ties in the order k mod
+ *                             n, k + 1 mod n, ... for state number k: a fresh process deals its states round-robin)
  *   SPEEXHIP_DEVICES=0,2,5    ... on the (k mod 3)-th listed device
  *   neither                   the calling thread's current HIP device (the behaviour before round 5)
  * speexhip_resampler_init / _init_frac / speexhip_batch_init follow the rule; the ..._init_on forms name the device
@@ -457,10 +458,25 @@ SPEEXHIP_API int speexhip_debug_launch_shape(uint32_t ratio_num, uint32_t ratio_
 SPEEXHIP_API int speexhip_debug_placement(int device_count, const char *env_device, const char *env_devices,
                                           uint64_t k, int current_device);
 
+/* Round 6: the placement rule with the load taken into account -- what speexhip_resampler_init really applies.  As
+ * speexhip_debug_placement, except that SPEEXHIP_DEVICES=all picks the device with the fewest LIVE states (live[d] for d <
+ * device_count; destroying a state frees its slot), ties going to the first such device in the order k mod n, k + 1 mod
+ * n, ...: a fresh process still deals its states round-robin, a long-running server fills the holes closed connections
+ * leave.  A LIST keeps the counter rule (a reproducible assignment is what the caller asked for).  Host only, pure.
+ * speexhip_debug_live_states(d): states alive on logical device d right now. */
+SPEEXHIP_API int speexhip_debug_placement_live(int device_count, const char *env_device, const char *env_devices,
+                                               uint64_t k, int current_device, const uint32_t *live);
+SPEEXHIP_API uint32_t speexhip_debug_live_states(int device);
+
 /* Which kind of box is this?  Runs ~0.3 ms of packed fp32 FMAs with LDS reads on every CU and reports the shader
  * clock (GHz) the chip held meanwhile (median / slowest workgroup): the pool's boxes differ by 4-6 %, so bench
  * lines and the perf gate (tests/test_gpu_perf_gate.py) quote it.  Diagnostics; blocks the calling thread. */
 SPEEXHIP_API int speexhip_debug_device_clock(double *ghz_median, double *ghz_min);
+
+/* The PCIe link's own rate on this box (round 6): plain pinned copies of `bytes` host -> device (out_gbs[0]), device ->
+ * host (out_gbs[1]) and both at once on two streams (out_gbs[2]: GB/s PER DIRECTION while both run), best of `reps`.
+ * The roofline of the host-fed legs of bench.py (`end_to_end`, `end_to_end_streams`).  Diagnostics; blocks. */
+SPEEXHIP_API int speexhip_debug_pcie_peak(uint64_t bytes, int reps, double out_gbs[3]);
 
 /* Test hook: the n-th next device allocation made while installing a filter fails, as if the
  * device were out of memory (exercises the resampler_basic_zero fallback, and the release of what

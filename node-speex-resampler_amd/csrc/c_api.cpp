@@ -50,6 +50,12 @@ int speexhip_debug_placement(int device_count, const char *env_device, const cha
   return speexhip::devices::placement_rule(device_count, env_device, env_devices, k, current_device);
 }
 
+int speexhip_debug_placement_live(int device_count, const char *env_device, const char *env_devices, uint64_t k,
+                                  int current_device, const uint32_t *live) {
+  return speexhip::devices::placement_rule_live(device_count, env_device, env_devices, k, current_device, live);
+}
+uint32_t speexhip_debug_live_states(int device) { return speexhip::devices::live_states(device); }
+
 SpeexHipResamplerState *speexhip_resampler_init(uint32_t nb_channels, uint32_t in_rate,
                                                 uint32_t out_rate, int quality, int *err) {
   return speexhip_resampler_init_on(-1, nb_channels, in_rate, out_rate, quality, err);

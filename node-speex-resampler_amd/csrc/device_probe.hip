@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "../../include/speexhip_resampler.h"
@@ -64,5 +65,43 @@ extern "C" SPEEXHIP_API int speexhip_debug_device_clock(double *ghz_median, doub
   std::sort(ghz.begin(), ghz.end());
   *ghz_median = ghz[ghz.size() / 2];
   if (ghz_min != nullptr) *ghz_min = ghz.front();
+  return SPEEXHIP_ERR_SUCCESS;
+}
+
+// speexhip_debug_pcie_peak: the link's own rate on this box, the roofline of the host-fed legs of bench.py (round 6).
+// Plain pinned hipMemcpyAsync of `bytes` host -> device, device -> host, and both at once on two non-blocking streams;
+// best of `reps`, in GB/s.  (Through torch's stream pool the two directions of the both-ways case ran one after the
+// other -- 28 + 28 GB/s where this measures 43-48 each way, profiles/r06_ubench_pcie.txt -- hence a probe of the
+// library's own.)  Diagnostics: nothing on the processing path calls this.
+extern "C" SPEEXHIP_API int speexhip_debug_pcie_peak(uint64_t bytes, int reps, double out_gbs[3]) {
+  if (out_gbs == nullptr || bytes == 0 || reps <= 0) return SPEEXHIP_ERR_INVALID_ARG;
+  char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+  hipStream_t s1 = nullptr, s2 = nullptr;
+  bool ok = hipMalloc(&d_in, bytes) == hipSuccess && hipMalloc(&d_out, bytes) == hipSuccess &&
+            hipHostMalloc(&h_in, bytes, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&h_out, bytes, hipHostMallocDefault) == hipSuccess &&
+            hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess;
+  if (ok) ok = hipMemset(d_out, 1, bytes) == hipSuccess;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  for (int which = 0; ok && which < 3; which++) {
+    double best = 1e30;
+    for (int r = 0; ok && r < reps + 2; r++) {  // (two warm-up rounds)
+      const double t0 = now();
+      if (which != 1) ok = ok && hipMemcpyAsync(d_in, h_in, bytes, hipMemcpyHostToDevice, s1) == hipSuccess;
+      if (which != 0) ok = ok && hipMemcpyAsync(h_out, d_out, bytes, hipMemcpyDeviceToHost, s2) == hipSuccess;
+      ok = ok && hipStreamSynchronize(s1) == hipSuccess && hipStreamSynchronize(s2) == hipSuccess;
+      if (r >= 2) best = std::min(best, now() - t0);
+    }
+    out_gbs[which] = static_cast<double>(bytes) / best / 1e9;  // (both ways: per direction)
+  }
+  if (s1 != nullptr) (void)hipStreamDestroy(s1);
+  if (s2 != nullptr) (void)hipStreamDestroy(s2);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  (void)hipHostFree(h_in);
+  (void)hipHostFree(h_out);
+  if (!ok) {
+    (void)hipGetLastError();
+    return SPEEXHIP_ERR_DEVICE;
+  }
   return SPEEXHIP_ERR_SUCCESS;
 }

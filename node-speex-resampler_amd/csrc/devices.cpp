@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +33,8 @@ int alias_count() {  // SPEEXHIP_ALIAS_DEVICES (diagnostics / tests), 0 = off
 }
 
 std::atomic<uint64_t> g_states{0};
+const int kMaxDevices = 64;
+std::atomic<uint32_t> g_live[kMaxDevices];  // states alive per logical device (zero-initialised: static storage)
 
 }  // namespace
 
@@ -80,7 +83,19 @@ int place_next_state() {
   const bool spread = (one == nullptr || one[0] == '\0') && many != nullptr && many[0] != '\0';
   // (the counter only moves when the rule uses it: a process that never sets SPEEXHIP_DEVICES keeps no history)
   const uint64_t k = spread ? g_states.fetch_add(1) : 0;
-  return placement_rule(n, one, many, k, current());
+  uint32_t live[kMaxDevices];
+  for (int d = 0; d < kMaxDevices; d++) live[d] = g_live[d].load(std::memory_order_relaxed);
+  return placement_rule_live(std::min(n, kMaxDevices), one, many, k, current(), live);
+}
+
+void state_born(int device) {
+  if (device >= 0 && device < kMaxDevices) g_live[device].fetch_add(1, std::memory_order_relaxed);
+}
+void state_gone(int device) {
+  if (device >= 0 && device < kMaxDevices) g_live[device].fetch_sub(1, std::memory_order_relaxed);
+}
+uint32_t live_states(int device) {
+  return device >= 0 && device < kMaxDevices ? g_live[device].load(std::memory_order_relaxed) : 0u;
 }
 
 }  // namespace devices

@@ -38,9 +38,22 @@ int placement_rule(int device_count, const char *env_device, const char *env_dev
 // device, or the thread's current device; empty when the environment is invalid or no GPU is visible.
 void placement_candidates(int *out, int *n, int cap);
 
+// Round 6 -- the rule with the load taken into account (pure, host only; speexhip_debug_placement_live): as
+// placement_rule, except that SPEEXHIP_DEVICES=all picks the device with the FEWEST LIVE STATES (live[d], d <
+// device_count; null = all zero), ties going to the first such device in the order k mod n, k+1 mod n, ... -- a fresh
+// process therefore still deals its states round-robin, and a long-running one that destroys states (connections that
+// close) fills the holes instead of piling new states onto whatever the counter points at.  An explicit LIST keeps the
+// counter rule: there the caller asked for a reproducible assignment.
+int placement_rule_live(int device_count, const char *env_device, const char *env_devices, uint64_t k, int current,
+                        const uint32_t *live);
+
 // Device for the next new state of this process by the rule above (advances the state counter);
 // -1 = the environment is invalid for this node (init then fails with SPEEXHIP_ERR_DEVICE).
 int place_next_state();
+// A state now lives on / has left logical device d (Batch::setup, ~Batch): the live counts placement_rule_live reads.
+void state_born(int device);
+void state_gone(int device);
+uint32_t live_states(int device);
 
 }  // namespace devices
 }  // namespace speexhip

@@ -47,5 +47,20 @@ int placement_rule(int device_count, const char *env_device, const char *env_dev
   return current_device >= 0 && current_device < device_count ? current_device : -1;
 }
 
+int placement_rule_live(int device_count, const char *env_device, const char *env_devices, uint64_t k, int current_device,
+                        const uint32_t *live) {
+  const bool one = env_device != nullptr && env_device[0] != '\0';
+  if (device_count > 0 && !one && env_devices != nullptr && std::strcmp(env_devices, "all") == 0 && live != nullptr) {
+    const uint64_t n = static_cast<uint64_t>(device_count);
+    int best = -1;
+    for (uint64_t j = 0; j < n; j++) {
+      const int d = static_cast<int>((k + j) % n);
+      if (best < 0 || live[d] < live[best]) best = d;
+    }
+    return best;
+  }
+  return placement_rule(device_count, env_device, env_devices, k, current_device);
+}
+
 }  // namespace devices
 }  // namespace speexhip

@@ -3,6 +3,7 @@
 
 #include "devices.h"
 #include "pool.h"
+#include "unit_workers.h"
 
 #include <algorithm>
 #include <atomic>
@@ -196,6 +197,8 @@ int wait_done(hipStream_t stream, volatile uint32_t *word, uint32_t seq, uint32_
   if (!signalled) HIP_TRY(hipStreamSynchronize(stream));
   return SPEEXHIP_ERR_SUCCESS;
 }
+// A/B (diagnostics build): a large pinned input through the copy engines in pieces (take_in_pieces) instead of read in place
+bool pinned_in_pieces() { return diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_PINNED_IN_PIECES"), 0) != 0; }
 // how long such a call may spin: 300 us for the launch itself plus what `bytes` take to cross PCIe (~40 GB/s), 2 ms at most
 uint32_t spin_budget_us(size_t bytes) { return static_cast<uint32_t>(std::min<size_t>(2000, 300 + bytes / 40000)); }
 }  // namespace
@@ -321,6 +324,8 @@ int Batch::setup() {
   int rc = install_filter(designed, std::vector<float>(), designed.taps - 1);  // resample.c:721-725: silence
   trace.step("install_filter (total)");
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
+  devices::state_born(device_);  // (the live count the placement rule balances: devices.h, round 6)
+  counted_ = true;
   return SPEEXHIP_ERR_SUCCESS;  // (install_filter waited for its own uploads)
 }
 
@@ -835,6 +840,7 @@ int Batch::reset_mem() {  // resample.c:1208-1220
 
 Batch::~Batch() {
   if (device_ < 0) return;  // setup() never got as far as a device
+  if (counted_) devices::state_gone(device_);
   DeviceScope device_scope(device_);
   // everything goes back to the pool (pool.h) for the next state, once nothing in flight uses it:
   // this batch's calls are chained, so the tail of its last stream is all there is to wait for
@@ -1300,7 +1306,7 @@ int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len
   // and only the last one rolls the history.  SPEEXHIP_PIECES=1 turns it off, =n forces n (A/B, tests).
   const uint32_t env_pieces = static_cast<uint32_t>(std::max(0, diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_PIECES"), 0)));
   uint32_t pieces = env_pieces > 0 ? env_pieces : static_cast<uint32_t>(in_bytes / kPieceBytes);
-  pieces = std::min<uint32_t>(pieces, kMaxPieces);
+  pieces = std::min<uint32_t>(pieces, env_pieces > 0 ? kMaxPieces : 4);  // (the rule: at most four; up to kMaxPieces when forced)
   // Round 6: an input the caller left in pinned memory (speexhip_block_acquire, or memory it pinned itself) is read where
   // it lies -- ONE launch whose loads and stores cross PCIe in opposite directions at the same time, no staging copy, no
   // second stream (the pieces above overlap the two directions only partly and pay ~15 us per piece for it).
@@ -1308,7 +1314,7 @@ int Batch::process_host_take(const void *in, uint32_t *in_len, uint32_t *out_len
   if (split || zero_mode_) {
     rc = process_host(in, in_len, blk, out_len, float_io);
     if (rc != SPEEXHIP_ERR_SUCCESS && rc != SPEEXHIP_ERR_ALLOC_FAILED) return rc;
-  } else if (pin_in == nullptr && pieces >= 2 && in != nullptr && in_bytes >= kZeroCopyBelow && frames < 0x40000000u && have_copy_stream()) {
+  } else if ((pin_in == nullptr || pinned_in_pieces()) && pieces >= 2 && in != nullptr && in_bytes >= kZeroCopyBelow && frames < 0x40000000u && have_copy_stream()) {
     rc = take_in_pieces(in, in_len, out_len, float_io, blk, pieces);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   } else {
@@ -1836,6 +1842,12 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
         launches.emplace_back(g.begin() + g0, g.begin() + std::min(g.size(), g0 + per));
     }
   }
+  auto commit_item = [&](Item &it) {  // counters and position of one state
+    for (uint32_t c = 0; c < it.b->channels_; c++) it.b->P(0, c) = it.plan.end;
+    in_len[it.i] = it.plan.consumed;
+    out_len[it.i] = it.plan.produced;
+    rcs[it.i] = SPEEXHIP_ERR_SUCCESS;
+  };
   // one launch of `launches[k]` on `stream`
   auto launch = [&](const std::vector<Item *> &g, hipStream_t stream) -> int {
     const uint32_t cnt = static_cast<uint32_t>(g.size());
@@ -1868,16 +1880,20 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     }
     const int lrc = g[0]->b->launch_chunk(pack.d, pack, cnt, max_out, float_io, stream);
     if (lrc != SPEEXHIP_ERR_SUCCESS) return lrc;
-    for (uint32_t j = 0; j < cnt; j++) g[j]->b->hist_cur_ ^= 1;
+    // A state moves as ONE step, the moment its launch is queued: the history ping-pong, the position and the counters
+    // together.  (Until round 6 the flip happened here and the positions behind the last launch of the call: a later
+    // group's failure left the earlier groups' states with a flipped history and their OLD position -- silently corrupt
+    // for every later call, ADVICE r5.  Now a failure further on costs such a state this call's audio -- its code says
+    // so -- and nothing else; states whose launch was never queued have not moved at all.)
+    for (uint32_t j = 0; j < cnt; j++) {
+      g[j]->b->hist_cur_ ^= 1;
+      commit_item(*g[j]);
+    }
     return SPEEXHIP_ERR_SUCCESS;
   };
-  auto commit = [&]() {  // counters and positions of every fused state
-    for (Item &it : items) {
-      for (uint32_t c = 0; c < it.b->channels_; c++) it.b->P(0, c) = it.plan.end;
-      in_len[it.i] = it.plan.consumed;
-      out_len[it.i] = it.plan.produced;
-      rcs[it.i] = SPEEXHIP_ERR_SUCCESS;
-    }
+  auto commit = [&]() {  // ... and the states with nothing to run: counters of an empty call, position unchanged
+    for (Item &it : items)
+      if (!it.work) commit_item(it);
   };
 
   static const int env_pipe2 = SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_PIPELINE") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_PIPELINE")) : -1;
@@ -1904,7 +1920,7 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     bool copy_failed = false;
     int worker_rc = SPEEXHIP_ERR_SUCCESS;
     std::string worker_err;
-    std::thread worker([&] {
+    auto helper = [&] {
       DeviceScope scope(device);
       try {
       for (size_t k = 0; k < launches.size() && worker_rc == SPEEXHIP_ERR_SUCCESS; k++) {
@@ -1941,7 +1957,11 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
       } catch (...) {  // (a host allocation inside a launcher: no exception leaves a thread)
         worker_rc = SPEEXHIP_ERR_ALLOC_FAILED;
       }
-    });
+    };
+    // (the launching half runs on this (device, lane)'s persistent helper thread -- unit_workers.h; until round 6 a
+    //  std::thread made and joined inside every such call.  No thread to be had: the call falls back to one thread,
+    //  copies first, launches after -- the helper's loop then finds every event recorded already.)
+    workers::Ticket helper_job = workers::submit(workers::key_of(device, lane, 1), helper);
     hipError_t copy_err = hipSuccess;
     for (size_t k = 0; k < launches.size() && copy_err == hipSuccess; k++) {
       for (Item *it : launches[k])
@@ -1957,7 +1977,12 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
       }
       cv.notify_all();
     }
-    worker.join();
+    if (helper_job != nullptr) {
+      workers::wait(helper_job);
+      if (workers::failed(helper_job)) worker_rc = SPEEXHIP_ERR_ALLOC_FAILED;
+    } else {
+      helper();
+    }
     if (hip_failed(copy_err, "hipMemcpyAsync (inputs)")) return SPEEXHIP_ERR_DEVICE;
     if (worker_rc != SPEEXHIP_ERR_SUCCESS) {
       g_last_error = worker_err;
@@ -2060,6 +2085,12 @@ int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in
       dev_rc[slot] = many_on_device(u.device, u.lane, u.idx, st, in, in_len, out, out_len, float_io, rcs.data());
     } catch (const std::bad_alloc &) {
       dev_rc[slot] = SPEEXHIP_ERR_ALLOC_FAILED;
+    } catch (const std::exception &e) {  // (anything else: a code and its text, never std::terminate in a worker)
+      g_last_error = std::string("internal error: ") + e.what();
+      dev_rc[slot] = SPEEXHIP_ERR_DEVICE;
+    } catch (...) {
+      g_last_error = "internal error: unknown exception";
+      dev_rc[slot] = SPEEXHIP_ERR_DEVICE;
     }
     if (dev_rc[slot] != SPEEXHIP_ERR_SUCCESS) {
       dev_err[slot] = g_last_error;  // (the text lives per thread)
@@ -2067,12 +2098,21 @@ int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in
     }
   };
   {
-    // GPUs side by side: every further unit of the call gets a thread of its own (a GPU is a PCIe link of its own,
-    // and the runtime's pageable copies keep the calling thread busy while they run)
-    std::vector<std::thread> workers;
-    for (size_t slot = 1; slot < units.size(); slot++) workers.emplace_back(run_device, slot);
+    // GPUs side by side: every further unit of the call runs on the persistent thread of its (device, lane) -- a GPU
+    // is a PCIe link of its own, and the runtime's pageable copies keep the thread that issues them busy -- while the
+    // calling thread runs the first one (unit_workers.h: one thread per (device, lane) for the life of the process;
+    // until round 6 a std::thread per unit per CALL, 7-15 thread creations per step on an 8-GPU node).  A unit whose
+    // job cannot be queued runs here, after the first.
+    std::vector<workers::Ticket> tickets(units.size());
+    for (size_t slot = 1; slot < units.size(); slot++)
+      tickets[slot] = workers::submit(workers::key_of(units[slot].device, units[slot].lane, 0), [&run_device, slot] { run_device(slot); });
     if (!units.empty()) run_device(0);
-    for (std::thread &w : workers) w.join();
+    for (size_t slot = 1; slot < units.size(); slot++) {
+      if (tickets[slot] != nullptr)
+        workers::wait(tickets[slot]);
+      else
+        run_device(slot);
+    }
     for (size_t k = 0; k < dev_rc.size(); k++)
       if (dev_rc[k] != SPEEXHIP_ERR_SUCCESS) {
         g_last_error = dev_err[k];

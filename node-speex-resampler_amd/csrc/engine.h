@@ -169,6 +169,7 @@ class Batch {
   FilterSpec filter_;
   uint32_t n_streams_ = 0, channels_ = 0;
   int device_ = 0;
+  bool counted_ = false;  // this state is in its device's live count (devices::state_born)
   int mode_ = SPEEXHIP_MODE_FAST;
   std::vector<StreamPos> pos_;    // [stream][channel] (the reference keeps them per channel, resample.c:135-137;
                                   // interleaved calls move all channels of a stream together)
@@ -231,7 +232,7 @@ class Batch {
   // host-buffer path (single stream)
   hipStream_t own_stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;   // input copies of a piecewise call (another of the pool's streams)
-  static const int kMaxPieces = 4;
+  static const int kMaxPieces = 8;
   hipEvent_t piece_ev_[kMaxPieces] = {};
   char *d_stage_in_ = nullptr, *d_stage_out_ = nullptr;
   char *h_pin_in_ = nullptr, *h_pin_out_ = nullptr;

@@ -488,9 +488,16 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
 }
 
 namespace {
-hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const float *d_rows, uint32_t channels,
+hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &plan, const float *d_rows, uint32_t channels,
                               const StreamDesc *h_descs, const DescPack *pack,
                               uint32_t n_streams, bool float_io, hipStream_t stream, PeriodShape *probe, bool fixed_shape) {
+  PeriodPlan t = plan;
+#ifdef SPEEXHIP_DIAG
+  {  // A/B: fewer periods per tile than the plan's (more, smaller workgroups over the same LDS allocation)
+    const int tp = diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_TILE_PERIODS"), 0);
+    if (tp > 0 && static_cast<uint32_t>(tp) < t.lane_periods && probe == nullptr) t.lane_periods = static_cast<uint32_t>(tp);
+  }
+#endif
   const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
   const uint32_t resident = 2 * device_compute_units();  // two workgroups fit per CU

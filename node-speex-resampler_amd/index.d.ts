@@ -1,6 +1,8 @@
 /// <reference types="node" />
-// Type declarations of the drop-in (hand-written; the reference ships tsc output with `any`
-// arguments -- the call signatures below accept everything that one accepts).
+// Type declarations of the drop-in (hand-written).  The reference ships tsc output that types `channels`, `inRate` and
+// `outRate` as `any` (app/index.d.ts:4-6, 23, 31-33, 44): so do the constructors and fields below -- a TypeScript caller
+// that compiles against the reference (rates held as strings, say: they are coerced like the reference coerces them)
+// compiles against the drop-in.
 import { Transform, TransformCallback } from 'stream';
 
 /**
@@ -34,6 +36,13 @@ export interface SpeexResamplerTransformOptions {
      */
     pipeline?: boolean;
     maxHeld?: number;
+    /**
+     * Copy every chunk ONCE into a pinned chunk of the library (a small ring of `SpeexResampler.allocChunk` Buffers,
+     * reused) so that the GPU reads it in place.  With `coalesceChunks`, `async` or `pipeline` this is the copy those
+     * modes make anyway, landing in pinned memory; in the plain mode it replaces the library's own copy into its bounce
+     * buffer.  Same bytes out.  A producer that fills chunks from `allocChunk` itself needs no option.
+     */
+    pinned?: boolean;
 }
 
 /**
@@ -44,9 +53,9 @@ declare class SpeexResampler {
     /** resolves once the native module is loaded; `processChunk` throws before that */
     static initPromise: Promise<unknown>;
 
-    channels: number;
-    inRate: number;
-    outRate: number;
+    channels: any;
+    inRate: any;
+    outRate: any;
     /** Speex quality, 0..10 */
     quality: number;
     /** native state handle, created by the first call */
@@ -59,12 +68,20 @@ declare class SpeexResampler {
      * library places it when its native state is made: the process's current GPU, or -- environment
      * SPEEXHIP_DEVICES=all -- instance number k of the process on GPU k mod the GPU count (SPEEXHIP_DEVICE=k: all on k).
      */
-    constructor(channels: number, inRate: number, outRate: number, quality?: number, options?: { device?: number });
+    constructor(channels: any, inRate: any, outRate: any, quality?: number, options?: { device?: number });
 
     /** GPU the instance lives on (-1 until the first call made its native state) */
     readonly device: number;
     /** GPUs the library can place instances on */
     static deviceCount(): number;
+    /**
+     * Extension: a Buffer over a PINNED block of the native library for the caller to fill (read a file or a socket into
+     * it, let a decoder write it) and pass to any processChunk* method or to SpeexResamplerBatch: the GPU reads the chunk
+     * where it lies, through PCIe, while it writes the result -- no staging copy (the reference copies every chunk into
+     * the WASM heap).  Same result bytes as for an ordinary Buffer; an ordinary Buffer comes back when no block is free.
+     * Refill it once the call that read it has returned (or its promise has settled).
+     */
+    static allocChunk(bytes: number): Buffer;
 
     /**
      * interleaved s16le PCM in, resampled s16le PCM out: a fresh Buffer the caller owns, like the reference's.
@@ -116,14 +133,14 @@ declare class SpeexResampler {
 
 /** `stream.Transform` around a SpeexResampler; misaligned trailing bytes wait for the next chunk. */
 export declare class SpeexResamplerTransform extends Transform {
-    channels: number;
-    inRate: number;
-    outRate: number;
+    channels: any;
+    inRate: any;
+    outRate: any;
     quality: number;
     resampler: SpeexResampler;
     _alignementBuffer: Buffer;
 
-    constructor(channels: number, inRate: number, outRate: number, quality?: number,
+    constructor(channels: any, inRate: any, outRate: any, quality?: number,
                 options?: SpeexResamplerTransformOptions);
     _transform(chunk: Buffer, encoding: string, callback: TransformCallback): void;
 }
@@ -135,13 +152,13 @@ export declare class SpeexResamplerTransform extends Transform {
  * listed GPU modulo their number).  Entry k of a result equals `streams[k].processChunk(chunks[k])`.
  */
 export declare class SpeexResamplerBatch {
-    channels: number;
-    inRate: number;
-    outRate: number;
+    channels: any;
+    inRate: any;
+    outRate: any;
     quality: number;
     streams: SpeexResampler[];
     readonly length: number;
-    constructor(nStreams: number, channels: number, inRate: number, outRate: number, quality?: number,
+    constructor(nStreams: number, channels: any, inRate: any, outRate: any, quality?: number,
                 options?: { devices?: number[] });
     /** one chunk per stream (null: the stream sits the step out) -> one fresh Buffer per stream (null likewise) */
     processChunks(chunks: Array<Buffer | null>): Array<Buffer | null>;

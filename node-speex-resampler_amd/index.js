@@ -279,6 +279,21 @@ SpeexResampler.deviceCount = () => {
   return speexModule.deviceCount();
 };
 
+/**
+ * Extension (round 6): a Buffer of `bytes` bytes over a PINNED block of the library for the caller to fill -- read a file
+ * or a socket into it, let a decoder write into it -- and hand to processChunk / processChunks / SpeexResamplerBatch.
+ * The library recognises its own blocks and lets the GPU read the chunk where it lies, through PCIe, while it writes the
+ * result block: no staging copy (the reference copies every chunk into the WASM heap, src/index.ts:71-92).  Results are
+ * the same bytes as for an ordinary Buffer.  When no block is free an ordinary Buffer comes back (same results, the usual
+ * staging).  The chunk may be refilled as soon as the call that read it has returned / its promise has settled.
+ */
+SpeexResampler.allocChunk = (bytes) => {
+  if (!speexModule) {
+    throw new Error('You need to wait for SpeexResampler.initPromise before calling this method');
+  }
+  return speexModule.allocChunk(bytes);
+};
+
 // processChunkAsync calls that became ready in this tick (see there)
 const tickQueue = [];
 let tickScheduled = false;
@@ -300,7 +315,20 @@ function flushTick() {
     return;
   }
   promise.then((outs) => { jobs.forEach((j, i) => j.resolve(outs[i])); },
-    (e) => { for (const j of jobs) j.reject(e); });
+    (e) => {
+      // The instances of a tick are independent (the reference's model: one failing instance does not touch the
+      // others): when the native call ran, its error carries every entry's own code and result -- entries that
+      // succeeded have advanced and get their audio, only the offending ones reject.
+      if (e && Array.isArray(e.codes) && Array.isArray(e.results) && e.codes.length === jobs.length) {
+        const first = e.codes.find((c) => c !== 0);
+        jobs.forEach((j, i) => {
+          if (e.codes[i] === 0) j.resolve(e.results[i]);
+          else j.reject(e.codes[i] === first ? e : new Error(speexModule.strerror(e.codes[i])));
+        });
+      } else {
+        for (const j of jobs) j.reject(e);
+      }
+    });
 }
 
 /**
@@ -387,8 +415,15 @@ class SpeexResamplerBatch {
     //  results were sized from the streams' counters when the step was queued)
     for (const k of g.index) this.streams[k]._inFlight++;
     const settle = () => { for (const k of g.index) this.streams[k]._inFlight--; };
-    const p = (this._pending || Promise.resolve()).then(run, run);
-    this._pending = p.then(settle, settle);
+    // The step waits for the batch's previous step AND for what its streams have pending of their own
+    // (streams[k].processChunkAsync), and later asynchronous calls of those streams wait for the step: a stream's calls
+    // stay in the order they were made, whichever object they were made through (ADVICE r5 -- the native call
+    // checks the same thing again under its locks and refuses the step rather than overrun a result).
+    const before = [this._pending].concat(g.index.map((k) => this.streams[k]._pending)).filter(Boolean);
+    const p = Promise.all(before.map((q) => q.then(() => {}, () => {}))).then(run);
+    const done = p.then(settle, settle);
+    this._pending = done;
+    for (const k of g.index) this.streams[k]._pending = done;
     return p;
   }
 
@@ -421,6 +456,11 @@ class SpeexResamplerTransform extends Transform {
    *   pipeline: true     -- off the event loop AND batched by load: a chunk that arrives while a call is in flight is
    *                         held, and everything held leaves as ONE call when that one returns (an idle stream sends each
    *                         chunk at once; a busy one sends few, large launches).  Same bytes out.
+   *   pinned: true       -- every chunk is copied ONCE into a pinned chunk of the library (SpeexResampler.allocChunk: a ring
+   *                         of them, reused) and the GPU reads it there -- in the modes that hold chunks (coalesceChunks,
+   *                         async, pipeline) that is the copy they make anyway, landing in pinned memory instead of an
+   *                         ordinary Buffer.  Same bytes out.  (A producer that can fill chunks from allocChunk itself needs
+   *                         no option: pinned chunks are recognised wherever they arrive.)
    */
   constructor(channels, inRate, outRate, quality = 7, options = undefined) {
     super();
@@ -476,6 +516,7 @@ class SpeexResamplerTransform extends Transform {
     }
     this.resampler.processChunksAsync(batch).then((outs) => {
       for (const out of outs) this.push(out);
+      for (const h of batch) this._recycle(h);
       this._busy = false;
       if (this._held.length > 0) {
         this._pump();
@@ -492,18 +533,45 @@ class SpeexResamplerTransform extends Transform {
     });
   }
 
+  // pinned: a copy of `chunk` in a pinned chunk of the library (a plain copy when none is to be had).  Chunks come from a
+  // small free list by size class; one is free again once the call that read it has returned -- _recycle().
+  _pinnedCopy(chunk) {
+    if (chunk.length === 0) return chunk;
+    if (!this._ring) this._ring = new Map();
+    let cls = 4096;
+    while (cls < chunk.length) cls *= 2;
+    const free = this._ring.get(cls);
+    const slab = free && free.length > 0 ? free.pop() : SpeexResampler.allocChunk(cls);
+    chunk.copy(slab, 0, 0, chunk.length);
+    const view = slab.slice(0, chunk.length);
+    view._slab = slab;
+    view._cls = cls;
+    return view;
+  }
+
+  _recycle(view) {
+    if (!view || !view._slab || !this._ring) return;
+    let free = this._ring.get(view._cls);
+    if (!free) this._ring.set(view._cls, free = []);
+    if (free.length < 8) free.push(view._slab);
+  }
+
+  // the copy a held chunk needs anyway (it must not change under us while it waits for its call)
+  _own(chunk) { return this._options.pinned ? this._pinnedCopy(chunk) : Buffer.from(chunk); }
+
   _emitHeld() {
     if (this._held.length === 0) return;
     const held = this._held;
     this._held = [];
     for (const out of this.resampler.processChunks(held)) this.push(out);
+    for (const h of held) this._recycle(h);
   }
 
   _transform(chunk, encoding, callback) {
     if (this._options.pipeline) {
       try {
         // (a copy: the held chunk must not change under us while it waits for its call)
-        this._held.push(Buffer.from(this._align(chunk)));
+        this._held.push(this._own(this._align(chunk)));
       } catch (e) {
         callback(e);
         return;
@@ -516,6 +584,19 @@ class SpeexResamplerTransform extends Transform {
     }
     if (this._options.coalesceChunks > 1 || this._options.async) {
       return this._transformExtended(chunk, callback);
+    }
+    if (this._options.pinned) {  // the reference's one synchronous call per chunk, on a pinned copy of the chunk
+      let out;
+      try {
+        const own = this._pinnedCopy(this._align(chunk));
+        out = this.resampler.processChunk(own);
+        this._recycle(own);
+      } catch (err) {
+        callback(err);
+        return;
+      }
+      callback(null, out);
+      return;
     }
     return this._transformReference(chunk, encoding, callback);
   }
@@ -538,13 +619,16 @@ class SpeexResamplerTransform extends Transform {
   _transformExtended(chunk, callback) {
     try {
       // copy: a held chunk must not change under us while it waits for its launch
-      const aligned = Buffer.from(this._align(chunk));
+      const aligned = this._own(this._align(chunk));
       if (this._options.coalesceChunks > 1) {
         this._held.push(aligned);
         if (this._held.length >= this._options.coalesceChunks) this._emitHeld();
         callback();
       } else {
-        this.resampler.processChunkAsync(aligned).then((res) => callback(null, res), callback);
+        this.resampler.processChunkAsync(aligned).then((res) => {
+          this._recycle(aligned);
+          callback(null, res);
+        }, callback);
       }
     } catch (e) {
       callback(e);

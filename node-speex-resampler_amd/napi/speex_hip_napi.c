@@ -150,6 +150,7 @@ static const size_t kExternalMin = 4096;            /* below this a copy is chea
  *  finalizers run on whichever thread owns the Buffer: every access is an atomic builtin) */
 static size_t g_external_bytes = 0;
 static size_t g_take_calls = 0, g_take_no_block = 0; /* stats(): results left in pinned blocks / slab full, copied instead */
+static size_t g_pinned_chunks = 0;                   /* stats(): allocChunk() calls served with a pinned block */
 static int g_no_external = 0; /* SPEEXHIP_NAPI_COPY=1: always copy (A/B, tests) */
 static void finalize_block(napi_env env, void *data, void *hint) {
   const size_t bytes = (size_t)hint;
@@ -734,6 +735,7 @@ typedef struct {
   napi_ref *refs;           /* handles, chunks, result Buffers: 3 per entry (chunk ref may be NULL) */
   napi_ref result_ref;      /* the result array */
   int rc;
+  int ran;                  /* the library call was made: codes[] says which entries succeeded */
   char errmsg[256];
 } ManyJob;
 
@@ -778,10 +780,27 @@ static void many_run(ManyJob *j) {
       return;
     }
   }
+  /* The result Buffers were sized from the states' counters when the call was prepared (will_make).  The asynchronous
+   * form released the locks in between: if a state has moved since (another call of that instance slipped in), the
+   * library would now write a different number of frames -- possibly more than the Buffer holds.  Ask again, under the
+   * locks, BEFORE anything is written, and refuse the step whole. */
+  for (uint32_t i = 0; i < j->n; i++) {
+    uint32_t will_use = 0, will_make = 0;
+    speexhip_resampler_peek(j->st[i], j->in_len[i], j->out_len[i], 0, &will_use, &will_make);
+    if (will_make != j->will_make[i]) {
+      j->rc = SPEEXHIP_ERR_BAD_STATE;
+      snprintf(j->errmsg, sizeof(j->errmsg), "%s (a state of this step was used by another call while the step was pending)",
+               speexhip_resampler_strerror(j->rc));
+      return;
+    }
+  }
   j->rc = speexhip_resampler_process_many_int(j->n, j->st, j->in, j->in_len, j->out, j->out_len, j->codes);
-  if (j->rc == 0)
-    for (uint32_t i = 0; i < j->n; i++)
-      if (j->out_len[i] != j->will_make[i]) j->rc = SPEEXHIP_ERR_BAD_STATE;
+  j->ran = 1;
+  for (uint32_t i = 0; i < j->n; i++)
+    if (j->codes[i] == 0 && j->out_len[i] != j->will_make[i]) {
+      j->codes[i] = SPEEXHIP_ERR_BAD_STATE;
+      if (j->rc == 0) j->rc = SPEEXHIP_ERR_BAD_STATE;
+    }
   if (j->rc != 0) snprintf(j->errmsg, sizeof(j->errmsg), "%s", speexhip_resampler_strerror(j->rc));
 }
 
@@ -877,7 +896,30 @@ static ManyJob *many_prepare(napi_env env, napi_callback_info info, napi_value *
       speexhip_resampler_peek(st, j->in_len[i], j->out_len[i], 0, &will_use, &j->will_make[i]);
       napi_value buf;
       void *dst = NULL;
-      if (napi_create_buffer(env, (size_t)j->will_make[i] * frame_bytes, &dst, &buf) != napi_ok ||
+      /* Round 6: like process(), results of a few KB and more are pinned blocks of the library handed to JavaScript
+       * as external Buffers -- the library recognises its own blocks among the out[] pointers and lets the kernel
+       * write them in place (no copy out of a staging buffer).  No block free, or a runtime without external
+       * Buffers: an ordinary Buffer, as before. */
+      const size_t made_bytes = (size_t)j->will_make[i] * frame_bytes;
+      int have = 0;
+      if (made_bytes >= kExternalMin && !g_no_external) {
+        void *block = speexhip_block_acquire(made_bytes);
+        if (block != NULL) {
+          if (napi_create_external_buffer(env, made_bytes, block, finalize_block, (void *)made_bytes, &buf) == napi_ok) {
+            int64_t adjusted = 0;
+            __atomic_fetch_add(&g_external_bytes, made_bytes, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&g_take_calls, 1, __ATOMIC_RELAXED);
+            (void)napi_adjust_external_memory(env, (int64_t)made_bytes, &adjusted);
+            dst = block;
+            have = 1;
+          } else {
+            speexhip_block_release(block);
+          }
+        } else {
+          __atomic_fetch_add(&g_take_no_block, 1, __ATOMIC_RELAXED);
+        }
+      }
+      if ((!have && napi_create_buffer(env, made_bytes, &dst, &buf) != napi_ok) ||
           napi_set_element(env, *result, i, buf) != napi_ok ||
           (keep_refs && napi_create_reference(env, buf, 1, &j->refs[3 * i + 2]) != napi_ok)) {
         fail = "speexhip N-API failure: building the result array";
@@ -934,6 +976,18 @@ static void many_complete(napi_env env, napi_status status, void *data) {
     napi_value msg;
     napi_create_string_utf8(env, j->rc != 0 ? j->errmsg : "speexhip: asynchronous call failed", NAPI_AUTO_LENGTH, &msg);
     napi_create_error(env, NULL, msg, &v);
+    /* When the library call was made, every entry has an outcome of its own (codes[i]; the states of the entries
+     * that succeeded HAVE advanced and their audio is in results[i]): the error carries both, so that a caller who
+     * coalesced independent instances can settle each one by itself (index.js, flushTick) -- in the reference only the
+     * offending instance fails. */
+    napi_value codes, results, c;
+    if (status == napi_ok && j->ran && napi_create_array_with_length(env, j->n, &codes) == napi_ok &&
+        napi_get_reference_value(env, j->result_ref, &results) == napi_ok) {
+      for (uint32_t i = 0; i < j->n; i++)
+        if (napi_create_int32(env, j->codes[i], &c) == napi_ok) napi_set_element(env, codes, i, c);
+      napi_set_named_property(env, v, "codes", codes);
+      napi_set_named_property(env, v, "results", results);
+    }
     napi_reject_deferred(env, j->deferred, v);
   }
   napi_delete_async_work(env, j->work);
@@ -993,6 +1047,40 @@ static napi_value Warmup(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+/* allocChunk(bytes) -> Buffer over a pinned block of the library (speexhip_block_acquire) for the caller to FILL -- read
+ * a file or a socket into it, let a decoder write it -- and pass to process() / processMany(): the library recognises its
+ * own blocks and lets the kernel read the chunk in place through PCIe, where an ordinary Buffer is first copied into
+ * staging memory (the reference copies every chunk into the WASM heap, src/index.ts:71-92).  The block goes back to the
+ * pool when the Buffer is collected.  No block free, a runtime without external Buffers, or SPEEXHIP_NAPI_COPY=1: an
+ * ordinary Buffer of that size -- same results, the usual staging. */
+static napi_value AllocChunk(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], buf;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  double want = 0;
+  if (argc < 1 || napi_get_value_double(env, argv[0], &want) != napi_ok || !(want >= 0) || want > 4294967295.0) {
+    napi_throw_range_error(env, NULL, "allocChunk expects a size in bytes");
+    return NULL;
+  }
+  const size_t bytes = (size_t)want;
+  if (bytes >= kExternalMin && !g_no_external) {
+    void *block = speexhip_block_acquire(bytes);
+    if (block != NULL) {
+      if (napi_create_external_buffer(env, bytes, block, finalize_block, (void *)bytes, &buf) == napi_ok) {
+        int64_t adjusted = 0;
+        __atomic_fetch_add(&g_external_bytes, bytes, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_pinned_chunks, 1, __ATOMIC_RELAXED);
+        (void)napi_adjust_external_memory(env, (int64_t)bytes, &adjusted);
+        return buf;
+      }
+      speexhip_block_release(block);
+    }
+  }
+  void *data = NULL;
+  NAPI_OK(napi_create_buffer(env, bytes, &data, &buf));
+  return buf;
+}
+
 /* deviceCount() -> GPUs the library can place states on (speexhip_device_count) */
 static napi_value DeviceCount(napi_env env, napi_callback_info info) {
   (void)info;
@@ -1013,6 +1101,8 @@ static napi_value Stats(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_set_named_property(env, obj, "takeCalls", v));
   NAPI_OK(napi_create_double(env, (double)__atomic_load_n(&g_take_no_block, __ATOMIC_RELAXED), &v));
   NAPI_OK(napi_set_named_property(env, obj, "takeNoBlock", v));
+  NAPI_OK(napi_create_double(env, (double)__atomic_load_n(&g_pinned_chunks, __ATOMIC_RELAXED), &v));
+  NAPI_OK(napi_set_named_property(env, obj, "pinnedChunks", v));
   return obj;
 }
 
@@ -1047,6 +1137,7 @@ NAPI_MODULE_INIT() {
       {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
       {"warmup", NULL, Warmup, NULL, NULL, NULL, napi_default, NULL},
       {"stats", NULL, Stats, NULL, NULL, NULL, napi_default, NULL},
+      {"allocChunk", NULL, AllocChunk, NULL, NULL, NULL, napi_default, NULL},
   };
   if (napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props) != napi_ok)
     napi_throw_error(env, NULL, "speexhip: cannot define exports");

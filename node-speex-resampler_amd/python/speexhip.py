@@ -56,7 +56,7 @@ EXPORTS = [
     "speexhip_resampler_process_many_int", "speexhip_resampler_process_many_float",
     "speexhip_resampler_get_info2", "speexhip_debug_placement", "speexhip_warmup",
     # round 6: pinned blocks the caller fills (inputs used in place)
-    "speexhip_block_acquire",
+    "speexhip_block_acquire", "speexhip_debug_pcie_peak", "speexhip_debug_placement_live", "speexhip_debug_live_states",
 ]
 
 
@@ -213,6 +213,12 @@ def lib():
         if hasattr(L, "speexhip_block_acquire") or "SPEEXHIP_LIB_PATH" not in os.environ:
             L.speexhip_block_acquire.restype = C.c_void_p
             L.speexhip_block_acquire.argtypes = [C.c_uint64]
+            L.speexhip_debug_placement_live.restype = i32
+            L.speexhip_debug_placement_live.argtypes = [i32, C.c_char_p, C.c_char_p, C.c_uint64, i32, C.POINTER(C.c_uint32)]
+            L.speexhip_debug_live_states.restype = C.c_uint32
+            L.speexhip_debug_live_states.argtypes = [i32]
+            L.speexhip_debug_pcie_peak.restype = i32
+            L.speexhip_debug_pcie_peak.argtypes = [C.c_uint64, i32, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -300,6 +306,13 @@ def placement(device_count_, env_device, env_devices, k, current=0):
     return lib().speexhip_debug_placement(device_count_, enc(env_device), enc(env_devices), k, current)
 
 
+def placement_live(device_count_, env_device, env_devices, k, current, live):
+    """host-only: the placement rule with live state counts per device (speexhip_debug_placement_live)"""
+    enc = lambda v: None if v is None else str(v).encode()
+    arr = (C.c_uint32 * max(len(live), 1))(*live)
+    return lib().speexhip_debug_placement_live(device_count_, enc(env_device), enc(env_devices), k, current, arr)
+
+
 def process_many(states, chunks, capacities, dtype=np.int16):
     """speexhip_resampler_process_many_int / _float: chunks[i] (frames x channels, or None with capacities[i] =
     (null_frames, capacity)) through states[i], all in one call.  Returns (outputs, consumed, codes)."""
@@ -352,6 +365,15 @@ class PinnedBlock:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def pcie_peak(nbytes, reps=6):
+    """(h2d, d2h, each way with both at once) GB/s of plain pinned copies of nbytes: speexhip_debug_pcie_peak"""
+    out = (C.c_double * 3)()
+    rc = lib().speexhip_debug_pcie_peak(int(nbytes), int(reps), out)
+    if rc:
+        raise RuntimeError(strerror(rc))
+    return tuple(out)
 
 
 def device_clock():

@@ -100,6 +100,101 @@ function goldenTest() {
   console.log(`golden cases checked through the JS API: ${checked}`);
 }
 
+// VERDICT r5 #8: the round-5 surface -- SpeexResamplerBatch.processChunks and the same-tick coalescer of
+// processChunkAsync -- anchored to the REFERENCE's bytes (tests/golden/golden.json: digests captured from the reference's
+// own C), not to separate instances of this library: the small-chunk capacity case (F5: 640-byte chunks, input dropped),
+// a ragged 8-channel down-sampler, a ragged up-sampler and the reference's own stream test tuple (44.1k -> 48k stereo q7 in
+// 64 KiB chunks; its tonal input comes from the Python harness, checked against the golden input digest).  EXACT mode
+// must reproduce out_sha1 through both paths; FAST within +-1 LSB of those bytes.  Also (round 6) with every chunk in a
+// pinned chunk from SpeexResampler.allocChunk, and through the Transform's `pinned` option.
+async function goldenBatchTest() {
+  const extra = process.env.SPEEXHIP_TEST_INPUTS ? JSON.parse(fs.readFileSync(process.env.SPEEXHIP_TEST_INPUTS)) : {};
+  const names = ['f5_640B_chunks', 'f5_ragged_down_8ch', 'f5_ragged_up', 't_44100_48000_2ch_q7_64k'];
+  let ran = 0;
+  for (const name of names) {
+    const c = golden.cases.find((x) => x.name === name);
+    assert(c, `golden case ${name} missing`);
+    let pcm;
+    if (c.input === 'lcg') pcm = lcg(c.frames, c.channels, c.seed);
+    else if (extra[name]) pcm = Buffer.from(extra[name], 'base64');
+    else { console.log(`goldenBatchTest: ${name} needs its input from the Python harness (SPEEXHIP_TEST_INPUTS): skipped`); continue; }
+    assert(sha1(pcm) === c.input_sha1, `${name}: input differs from the golden input`);
+    // the call sequence: recorded per call for ragged cases, a fixed size otherwise
+    const fb = 2 * c.channels, sizes = [];
+    if (c.chunks === 'ragged') {
+      assert(c.calls.length === c.n_calls, `${name}: the golden file holds ${c.calls.length} of ${c.n_calls} calls`);
+      for (const row of c.calls) sizes.push(row[0] * fb);
+    } else {
+      for (let o = 0; o < pcm.length; o += c.chunks) sizes.push(Math.min(c.chunks, pcm.length - o));
+    }
+    const cut = (own) => {
+      const v = [];
+      let off = 0;
+      for (const n of sizes) {
+        let ch = pcm.slice(off, off + n);
+        if (own) { const p = SpeexResampler.allocChunk(Math.max(n, 1)); ch.copy(p); ch = p.slice(0, n); }
+        v.push(ch);
+        off += n;
+      }
+      return v;
+    };
+    const N = 3;
+    let exactBytes = null;
+    for (const mode of ['exact', 'fast']) {
+      for (const pinned of [false, true]) {
+        const chunks = cut(pinned);
+        // (1) the batch class: N streams, each fed the golden stream
+        const batch = new SpeexResamplerBatch(N, c.channels, c.in_rate, c.out_rate, c.quality);
+        batch.processChunks(new Array(N).fill(Buffer.alloc(0)));
+        batch.setMode(mode);
+        const outs = Array.from({ length: N }, () => []);
+        for (const ch of chunks) batch.processChunks(new Array(N).fill(ch)).forEach((o, k) => outs[k].push(o));
+        // (2) the coalescer: N instances whose processChunkAsync calls become ready in the same tick
+        const inst = Array.from({ length: N }, () => {
+          const r = new SpeexResampler(c.channels, c.in_rate, c.out_rate, c.quality);
+          r.setMode(mode);
+          return r;
+        });
+        const couts = Array.from({ length: N }, () => []);
+        for (const ch of chunks) (await Promise.all(inst.map((r) => r.processChunkAsync(ch)))).forEach((o, k) => couts[k].push(o));
+        for (const [what, list] of [['SpeexResamplerBatch', outs], ['coalescer', couts]]) {
+          list.forEach((parts, k) => {
+            const out = Buffer.concat(parts);
+            assert(out.length / fb === c.out_frames, `${name} ${what} stream ${k} (${mode}${pinned ? ', pinned chunks' : ''}): ${out.length / fb} frames, want ${c.out_frames}`);
+            if (mode === 'exact') {
+              assert(sha1(out) === c.out_sha1, `${name} ${what} stream ${k}${pinned ? ' (pinned chunks)' : ''}: EXACT bytes differ from the reference digest`);
+              exactBytes = out;
+            } else {
+              for (let i = 0; i < out.length; i += 2) {
+                assert(Math.abs(out.readInt16LE(i) - exactBytes.readInt16LE(i)) <= 1, `${name} ${what} stream ${k}: FAST sample ${i / 2} off by more than 1 LSB`);
+              }
+            }
+          });
+        }
+        batch.destroy();
+        inst.forEach((r) => r.destroy());
+      }
+    }
+    // (3) the Transform with `pinned` (alone and with the modes that hold chunks): the golden bytes again
+    if (c.chunks !== 'ragged') {
+      for (const options of [{ pinned: true }, { pinned: true, coalesceChunks: 4 }, { pinned: true, pipeline: true }, { pinned: true, async: true }]) {
+        const t = new SpeexResamplerTransform(c.channels, c.in_rate, c.out_rate, c.quality, options);
+        t.resampler.setMode('exact');
+        const parts = [];
+        t.on('data', (d) => parts.push(d));
+        Readable.from(cut(false)).pipe(t);
+        await new Promise((res, rej) => { t.on('end', res); t.on('error', rej); });
+        assert(sha1(Buffer.concat(parts)) === c.out_sha1, `${name} Transform ${JSON.stringify(options)}: bytes differ from the reference digest`);
+      }
+    }
+    ran++;
+  }
+  assert(ran >= 3, 'goldenBatchTest ran too few cases');
+  const st = require('../speex_hip_napi.node').stats();
+  if (process.env.SPEEXHIP_NAPI_COPY !== '1') assert(st.pinnedChunks > 0, 'allocChunk never returned a pinned chunk');
+  console.log(`golden cases through SpeexResamplerBatch / the coalescer / pinned chunks / Transform{pinned}: ${ran} (pinned chunks handed out: ${st.pinnedChunks})`);
+}
+
 function errorTest() {
   const msg = (f) => { try { f(); return null; } catch (e) { return e.message; } };
   assert(msg(() => new SpeexResampler(2, 44100, 48000).processChunk(Buffer.alloc(7))) ===
@@ -568,6 +663,7 @@ async function workerTest() {
   externalBufferTest();
   modeTest();
   await batchTest();
+  await goldenBatchTest();
   await workerTest();
   console.log('ALL NODE TESTS PASSED');
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -685,6 +685,54 @@ def test_device_placement_rule():
     assert counts == [32] * 8
 
 
+def test_device_placement_by_live_state_count_with_create_destroy_churn():
+    """Round 6: SPEEXHIP_DEVICES=all places a new state on the device with the fewest LIVE states --
+    destroying a state frees its slot -- with ties broken so that a fresh process still deals round-robin; a list and a
+    single device keep the counter rule; the no-environment default stays on the thread's current device.  Simulated
+    process: a server whose connections open and close at random."""
+    PL = speexhip.placement_live
+    n = 8
+    live = [0] * n
+    # a fresh process: exactly the round-robin of the counter rule
+    order = []
+    for k in range(2 * n):
+        d = PL(n, None, "all", k, 0, live)
+        live[d] += 1
+        order.append(d)
+    assert order == [k % n for k in range(2 * n)]
+    # churn: 3000 events, 40 % closes of a random live state; the spread never exceeds what the closes themselves opened
+    rng = np.random.RandomState(5)
+    owner, k = [], 2 * n
+    for d in order:
+        owner.append(d)
+    worst_after_open = 0
+    for _ in range(3000):
+        if owner and rng.rand() < 0.4:
+            d = owner.pop(rng.randint(len(owner)))
+            live[d] -= 1
+        else:
+            before_min = min(live)
+            d = PL(n, None, "all", k, 3, live)
+            assert live[d] == before_min, "a new state must land on a least-loaded device"
+            live[d] += 1
+            owner.append(d)
+            k += 1
+            worst_after_open = max(worst_after_open, max(live) - min(live))
+    # only opens for a while: the holes are filled before anything piles up
+    for _ in range(4 * n):
+        d = PL(n, None, "all", k, 3, live)
+        live[d] += 1
+        k += 1
+    assert max(live) - min(live) <= 1, live
+    # the counter rule where the caller asked for determinism, whatever the load
+    skew = [100, 0, 0, 0, 0, 0, 0, 0]
+    assert [PL(n, None, "0,2,5", j, 0, skew) for j in range(4)] == [0, 2, 5, 0]
+    assert [PL(n, "0", "all", j, 4, skew) for j in range(3)] == [0, 0, 0]
+    assert [PL(n, None, None, j, 6, skew) for j in range(3)] == [6, 6, 6]
+    assert PL(n, None, "all", 0, 0, skew) == 1 and PL(n, None, "all", 5, 0, skew) == 5  # ties: k mod n first
+    assert PL(0, None, "all", 0, 0, []) == -1
+
+
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_node_batch_class_and_many_call_check_their_arguments_without_a_gpu():
     """Round 5's JS surface on a box without a GPU: the argument checks of SpeexResamplerBatch and of the addon's

@@ -288,9 +288,21 @@ def test_node_drop_in_harness():
     """The JS drop-in (index.js -> N-API addon -> libspeexhip): the counterpart of the reference's
     src/test.ts, plus sha1 goldens and the F5 small-chunk case."""
     script = os.path.join(ROOT, "node-speex-resampler_amd", "test", "test.js")
+    # (the tonal input of the reference's stream-test tuple comes out of numpy's generator: handed to the harness as a
+    #  file, which checks it against the golden input digest before use -- goldenBatchTest)
+    import base64
+    import json
+    import tempfile
+    extra = {}
+    for c in json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["cases"]:
+        if c["name"] == "t_44100_48000_2ch_q7_64k":
+            extra[c["name"]] = base64.b64encode(np.ascontiguousarray(make_input(c)).tobytes()).decode()
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+    json.dump(extra, tmp)
+    tmp.close()
     # twice: results as external Buffers over the library's pinned blocks (round 4: the default from 4 KB) and as
     # copies (SPEEXHIP_NAPI_COPY=1, every call of rounds 1-3) -- the sha1 goldens hold either way
-    for env in (dict(os.environ), dict(os.environ, SPEEXHIP_NAPI_COPY="1")):
+    for env in (dict(os.environ, SPEEXHIP_TEST_INPUTS=tmp.name), dict(os.environ, SPEEXHIP_NAPI_COPY="1", SPEEXHIP_TEST_INPUTS=tmp.name)):
         res = subprocess.run(["node", "--expose-gc", script], capture_output=True, text=True, timeout=900, env=env)
         assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
         assert "ALL NODE TESTS PASSED" in res.stdout

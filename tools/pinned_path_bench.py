@@ -7,12 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "node-speex-resampler_amd", "python"))
 sys.path.insert(0, ROOT)
 import numpy as np
-import torch
+import torch  # noqa: F401  (one HIP runtime per process: speexhip.lib() loads behind torch's)
 import speexhip
 from bench import lcg_pcm, wrapper_capacity, pcie_peak
 
 L = speexhip.lib()
-out = {"pcie": pcie_peak(torch)}
+out = {"pcie": pcie_peak(speexhip, 4 << 20)}
 
 
 def timed(fn, n, warm=3):
