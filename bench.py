@@ -451,6 +451,31 @@ def cpu_worker(spec):
     print(json.dumps({"chunks": chunks, "seconds": time.perf_counter() - t0, "kind": kind}), flush=True)
 
 
+def host_legs(args):
+    """Child process of the N = 1 line: the HOST-FED legs (`end_to_end`, `end_to_end_streams`) and the link's own rate
+    (`pcie_peak`), in a process WITHOUT torch -- the library then runs on /opt/rocm's HIP runtime, which is what a Node
+    or C caller of the drop-in loads.  (Behind torch the library shares torch's bundled runtime, under which pinned
+    copies of opposite directions do not overlap: 26 + 26 GB/s where /opt/rocm's gives 43 + 43 at 4 MiB,
+    profiles/r06_runtime_ab.txt -- a probe of the link there would understate it, and the legs would measure a runtime no
+    host caller of the product uses.)  Prints one JSON object."""
+    os.environ["SPEEXHIP_PY_NO_TORCH"] = "1"
+    import speexhip
+    cfg = tuple(int(v) for v in args.custom.split(",")) if args.custom else CONFIGS[args.config]
+    ch, fi, fo, q = cfg
+    F = args.frames
+    fio = args.io == "float"
+    es = 4 if fio else 2
+    mode = {"exact": speexhip.MODE_EXACT, "fast": speexhip.MODE_FAST, "fast_f32": speexhip.MODE_FAST_F32,
+            "fast_fixed": speexhip.MODE_FAST_FIXED}[args.mode]
+    base = lcg_pcm(F * ch, 12345).reshape(F, ch)
+    peak = pcie_peak(speexhip, F * ch * es)
+    out = {"pcie_peak": peak, "end_to_end": end_to_end(speexhip, cfg, F, mode, fio, base, peak=peak)}
+    if not fio:
+        out["end_to_end_streams"] = end_to_end_streams(speexhip, cfg, F, mode, peak=peak)
+    out["runtime"] = sorted(set(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l))
+    print(json.dumps(out), flush=True)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,9 +491,11 @@ def parse_args(argv=None):
                     help="independent streams in the WHOLE JOB, stream s on rank s %% N (strong scaling; "
                          "256 = BASELINE configs[4]); overrides --streams")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
-    ap.add_argument("--mode", default="fast", choices=["fast", "exact", "fast_f32", "fast_fixed"],
-                    help="fast: +-1 LSB, fp64 accumulator where the reference has one (q9, q10); fast_f32: one fp32 "
-                         "FMA chain for every filter (rounds 1-3); exact: the reference's arithmetic order")
+    ap.add_argument("--mode", default="fast_fixed", choices=["fast", "exact", "fast_f32", "fast_fixed"],
+                    help="fast_fixed: the library's default -- +-1 LSB, fp64 accumulator where the reference has one (q9, "
+                         "q10), bytes independent of chunking / batch size; fast: the same with tap-range shares on small "
+                         "launches (bytes may depend on chunking); fast_f32: one fp32 FMA chain for every filter "
+                         "(rounds 1-3); exact: the reference's arithmetic order")
     ap.add_argument("--io", default="int16", choices=["int16", "float"],
                     help="sample type of the buffers: int16 = the BASELINE metric; float = the N2 entry point")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
@@ -477,6 +504,7 @@ def parse_args(argv=None):
                          "launch train run 20-30 %% slower), and W steps of a 15 us kernel are over before that")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)  # (child of cpu_baseline_workers)
+    ap.add_argument("--host-legs", action="store_true", help=argparse.SUPPRESS)  # (child: the host-fed legs, see host_legs)
     ap.add_argument("--no-parity", action="store_true")
     return ap.parse_args(argv)
 
@@ -530,6 +558,9 @@ def main():
         sys.exit("--gpus must be >= 1")
     if args.cpu_worker:
         cpu_worker(args.cpu_worker)
+        return
+    if args.host_legs:
+        host_legs(args)
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
@@ -743,11 +774,24 @@ def main():
             if not ok:
                 rc = 3
         if world == 1 and not args.no_cpu_baseline:
-            peak = pcie_peak(speexhip, F * ch * es)
-            line["pcie_peak"] = peak
-            line["end_to_end"] = end_to_end(speexhip, cfg, F, mode, fio, base[0], peak=peak)
-            if not fio:
-                line["end_to_end_streams"] = end_to_end_streams(speexhip, cfg, F, mode, peak=peak)
+            # the host-fed legs and the link probe: a child process without torch (host_legs: the runtime a Node / C caller
+            # of the drop-in loads); this process is idle meanwhile
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--host-legs", "--config", args.config,
+                                    "--frames", str(F), "--mode", args.mode, "--io", args.io] +
+                                   (["--custom", args.custom] if args.custom else []),
+                                   env=dict(os.environ, SPEEXHIP_PY_NO_TORCH="1"), capture_output=True, text=True, timeout=900)
+            if child.returncode == 0 and child.stdout.strip():
+                legs = json.loads(child.stdout.strip().splitlines()[-1])
+                line["pcie_peak"] = legs["pcie_peak"]
+                line["end_to_end"] = legs["end_to_end"]
+                if "end_to_end_streams" in legs:
+                    line["end_to_end_streams"] = legs["end_to_end_streams"]
+                line["host_legs_runtime"] = {"libamdhip64": legs["runtime"],
+                                             "note": "end_to_end*, pcie_peak: measured in a child process without torch, on the HIP "
+                                                     "runtime a Node / C caller of the drop-in loads; `value` and `roofline`: this "
+                                                     "process (torch's bundled runtime; device-resident, no PCIe inside)"}
+            else:
+                line["end_to_end"] = {"error": "host-legs child failed: " + (child.stderr or "")[-400:]}
             line["cpu_baseline"] = cpu_baseline(cfg, F)
             if cpu_many is not None:
                 # the strong-scaling line: T streams against min(cores, T) CPU workers; the 1-core figure stays beside it

@@ -9,7 +9,7 @@
  * deps/speex/speex_resampler.h:50-79).  Plain pointers and sizes only; no HIP/torch types.
  *
  * Numerical contract: output int16 PCM is within +-1 LSB of the reference on the same input
- * (SPEEXHIP_MODE_FAST, default) or bit-identical to it (SPEEXHIP_MODE_EXACT).  Stream
+ * (SPEEXHIP_MODE_FAST_FIXED, the default, and SPEEXHIP_MODE_FAST) or bit-identical to it (SPEEXHIP_MODE_EXACT).  Stream
  * bookkeeping (frames consumed / produced per call, resample.c:878-902,968-1036) is always
  * identical to the reference.
  *
@@ -42,16 +42,21 @@ enum {
 };
 
 enum {
-  SPEEXHIP_MODE_FAST = 0,      /* +-1 LSB; the filters the reference sums in fp64 (quality 9, 10) in fp64 */
+  SPEEXHIP_MODE_FAST = 0,      /* +-1 LSB; the filters the reference sums in fp64 (quality 9, 10) in fp64.  Launches that
+                                  cannot fill the chip may split an output's sum over several waves (tap-range shares): up
+                                  to 2x faster on one-stream calls of long decimators, but the last bit of a sample then
+                                  depends on how the stream was cut into calls and on what shared its launch.  Opt-in
+                                  since round 6 (set_mode, or SPEEXHIP_MODE=fast) */
   SPEEXHIP_MODE_EXACT = 1,     /* bit-identical arithmetic order */
   SPEEXHIP_MODE_FAST_F32 = 2,  /* FAST with one fp32 FMA chain for every filter (the fast path of rounds 1-3):
                                   narrower than the reference's accumulator at quality 9 and 10, still +-1 LSB */
-  SPEEXHIP_MODE_FAST_FIXED = 3 /* FAST with a pinned summation order (round 5): no tap-range shares, the one launch-time
-                                  choice that re-associates an output's sum.  Like the reference -- and unlike FAST -- the
-                                  bytes of a stream then do not depend on how it is cut into chunks, on how many
-                                  streams share a launch or on the GPU's size; still +-1 LSB.  Costs nothing on
-                                  launches that fill the chip (the BASELINE configs); small launches of long filters
-                                  (one-stream decimators) lose the 1.5-2x the shares bought */
+  SPEEXHIP_MODE_FAST_FIXED = 3 /* THE DEFAULT (round 6).  FAST with a pinned summation order: no tap-range shares, the one
+                                  launch-time choice that re-associates an output's sum.  Like the reference (whose output
+                                  for 64 KiB chunks equals its output for one chunk) the bytes of a stream do
+                                  not depend on how it is cut into chunks, on how many streams share a launch or on the
+                                  GPU's size; +-1 LSB of the reference.  Costs nothing on launches that fill the chip
+                                  (every BASELINE config); one-stream calls of long decimators run
+                                  at the unshared speed (48k -> 11.025k stereo: 30 us against 14 for a 2^20-frame call) */
 };
 
 /* Which of the reference's inner kernels the (rates, quality) pair selects
@@ -302,9 +307,10 @@ SPEEXHIP_API int speexhip_resampler_process_many_float(uint32_t n, SpeexHipResam
 SPEEXHIP_API int speexhip_resampler_peek(SpeexHipResamplerState *st, uint32_t in_len, uint32_t out_capacity,
                                          int float_entry, uint32_t *consumed, uint32_t *produced);
 
-/* SPEEXHIP_MODE_FAST (default; +-1 LSB), SPEEXHIP_MODE_EXACT (bit-identical arithmetic order,
- * slower), SPEEXHIP_MODE_FAST_F32 or SPEEXHIP_MODE_FAST_FIXED.  The environment variable
- * SPEEXHIP_MODE=exact|fast|fast_f32|fast_fixed sets the initial mode. */
+/* SPEEXHIP_MODE_FAST_FIXED (default; +-1 LSB, bytes a function of the stream alone), SPEEXHIP_MODE_FAST (+-1 LSB, faster on
+ * small launches of long filters, bytes may depend on chunking), SPEEXHIP_MODE_EXACT (bit-identical arithmetic order,
+ * slower) or SPEEXHIP_MODE_FAST_F32.  The environment variable SPEEXHIP_MODE=exact|fast|fast_f32|fast_fixed sets the
+ * initial mode. */
 SPEEXHIP_API int speexhip_resampler_set_mode(SpeexHipResamplerState *st, int mode);
 
 typedef struct SpeexHipInfo {

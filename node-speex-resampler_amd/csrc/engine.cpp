@@ -313,7 +313,10 @@ int Batch::setup() {
     g_last_error = std::string("HIP device error: built for gfx950 (MI355X), found ") + prop.gcnArchName;
     return SPEEXHIP_ERR_DEVICE;
   }
+  // (default: SPEEXHIP_MODE_FAST_FIXED -- a stream's bytes do not depend on chunking, batch size or GPU, like the
+  //  reference's; 'fast' opts into launch-time re-association where it buys speed)
   const char *m = std::getenv("SPEEXHIP_MODE");
+  if (m != nullptr && std::strcmp(m, "fast") == 0) mode_ = SPEEXHIP_MODE_FAST;
   if (m != nullptr && std::strcmp(m, "exact") == 0) mode_ = SPEEXHIP_MODE_EXACT;
   if (m != nullptr && std::strcmp(m, "fast_f32") == 0) mode_ = SPEEXHIP_MODE_FAST_F32;
   if (m != nullptr && std::strcmp(m, "fast_fixed") == 0) mode_ = SPEEXHIP_MODE_FAST_FIXED;
@@ -1780,6 +1783,11 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     it.out_bytes = static_cast<size_t>(it.plan.produced) * it.b->channels_ * es;
     it.pin_in = pinned_view(in[it.i], it.in_bytes);
     it.pin_out = pinned_view(out[it.i], it.out_bytes);
+    // (a pinned input whose result goes to a LARGE pageable buffer is copied like any other -- from pinned memory the copy
+    //  is a plain DMA -- so that the call can take the pipelined path, inputs arriving while results leave: read in place,
+    //  all the reads come first and all the pageable copies out after them, 32 x 2^20 stereo frames 5.4 ms against 4.0,
+    //  profiles/r06_bench_driver_form_v2.json)
+    if (it.pin_in != nullptr && it.pin_out == nullptr && it.out_bytes >= kDirectCopyBytes) it.pin_in = nullptr;
     if (it.pin_in != nullptr) pinned_bytes += it.in_bytes, it.in_bytes = 0;
     if (it.pin_out != nullptr) pinned_bytes += it.out_bytes, it.out_bytes = 0;
     it.work = it.plan.produced != 0 || it.plan.magic_used + it.plan.consumed != 0;

@@ -170,7 +170,7 @@ class Batch {
   uint32_t n_streams_ = 0, channels_ = 0;
   int device_ = 0;
   bool counted_ = false;  // this state is in its device's live count (devices::state_born)
-  int mode_ = SPEEXHIP_MODE_FAST;
+  int mode_ = SPEEXHIP_MODE_FAST_FIXED;  // (round 6: the default is the mode whose bytes depend on the stream alone)
   std::vector<StreamPos> pos_;    // [stream][channel] (the reference keeps them per channel, resample.c:135-137;
                                   // interleaved calls move all channels of a stream together)
   bool zero_mode_ = false;        // resampler_ptr == resampler_basic_zero (resample.c:785-791): the last

@@ -206,7 +206,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // (SPEEXHIP_MIN_FILL=n, diagnostics: at least 1/n of the lanes instead of a quarter -- profiles/r05_wide_windows.txt)
   // (a ninth, late in round 5: seven channels at num = 1280 fit 2 of a tile's 18 periods and still ran the exact kernel --
   //  32 x 131 072 frames of 96k / 32k -> 11.025k 1430 / 1400 us there, 387 / 269 here, one stream 361 -> 133 / 98:
-  //  tools/r05_minfill9.sh)
+  //  profiles/r05_minfill9.txt)
   static const uint32_t min_fill = SPEEXHIP_DIAG_ENV("SPEEXHIP_MIN_FILL") ? std::max(1, std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MIN_FILL"))) : 9;
   // (the fp64 plans keep the quarter: at quality 10 the same two ratios, 32 streams, took 459 / 898 / 429 / 886 us on the
   //  exact kernel -- bit-exact there -- against 643 / 977 / 473 / 998 here; profiles/r05_wide_windows.txt)
@@ -215,7 +215,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // (... or its int16-window plan does: 8 channels at num = 1280 with 2 232 taps -- 96k -> 11.025k, quality 8-10 -- fit ONE
   //  period of the float window, a sixteenth of a tile, and three of the int16 one.  The float plan then exists for the
   //  int16 plan to hang off -- int16 calls run over that -- and serves the float calls of such a state itself.  Late in
-  //  round 5: 32 x 131 072 frames 3 241 us on the exact kernel, tools/r05_q10_sweep.sh)
+  //  round 5: 32 x 131 072 frames 3 241 us on the exact kernel, profiles/r05_q10_sweep.txt)
   if (!filled && !w16 && !a64 && !t.pp && t.lane_periods >= 1 && t.window_bytes <= lds_budget) {
     const PeriodPlan i16 = plan_period_r(f, channels, lds_budget, r, true, false, false);
     filled = i16.usable;
@@ -573,7 +573,7 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &plan, const
   // the doubling above neither counts those nor knows three shares: 8 streams x 131 072 frames of 4-channel 32k ->
   // 11.025k is 8 tiles + 1 per stream, x 4 shares = 288 workgroups on 256 CUs, 70 us against 48 in 3 shares (216); 32
   // mono streams in 2 tiles each took 4 shares, 384 workgroups, 85 us against 49 in 2.  The shares by a model of the
-  // generations instead, fitted to tools/r05_wide_grid.sh (profiles/r05_wide_grid.txt: 27 launches x 7 split counts): a
+  // generations instead, fitted to profiles/r05_wide_grid.txt (tools/ab.sh over SPEEXHIP_SPLITS: 27 launches x 7 split counts): a
   // workgroup stages its window at ~5 bytes per cycle (all CUs at once) and then spends 4.75 cycles per packed FMA and
   // SIMD on the groups of its share, its slowest wave at least `walks` chains; within +-15 % of the measured launches,
   // argmin within 6 % of the best measured on 25 of the 27.  A candidate has to beat fewer shares by 10 %.

@@ -110,8 +110,10 @@ declare class SpeexResampler {
     setRate(inRate: number, outRate: number): void;
     setQuality(quality: number): void;
     /**
-     * 'fast' (default, +-1 LSB, fp64 sums at quality 9 / 10), 'exact' (bit-identical to the reference), 'fast_f32', or
-     * 'fast_fixed': 'fast' whose bytes do not depend on chunking, batch size or GPU (pinned summation order)
+     * 'fast_fixed' (the default: +-1 LSB of the reference, fp64 sums at quality 9 / 10, and bytes that -- like the
+     * reference's -- do not depend on chunking, batch size or GPU), 'fast' (+-1 LSB; up to 2x faster on one-stream calls of
+     * long decimators, but the last bit of a sample may depend on how the stream was cut into chunks), 'exact'
+     * (bit-identical to the reference, slower) or 'fast_f32'.  SPEEXHIP_MODE in the environment sets the initial mode.
      */
     setMode(mode: 'fast' | 'exact' | 'fast_f32' | 'fast_fixed'): void;
     skipZeros(): void;

@@ -217,12 +217,13 @@ class SpeexResampler {
   }
 
   /**
-   * Arithmetic of this instance's kernels: 'fast' (default; every sample within +-1 LSB of the reference, fp64 sums
-   * where the reference has them: quality 9 and 10), 'exact' (bit-identical to the reference, slower), 'fast_f32'
-   * (one fp32 FMA chain for every filter: the fast path of the first releases), 'fast_fixed' ('fast' with a pinned
-   * summation order: like the reference's, a stream's bytes then do not depend on how it is cut into chunks, on how
-   * many streams share a launch or on the GPU).  The environment variable SPEEXHIP_MODE sets the initial mode of every
-   * instance.
+   * Arithmetic of this instance's kernels: 'fast_fixed' (the default since round 6: every sample within +-1 LSB of the
+   * reference, fp64 sums where the reference has them -- quality 9 and 10 -- and, like the reference's, bytes that do not
+   * depend on how the stream is cut into chunks, on how many streams share a launch or on the GPU), 'fast' (the same
+   * tolerance; small launches of long filters may split a sum over several waves: up to 2x faster there, but the last bit
+   * then depends on the chunking), 'exact' (bit-identical to the reference, slower), 'fast_f32' (one fp32 FMA chain for
+   * every filter: the fast path of the first releases).  The environment variable SPEEXHIP_MODE sets the initial mode of
+   * every instance.
    */
   setMode(mode) {
     this._refuseWhileAsyncPending('setMode');

@@ -86,10 +86,13 @@ def lib():
         # One HIP runtime per process: PyTorch-ROCm preloads its bundled libamdhip64.so.7 by path;
         # if ours pulled in /opt/rocm's copy first there would be two runtimes and the second
         # to initialise sees no device.  Loading torch first makes both share one copy.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # (SPEEXHIP_PY_NO_TORCH=1, tools only: load the library behind /opt/rocm's runtime, as the Node addon does --
+        #  the two runtimes differ, e.g. in whether pinned copies of opposite directions overlap, profiles/r06_runtime_ab.txt)
+        if os.environ.get("SPEEXHIP_PY_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         u32, i32, p = C.c_uint32, C.c_int, C.c_void_p
         pu32, pi16 = C.POINTER(C.c_uint32), C.POINTER(C.c_int16)

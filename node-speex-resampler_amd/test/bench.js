@@ -11,7 +11,7 @@ const { Readable, Writable } = require('stream');
 const { performance } = require('perf_hooks');
 const mod = require('../index.js');
 const SpeexResampler = mod.default;
-const { SpeexResamplerTransform } = mod;
+const { SpeexResamplerTransform, SpeexResamplerBatch } = mod;
 
 const tuples = [
   { bytes: 882044, inRate: 24000, outRate: 48000, channels: 1, quality: 5 },
@@ -99,10 +99,59 @@ async function pipeOnce(t, data, options) {
     console.log(JSON.stringify(row));
     rows.push(row);
   }
+  // round 6: chunks in pinned memory (SpeexResampler.allocChunk) against ordinary Buffers -- a 2^20-frame stereo chunk through
+  // processChunk, 32 instances x 16384 frames through SpeexResamplerBatch, and the 64 KiB pipe with { pinned: true }
+  const pinnedRows = {};
+  {
+    const t = tuples[3];
+    const big = pcm(4 << 20, 7);
+    const bigPinned = SpeexResampler.allocChunk(big.length);
+    big.copy(bigPinned);
+    const r = new SpeexResampler(t.channels, t.inRate, t.outRate, t.quality);
+    for (const [name, chunk] of [['chunk_4MiB_ordinary_ms', big], ['chunk_4MiB_allocChunk_ms', bigPinned]]) {
+      for (let i = 0; i < 4; i++) r.processChunk(chunk);
+      const ts = [];
+      for (let rep = 0; rep < 30; rep++) {
+        const t0 = performance.now();
+        r.processChunk(chunk);
+        ts.push(performance.now() - t0);
+        // (results are external Buffers over pinned blocks; their finalizers run from the event loop -- a server yields
+        //  to it all the time, a benchmark loop has to: otherwise the slabs fill up and the calls fall back to copies)
+        if (rep % 5 === 4) { if (global.gc) global.gc(); await new Promise((res) => setImmediate(res)); }
+      }
+      pinnedRows[name] = +median(ts).toFixed(4);
+    }
+    r.destroy();
+    const N = 32, small = pcm(65536, 9);
+    const batch = new SpeexResamplerBatch(N, t.channels, t.inRate, t.outRate, t.quality);
+    const ordinary = new Array(N).fill(small);
+    const pinned = ordinary.map((c) => { const p = SpeexResampler.allocChunk(c.length); c.copy(p); return p; });
+    for (const [name, chunks] of [['batch32_64KiB_ordinary_ms', ordinary], ['batch32_64KiB_allocChunk_ms', pinned]]) {
+      for (let i = 0; i < 10; i++) batch.processChunks(chunks);
+      const ts = [];
+      for (let rep = 0; rep < 100; rep++) {
+        const t0 = performance.now();
+        batch.processChunks(chunks);
+        ts.push(performance.now() - t0);
+        if (rep % 5 === 4) { if (global.gc) global.gc(); await new Promise((res) => setImmediate(res)); }
+      }
+      pinnedRows[name] = +median(ts).toFixed(4);
+    }
+    batch.destroy();
+    const data = pcm(t.bytes, 12345);
+    for (const [name, options] of [['pipe_ms', undefined], ['pipe_pinned_ms', { pinned: true }],
+      ['pipe_pipeline_pinned_ms', { pipeline: true, pinned: true }], ['pipe_coalesce8_pinned_ms', { coalesceChunks: 8, pinned: true }]]) {
+      const ts = [];
+      for (let rep = 0; rep < 9; rep++) ts.push((await pipeOnce(t, data, options))[0]);
+      pinnedRows[name] = +median(ts.slice(1)).toFixed(3);
+    }
+    console.log(JSON.stringify({ pinned_chunks: pinnedRows }));
+  }
   if (process.argv[2]) {
     fs.writeFileSync(process.argv[2], JSON.stringify({
       what: 'index.js drop-in on one MI355X: host Buffers in and out (PCIe + N-API included); whole = one ' +
         'processChunk over the buffer with a fresh state (median of 10 after 2 warm-ups), steady = the same call ' +
-        'on a running state, pipe = SpeexResamplerTransform fed 64 KiB chunks', rows }, null, 1) + '\n');
+        'on a running state, pipe = SpeexResamplerTransform fed 64 KiB chunks; pinned_chunks (round 6) = the same calls on chunks ' +
+        'from SpeexResampler.allocChunk (44.1k -> 48k stereo q7)', rows, pinned_chunks: pinnedRows }, null, 1) + '\n');
   }
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -431,9 +431,11 @@ function modeTest() {
   // 'fast_fixed': the bytes of a stream do not depend on how it is cut into chunks (the reference's property)
   {
     const whole = new SpeexResampler(2, 48000, 11025, 7), cut = new SpeexResampler(2, 48000, 11025, 7);
-    whole.setMode('fast_fixed'); cut.setMode('fast_fixed');
+    // (round 6: no mode is set -- the property belongs to the DEFAULT mode)
+    whole.processChunk(Buffer.alloc(0)); cut.processChunk(Buffer.alloc(0));
     const x = lcg(200000, 2, 77);
     const addon = require('../speex_hip_napi.node');
+    if (!process.env.SPEEXHIP_MODE) assert(addon.getInfo(whole._resamplerPtr).mode === 3, 'the default mode must be fast_fixed');
     // (through the addon with room to spare: processChunk's capacity rule DROPS input when chunk sizes vary -- F5 --
     //  and four chunks would then not be the stream of the one)
     const one = addon.process(whole._resamplerPtr, x, 200000, 60000);
@@ -441,8 +443,8 @@ function modeTest() {
     for (const [a, b] of [[0, 4800], [4800, 4900], [4900, 150000], [150000, 200000]]) {
       parts.push(addon.process(cut._resamplerPtr, x.slice(a * 4, b * 4), b - a, 60000));
     }
-    assert(Buffer.concat(parts).length === one.length, "'fast_fixed': four chunks, another length");
-    assert(Buffer.concat(parts).equals(one), "'fast_fixed': four chunks differ from one");
+    assert(Buffer.concat(parts).length === one.length, "default mode: four chunks, another length");
+    assert(Buffer.concat(parts).equals(one), "default mode: four chunks differ from one");
     whole.destroy(); cut.destroy();
   }
   console.log(`modes: fast ${off.fast} / fast_f32 ${off.fast_f32} / fast_fixed ${off.fast_fixed} of ${outs.exact.length / 2} samples off by one`);
@@ -607,7 +609,9 @@ async function batchTest() {
       const b = new SpeexResamplerBatch(2 * n, 2, 44100, 48000, 7);
       b.processChunks(new Array(2 * n).fill(Buffer.alloc(0)));
       const seen = b.streams.map((s) => s.device);
-      for (let k = 1; k < seen.length; k++) assert(seen[k] === (seen[0] + k) % n, `SPEEXHIP_DEVICES=all: devices ${seen}`);
+      // (round 6: a new state goes to the GPU with the fewest LIVE states -- instances of the tests above that the
+      //  collector has not finalized yet still count, so the deal need not start at 0; every GPU must get its share)
+      for (let d = 0; d < n; d++) assert(seen.includes(d), `SPEEXHIP_DEVICES=all: devices ${seen}`);
       b.destroy();
       console.log(`placement: ${2 * n} streams on devices ${seen.join(',')}`);
     }

@@ -22,7 +22,7 @@ from golden_util import ROOT, drive, make_input, sha1
 pytestmark = pytest.mark.gpu
 
 TOL_LSB = 1            # north star: +-1 LSB vs the reference
-MISMATCH_RATE = 5e-3   # measured (tools/num_check.py, cfg2, 2^20 frames): 4.4e-4 (tonal input) .. 2.6e-3
+MISMATCH_RATE = 4e-3   # (5e-3 until round 5; 3.5e-3 met a 3.53e-3 on 23 000 samples of 48k->11.025k) measured (tools/num_check.py, cfg2, 2^20 frames): 4.4e-4 (tonal input) .. 2.6e-3
                        # (full-scale white noise); up to 3.1e-3 on other ratios.  The rate is ~E|fp32
                        # re-association error| in LSB; every differing sample differs by exactly 1
 
@@ -741,10 +741,25 @@ def test_int16_window_on_small_launches_too():
     so that the small multi-call cases of the layout and mixed int16 / float tests run over it as well."""
     import subprocess
     import sys
-    env = diag_env(SPEEXHIP_W16_ALWAYS="1")
+    env = diag_env(SPEEXHIP_MODE="fast", SPEEXHIP_W16_ALWAYS="1")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                           "window_layout_variants or int16_window_plan_serves or edge_cases"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_opt_in_fast_mode_takes_its_shares_by_the_planners_rule():
+    """Round 6: the default mode is SPEEXHIP_MODE_FAST_FIXED (no tap-range shares), so the tests of this file that name
+    no mode run on it.  SPEEXHIP_MODE=fast (the documented switch, read by the product library) makes FAST the initial
+    mode of every state: the layout, golden, edge-case, rate-grid and slide tests again, where small launches of long
+    filters take their shares by the planners' own rules -- still +-1 LSB everywhere."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEEXHIP_MODE="fast")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "window_layout_variants or every_golden_case or edge_cases or many_rates or small_ratio or "
+                          "n_to_one or mono_packed or float_entry or fp64_accumulate"],
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
 
 
@@ -756,7 +771,7 @@ def test_tap_range_shares_on_every_layout():
     phase-group sizes -- over the small multi-call cases."""
     import subprocess
     import sys
-    env = diag_env(SPEEXHIP_KSPLIT="3")
+    env = diag_env(SPEEXHIP_MODE="fast", SPEEXHIP_KSPLIT="3")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                           "window_layout_variants or every_golden_case or edge_cases or many_rates or mono_packed "
                           "or float_entry or mid_stream_control_scripts_fast or fp64_accumulate_period"],   # (round 4: the
@@ -772,7 +787,7 @@ def test_slide_kernel_tap_range_parts_on_every_shape():
     every launch of every shape."""
     import subprocess
     import sys
-    env = diag_env(SPEEXHIP_SLIDE_PARTS="3")
+    env = diag_env(SPEEXHIP_MODE="fast", SPEEXHIP_SLIDE_PARTS="3")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                           "small_ratio or n_to_one or slide_kernel_workgroups or every_golden_case or edge_cases "
                           "or many_rates or mono_packed or float_entry"],
@@ -1767,7 +1782,7 @@ def test_phase_pair_plans_for_mono_on_every_launch():
     window, packed-store and control tests (stereo frames leave through a DPP swap of lane pairs), +-1 LSB."""
     import subprocess
     import sys
-    env = diag_env(SPEEXHIP_PP="1")
+    env = diag_env(SPEEXHIP_MODE="fast", SPEEXHIP_PP="1")
     res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
                           "(mono or every_golden_case or many_rates or window_layout_variants or edge_cases or tap_range_shares "
                           "or int16_window_plan_serves or history_after or float_entry or control_scripts_fast or many_generation) "
@@ -1815,7 +1830,7 @@ def test_tap_rows_fetched_behind_the_window_and_shares_on_unsplit_launches():
             "ragged or float_entry) and not phase_pair and not tap_rows_fetched")
     for extra in ({"SPEEXHIP_TOUCH": "1"}, {"SPEEXHIP_TOUCH": "1", "SPEEXHIP_PP": "1"}, {"SPEEXHIP_KS_UNSPLIT": "0"}):
         res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", pick],
-                             env=diag_env(**extra), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+                             env=diag_env(SPEEXHIP_MODE="fast", **extra), capture_output=True, text=True, timeout=1500, cwd=ROOT)
         assert res.returncode == 0, str(extra) + res.stdout[-3000:] + res.stderr[-2000:]
     # by the rules: shares on an unsplit launch (three channels, 8 groups of 20 phases), the fetch by bytes moved
     # (4 channels, 33 MB), stereo in phase pairs because the other plan splits -- all through the default environment
@@ -1975,8 +1990,21 @@ for step, f in enumerate([5000, 160, 400000, 160]):
         got, used1 = states[s].process(x, 1200)
         want, wu = refs[s].process(x, 1200)
         assert used1 == wu and np.array_equal(got, want), (step, s)
-for s in states:
+# round 6: placement by LIVE state count -- states that close make room on their device, new ones fill the hole
+live = lambda: [speexhip.lib().speexhip_debug_live_states(d) for d in (0, 1)]
+assert live() == [3, 4], live()
+states[1].close()
+states[3].close()
+assert live() == [3, 2], live()
+fresh = [speexhip.Resampler(2, 44100, 48000, 7) for _ in range(3)]
+assert [s.info()["device"] for s in fresh] == [1, 0, 1], [s.info()["device"] for s in fresh]
+assert live() == [4, 4], live()
+for s in fresh:
     s.close()
+for k, s in enumerate(states):
+    if k not in (1, 3):
+        s.close()
+assert live() == [0, 0], live()
 print("PLACEMENT OK")
 """
 
@@ -2045,14 +2073,15 @@ def test_fast_fixed_mode_bytes_do_not_depend_on_chunking_or_batch_size(ch, i, o,
     frames = 300000
     x = orc.lcg_pcm(frames * ch, 5).reshape(frames, ch)
     cap = int(frames * o / i) + 64
-    whole = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_FAST_FIXED)
+    whole = speexhip.Resampler(ch, i, o, q)  # (round 6: no mode named -- this IS the default)
+    assert whole.info()["mode"] == speexhip.MODE_FAST_FIXED, "the default mode must be the chunking-invariant one"
     a, ua = whole.process(x, cap)
     whole.close()
     want, _ = orc.Oracle(ch, i, o, q).process(x, cap)
     assert ua == frames
     assert_close(a, want, "fast_fixed, one call")
     sizes = (480, 100000, 7, 20000, 150000, frames)
-    pieces = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_FAST_FIXED)
+    pieces = speexhip.Resampler(ch, i, o, q)
     out, used = [], 0
     for n in sizes:
         n = min(n, frames - used)
@@ -2065,7 +2094,7 @@ def test_fast_fixed_mode_bytes_do_not_depend_on_chunking_or_batch_size(ch, i, o,
     pieces.close()
     assert np.array_equal(np.concatenate(out), a), "fast_fixed: six calls differ from one call"
     for others in (6, 32):   # the same stream as state 3 of a many-states call (other states: other audio)
-        states = [speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_FAST_FIXED) for _ in range(others + 1)]
+        states = [speexhip.Resampler(ch, i, o, q) for _ in range(others + 1)]
         out, used = [], 0
         for n in sizes:
             n = min(n, frames - used)

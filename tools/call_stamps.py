@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/r05_call_stamps.py -- VERDICT r4 #5: calls 1..6 of one state through the C ABI on preallocated, touched
+"""tools/call_stamps.py -- VERDICT r4 #5: calls 1..6 of one state through the C ABI on preallocated, touched
 buffers (no allocation, no first-touch page faults inside the timed call): copy-out call, owned-block call, and the
 kernel alone (device pointers, HIP events).  profiles/r04_init_cost.txt showed call 2 at 0.79 ms for 24k->48k stereo q10."""
 import ctypes as C, os, sys, time

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""tools/r04_cold_state.py -- what state a launch inherits from the one before (diagnostics, run through gpurun).
+"""tools/cold_state.py -- what state a launch inherits from the one before (diagnostics, run through gpurun).
 The same batch launch timed with HIP events around each launch, back to back and with another kernel between two
 launches that (a) reads 256 MB (every L2 and most of the Infinity Cache replaced), (b) reads 8 MB, (c) does nothing
-but sit between them.  Environment (SPEEXHIP_SKIP, SPEEXHIP_TOUCH, SPEEXHIP_PP ...) as for bench.py.
-usage: python tools/r04_cold_state.py channels,in,out,q [streams] [frames]"""
+but sit between them.  Diagnostics switches (SPEEXHIP_SKIP, SPEEXHIP_TOUCH, SPEEXHIP_PP ...) need the diagnostics build: run it through tools/ab.sh.
+usage: python tools/cold_state.py channels,in,out,q [streams] [frames]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "node-speex-resampler_amd", "python"))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/r04_data_dep.py -- does a launch's time depend on the samples?  The same batch launch on random PCM, on
+"""tools/data_dep.py -- does a launch's time depend on the samples?  The same batch launch on random PCM, on
 silence and on a constant, timed with HIP events over a train of launches (diagnostics, run through gpurun).
-usage: python tools/r04_data_dep.py channels,in,out,q [streams] [frames]"""
+usage: python tools/data_dep.py channels,in,out,q [streams] [frames]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "node-speex-resampler_amd", "python"))

@@ -8,7 +8,7 @@
 # and, AFTER the PMC passes (bench.py reads profiles/pmc_traffic.json), the bench lines of every
 # workload (parity block in each; cpu_baseline in the 1-stream ones)   -> r0N_bench_lines.jsonl
 # Results land in gpurun_out/prof_r0N/; copy the summaries into profiles/ by hand.
-N=${1:-04}
+N=${1:-06}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_r$N; rm -rf $O; mkdir -p $O; cd $R
 cd /tmp && export TMPDIR=/tmp
 for CFG in cfg2 cfg3 cfg4 f3; do
@@ -73,7 +73,7 @@ for cfg in ('cfg2', 'cfg3', 'cfg4', 'f3'):
         f = summary.get('pmc_FETCH_SIZE_%s_s%d' % (cfg, s), {}).get('FETCH_SIZE')
         w = summary.get('pmc_WRITE_SIZE_%s_s%d' % (cfg, s), {}).get('WRITE_SIZE')
         if f and w:
-            traffic['%s_s%d_fast' % (cfg, s)] = int(round(2 * f['avg_per_dispatch'] * 1024 + w['avg_per_dispatch'] * 1024))
+            traffic['%s_s%d_fast_fixed' % (cfg, s)]  # (bench.py's default mode since round 6) = int(round(2 * f['avg_per_dispatch'] * 1024 + w['avg_per_dispatch'] * 1024))
 json.dump(summary, open(O + '/r%s_pmc_summary.json' % N, 'w'), indent=1)
 json.dump(traffic, open(O + '/pmc_traffic.json', 'w'), indent=1)
 shutil.copy(O + '/pmc_traffic.json', R + '/profiles/pmc_traffic.json')   # bench.py reads it from here
@@ -102,19 +102,20 @@ for IO in int16 float; do
   python bench.py --custom 1,44100,48000,7 --io $IO --steps 300 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
   python bench.py --custom 1,44100,48000,7 --io $IO --streams 32 --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
 done
-# round 5: the pinned summation order at the BASELINE configs (cost of SPEEXHIP_MODE_FAST_FIXED), configs[4] whole on one
-# GPU with its CPU column on min(cores, 256) worker processes
+# round 6: the default mode is the pinned summation order (fast_fixed); the opt-in mode with tap-range shares (fast) beside
+# it at the BASELINE configs; configs[4] whole on one GPU with its CPU column on min(cores, 256) worker processes
 for CFG in cfg2 cfg3 cfg4; do
   for S in 1 32; do
-    python bench.py --config $CFG --mode fast_fixed --streams $S --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
+    python bench.py --config $CFG --mode fast --streams $S --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
   done
 done
+python tools/pinned_path_bench.py > $O/r${N}_pinned_path.json 2>/dev/null
 python bench.py --total-streams 256 --steps 10 --warmup 2 > $O/r${N}_bench_total256.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_form.json 2>/dev/null
-python tools/r05_call_stamps.py > $O/r${N}_call_stamps.txt 2>/dev/null
+python tools/call_stamps.py > $O/r${N}_call_stamps.txt 2>/dev/null
 python tools/first_call.py > $O/r${N}_first_call.txt 2>/dev/null
 FIRST_CALL_WARMUP=1 python tools/first_call.py > $O/r${N}_first_call_warm.txt 2>/dev/null
-node --expose-gc tools/r05_steady.js > $O/r${N}_steady.txt 2>/dev/null
+node --expose-gc tools/steady.js > $O/r${N}_steady.txt 2>/dev/null
 python tools/host_path_bench.py > $O/r${N}_host_path.json 2>/dev/null
 python tools/small_call_latency.py > $O/r${N}_small_call_latency.txt 2>/dev/null
 python tools/init_cost.py > $O/r${N}_init_cost.txt 2>/dev/null

@@ -76,6 +76,14 @@ WORKLOADS = [
     ("one_48k_11k_2ch", (2, 48000, 11025, 7), 1, 441000, "fast", "int16"),
     ("one_48k_8k_2ch", (2, 48000, 8000, 7), 1, 441000, "fast", "int16"),
     ("one_44k_48k_mono", (1, 44100, 48000, 7), 1, 1 << 20, "fast", "int16"),
+    # round 6: the DEFAULT mode (fast_fixed: no tap-range shares) on the BASELINE configs and on the one-stream decimator
+    # that pays for it
+    ("cfg2_s1_default", (2, 44100, 48000, 7), 1, 1 << 20, "fast_fixed", "int16"),
+    ("cfg2_s32_default", (2, 44100, 48000, 7), 32, 1 << 20, "fast_fixed", "int16"),
+    ("cfg3_s1_default", (1, 24000, 48000, 10), 1, 1 << 20, "fast_fixed", "int16"),
+    ("cfg4_s1_default", (8, 48000, 44100, 5), 1, 1 << 20, "fast_fixed", "int16"),
+    ("cfg4_s32_default", (8, 48000, 44100, 5), 32, 1 << 20, "fast_fixed", "int16"),
+    ("one_48k_11k_2ch_default", (2, 48000, 11025, 7), 1, 441000, "fast_fixed", "int16"),
 ]
 
 
@@ -88,7 +96,7 @@ def measure(workload, launches=50, reps=3, preheat_ms=150.0):
     fio = io == "float"
     cap = int(F * fo / fi) + 1024
     b = speexhip.Batch(S, ch, fi, fo, q, mode={"fast": speexhip.MODE_FAST, "fast_f32": speexhip.MODE_FAST_F32,
-                                              "exact": speexhip.MODE_EXACT}[mode])
+                                              "exact": speexhip.MODE_EXACT, "fast_fixed": speexhip.MODE_FAST_FIXED}[mode])
     g = torch.Generator(device="cpu").manual_seed(1234)
     x = torch.randint(-20000, 20000, (S, F, ch), generator=g, dtype=torch.int16)
     nbuf = 3

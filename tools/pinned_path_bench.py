@@ -7,7 +7,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "node-speex-resampler_amd", "python"))
 sys.path.insert(0, ROOT)
 import numpy as np
-import torch  # noqa: F401  (one HIP runtime per process: speexhip.lib() loads behind torch's)
 import speexhip
 from bench import lcg_pcm, wrapper_capacity, pcie_peak
 

@@ -1,5 +1,5 @@
 'use strict';
-// tools/r05_steady.js -- VERDICT r4 #5: 24k->48k stereo q10 through processChunk took 0.16 ms on a fresh state and
+// tools/steady.js -- VERDICT r4 #5: 24k->48k stereo q10 through processChunk took 0.16 ms on a fresh state and
 // 0.43 ms on a running one (profiles/r04_node_bench.json).  Per call: time, whether the result was an external Buffer
 // over a pinned block or a copy (addon.stats()), with and without event-loop turns between the calls.
 const { performance } = require('perf_hooks');
