@@ -267,8 +267,12 @@ int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uin
     const int rc = speexhip::design_filter_frac(ratio_num, ratio_den, ratio_num, ratio_den, quality, &f, false);
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     std::memset(out, 0, 8 * sizeof(uint32_t));
-    const speexhip::PeriodPlan t = speexhip::plan_period(f, channels, speexhip::lds_budget());
-    const speexhip::SlidePlan sl = speexhip::plan_slide(f, channels);
+    // (round 6: small-denominator ratios outside the slide kernel's shapes plan the period kernel on a folded view)
+    speexhip::FilterSpec view;
+    const speexhip::FilterSpec &real = f;
+    const speexhip::FilterSpec &pf = speexhip::period_view(real, channels, &view) ? view : real;
+    const speexhip::PeriodPlan t = speexhip::plan_period(pf, channels, speexhip::lds_budget());
+    const speexhip::SlidePlan sl = speexhip::plan_slide(real, channels);
     if (t.usable) {
       out[0] = 2;
       out[1] = t.r;
@@ -277,10 +281,10 @@ int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uin
       out[4] = static_cast<uint32_t>(t.window_bytes);
       out[5] = t.pad;
       if (t.r == 10) {
-        const speexhip::PeriodPlan fine = speexhip::plan_period_r(f, channels, speexhip::lds_budget(), 5);
+        const speexhip::PeriodPlan fine = speexhip::plan_period_r(pf, channels, speexhip::lds_budget(), 5);
         out[6] = fine.usable && fine.lane_periods == t.lane_periods;
       }
-      const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, speexhip::lds_budget(), t);
+      const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(pf, channels, speexhip::lds_budget(), t);
       out[7] = w16.usable ? w16.lane_periods : 0;
     } else if (sl.usable) {
       out[0] = 3;
@@ -304,14 +308,16 @@ int speexhip_debug_launch_shape(uint32_t ratio_num, uint32_t ratio_den, int qual
     // the plans a stream state holds (engine.cpp, build_tables) and the choice of launch_chunk among them, for a
     // first call of `frames` frames on every stream (an r = 5 companion plan, where one exists, is not modelled)
     const size_t lds = speexhip::lds_budget();
-    const speexhip::PeriodPlan base = speexhip::plan_period(f, channels, lds);
+    speexhip::FilterSpec view;
+    const speexhip::FilterSpec &pf = speexhip::period_view(f, channels, &view) ? view : f;
+    const speexhip::PeriodPlan base = speexhip::plan_period(pf, channels, lds);
     if (!base.usable) return SPEEXHIP_ERR_SUCCESS;
     if (float_io != 0 && !base.float_ok) return SPEEXHIP_ERR_SUCCESS;  // (a plan that stands for its int16 plan alone: float calls run the exact kernel)
-    const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, lds, base);
+    const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(pf, channels, lds, base);
     speexhip::PeriodPlan pp, pp_w16;
-    if (speexhip::period_wants_pp_plans(f, channels)) {
-      pp = speexhip::plan_period(f, channels, lds, false, false, true);
-      pp_w16 = speexhip::plan_period_w16(f, channels, lds, pp);
+    if (speexhip::period_wants_pp_plans(pf, channels)) {
+      pp = speexhip::plan_period(pf, channels, lds, false, false, true);
+      pp_w16 = speexhip::plan_period_w16(pf, channels, lds, pp);
     }
     std::vector<speexhip::StreamDesc> descs(streams);
     for (auto &d : descs) {
@@ -344,9 +350,11 @@ int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, u
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     std::memset(out, 0, 8 * sizeof(uint32_t));
     const bool double_kind = f.kind == speexhip::kDirectDouble || f.kind == speexhip::kInterpolateDouble;
-    const speexhip::PeriodPlan base = speexhip::plan_period(f, channels, speexhip::lds_budget());
+    speexhip::FilterSpec view;
+    const speexhip::FilterSpec &pf = speexhip::period_view(f, channels, &view) ? view : f;
+    const speexhip::PeriodPlan base = speexhip::plan_period(pf, channels, speexhip::lds_budget());
     if (double_kind && base.usable) {
-      const speexhip::PeriodPlan t = speexhip::plan_period(f, channels, speexhip::lds_budget(), false, true);
+      const speexhip::PeriodPlan t = speexhip::plan_period(pf, channels, speexhip::lds_budget(), false, true);
       if (t.usable) {
         out[0] = 5;
         out[1] = t.r;
@@ -355,7 +363,7 @@ int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, u
         out[4] = static_cast<uint32_t>(t.window_bytes);
         out[5] = t.pad;
         out[6] = t.l4;
-        const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, speexhip::lds_budget(), t);  // (round 5)
+        const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(pf, channels, speexhip::lds_budget(), t);  // (round 5)
         out[7] = w16.usable ? w16.lane_periods : 0;
       }
     } else if (double_kind && speexhip::plan_slide(f, channels).usable) {
@@ -370,8 +378,8 @@ int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, u
       }
     }
     // phase-pair plans of mono filters with wide windows (any quality below 9)
-    if (!double_kind && base.usable && speexhip::period_wants_pp_plans(f, channels)) {
-      const speexhip::PeriodPlan t = speexhip::plan_period(f, channels, speexhip::lds_budget(), false, false, true);
+    if (!double_kind && base.usable && speexhip::period_wants_pp_plans(pf, channels)) {
+      const speexhip::PeriodPlan t = speexhip::plan_period(pf, channels, speexhip::lds_budget(), false, false, true);
       if (t.usable) {
         out[0] = 6;
         out[1] = t.r;
@@ -379,7 +387,7 @@ int speexhip_debug_plan64(uint32_t ratio_num, uint32_t ratio_den, int quality, u
         out[3] = t.row_len;
         out[4] = static_cast<uint32_t>(t.window_bytes);
         out[5] = t.pad;
-        const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(f, channels, speexhip::lds_budget(), t);
+        const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(pf, channels, speexhip::lds_budget(), t);
         out[7] = w16.usable ? w16.lane_periods : 0;
       }
     }

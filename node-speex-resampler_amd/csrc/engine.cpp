@@ -399,41 +399,46 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
   if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   t->geo = exact_geometry(f, channels, kLdsBudget);
   t->geo_ch = exact_geometry(f, 1, kLdsBudget);
-  t->period = plan_period(f, channels, kLdsBudget);
+  // (ratios with den <= 6 outside the slide kernel's shapes -- 7:6, 11:1, 16:3 ... -- plan the period kernel on a folded
+  //  view of the filter, 35:30, 110:10, 80:15: kernels.h, period_view; `pf` is what every period plan below is made on)
+  FilterSpec folded;
+  const bool use_fold = period_view(f, channels, &folded);
+  const FilterSpec &pf = use_fold ? folded : f;
+  t->period = plan_period(pf, channels, kLdsBudget);
   if (t->period.usable && t->period.float_ok) {
     std::vector<float> rows;
-    build_period_rows(f, t->period, &rows);
+    build_period_rows(pf, t->period, &rows);
     rc = upload(&t->period_rows, rows.data(), rows.size());
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
   if (t->period.usable && t->period.float_ok && t->period.r == 10) {
     static const bool no_fine = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
-    t->fine = plan_period_r(f, channels, kLdsBudget, 5);
+    t->fine = plan_period_r(pf, channels, kLdsBudget, 5);
     if (no_fine || t->fine.lane_periods != t->period.lane_periods) t->fine.usable = false;
     if (t->fine.usable) {
       std::vector<float> rows;
-      build_period_rows(f, t->fine, &rows);
+      build_period_rows(pf, t->fine, &rows);
       rc = upload(&t->fine_rows, rows.data(), rows.size());
       if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
     }
   }
-  t->w16 = plan_period_w16(f, channels, kLdsBudget, t->period);
+  t->w16 = plan_period_w16(pf, channels, kLdsBudget, t->period);
   if (t->w16.usable) {
     std::vector<float> rows;
-    build_period_rows(f, t->w16, &rows);
+    build_period_rows(pf, t->w16, &rows);
     rc = upload(&t->w16_rows, rows.data(), rows.size());
     if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
   }
-  if (t->period.usable && period_wants_pp_plans(f, channels)) {
-    t->pp = plan_period(f, channels, kLdsBudget, false, false, true);
+  if (t->period.usable && period_wants_pp_plans(pf, channels)) {
+    t->pp = plan_period(pf, channels, kLdsBudget, false, false, true);
     if (t->pp.usable) {
       std::vector<float> rows;
-      build_period_rows(f, t->pp, &rows);
+      build_period_rows(pf, t->pp, &rows);
       rc = upload(&t->pp_rows, rows.data(), rows.size());
       if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
-      t->pp_w16 = plan_period_w16(f, channels, kLdsBudget, t->pp);
+      t->pp_w16 = plan_period_w16(pf, channels, kLdsBudget, t->pp);
       if (t->pp_w16.usable) {
-        build_period_rows(f, t->pp_w16, &rows);
+        build_period_rows(pf, t->pp_w16, &rows);
         rc = upload(&t->pp_w16_rows, rows.data(), rows.size());
         if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
       }
@@ -451,30 +456,30 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
   // the reference's double kinds (quality 9, 10): fp64-accumulate twins of the fast kernels
   if (f.kind == kDirectDouble || f.kind == kInterpolateDouble) {
     if (t->period.usable) {
-      t->period64 = plan_period(f, channels, kLdsBudget, false, true);
+      t->period64 = plan_period(pf, channels, kLdsBudget, false, true);
       if (t->period64.usable) {
         std::vector<double> rows;
-        build_period_rows64(f, t->period64, &rows);
+        build_period_rows64(pf, t->period64, &rows);
         rc = upload_bytes(reinterpret_cast<void **>(&t->period64_rows), rows.data(), rows.size() * sizeof(double));
         if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
       }
       if (t->period64.usable && t->period64.r == 10) {
         static const bool no_fine64 = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
-        t->fine64 = plan_period_r(f, channels, kLdsBudget, 5, false, true);
+        t->fine64 = plan_period_r(pf, channels, kLdsBudget, 5, false, true);
         if (no_fine64 || t->fine64.lane_periods != t->period64.lane_periods) t->fine64.usable = false;
         if (t->fine64.usable) {
           std::vector<double> rows;
-          build_period_rows64(f, t->fine64, &rows);
+          build_period_rows64(pf, t->fine64, &rows);
           rc = upload_bytes(reinterpret_cast<void **>(&t->fine64_rows), rows.data(), rows.size() * sizeof(double));
           if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
         }
       }
     }
     if (t->period64.usable) {
-      t->period64_w16 = plan_period_w16(f, channels, kLdsBudget, t->period64);
+      t->period64_w16 = plan_period_w16(pf, channels, kLdsBudget, t->period64);
       if (t->period64_w16.usable) {
         std::vector<double> rows;
-        build_period_rows64(f, t->period64_w16, &rows);
+        build_period_rows64(pf, t->period64_w16, &rows);
         rc = upload_bytes(reinterpret_cast<void **>(&t->period64_w16_rows), rows.data(), rows.size() * sizeof(double));
         if (rc != SPEEXHIP_ERR_SUCCESS) return rc;
       }

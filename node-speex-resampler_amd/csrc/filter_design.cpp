@@ -170,8 +170,12 @@ int design_filter_frac(uint32_t ratio_num, uint32_t ratio_den, uint32_t in_rate,
 }
 
 void phase_blend(const FilterSpec &f, uint32_t phase, int *offset, float w[4]) {
-  *offset = static_cast<int>(phase * f.oversample / f.den);
-  const float t = (static_cast<float>((phase * f.oversample) % f.den)) / f.den;
+  // (a folded view, FilterSpec::fold: its phases and its den are `fold` times the filter's -- the reference's
+  //  arithmetic below runs on the filter's own)
+  const uint32_t den = f.den / f.fold;
+  phase /= f.fold;
+  *offset = static_cast<int>(phase * f.oversample / den);
+  const float t = (static_cast<float>((phase * f.oversample) % den)) / den;
   w[0] = -0.16667f * t + 0.16667f * t * t * t;
   w[1] = t + 0.5f * t * t - 0.5f * t * t * t;
   w[3] = -0.33333f * t + 0.5f * t * t - 0.16667f * t * t * t;
@@ -181,7 +185,7 @@ void phase_blend(const FilterSpec &f, uint32_t phase, int *offset, float w[4]) {
 void phase_taps(const FilterSpec &f, uint32_t phase, double *row) {
   const int n = static_cast<int>(f.taps);
   if (f.direct()) {
-    for (int j = 0; j < n; j++) row[j] = f.table[static_cast<size_t>(phase) * n + j];
+    for (int j = 0; j < n; j++) row[j] = f.table[static_cast<size_t>(phase / f.fold) * n + j];
     return;
   }
   int offset;

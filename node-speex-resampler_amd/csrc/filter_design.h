@@ -29,6 +29,13 @@ struct FilterSpec {
   uint32_t table_len = 0;     // floats in the reference-layout table
   std::vector<float> table;   // reference layout: den*taps (direct) or taps*oversample+8
   bool direct() const { return kind == kDirectSingle || kind == kDirectDouble; }
+  // Round 6 -- the PERIOD KERNEL'S VIEW of a ratio with a small denominator (kernels.h, period_view): num and den are
+  // `fold` times the filter's own.  A resampler's outputs repeat with period den; they repeat with period fold * den just
+  // as well -- output K has phase (K * num) mod den and window start (K * num) div den either way -- and the period
+  // kernel wants den >= 7 phases to fill its register tile.  So 7:6 runs as 35:30, 11:1 as 110:10: the same taps per
+  // output, in groups of five phases.  Phases of a folded spec are `fold` times the table's: phase_taps / phase_blend
+  // divide them back.  1 everywhere else.
+  uint32_t fold = 1;
 };
 
 // Returns a SPEEXHIP_ERR_* code.  `fill_table=false` computes the geometry only.

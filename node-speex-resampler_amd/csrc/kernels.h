@@ -96,7 +96,14 @@ struct PeriodPlan {         // per filter, fixed at init
   size_t rows_floats = 0, window_bytes = 0;
   bool float_ok = true;      // false (late in round 5): not even one period of the FLOAT window fits the LDS; the plan stands for
                              // its int16-window plan to hang off (int16 calls run over that), float calls take the exact kernel
+  uint32_t fold = 1;         // round 6: planned on a folded view of the filter (FilterSpec::fold, period_view): the kernel's
+                             // num and den are fold times the filter's
 };
+// Round 6: ratios with den <= 6 that the slide kernel does not cover (7:6, 11:1, 16:3, 25:1 ...) ran the exact kernel,
+// ~5x slower.  They get the period kernel on a FOLDED view: *view = f with num, den and fold multiplied so that den becomes
+// a multiple of 5 that is at least 10 (whole groups of five phases); returns true and fills *view (a copy of f, table
+// included) when this (filter, channel count) wants it, false (view untouched) otherwise.
+bool period_view(const FilterSpec &f, uint32_t channels, FilterSpec *view);
 PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16 = false, bool a64 = false,
                        bool pp = false);
 PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budget, uint32_t r, bool w16 = false,

@@ -46,6 +46,39 @@ uint32_t default_r_pp(const FilterSpec &f) {
 
 }  // namespace
 
+bool period_view(const FilterSpec &f, uint32_t channels, FilterSpec *view) {
+  if (f.fold != 1 || f.den > 6 || f.den == 0 || plan_slide(f, channels).usable) return false;
+  uint32_t k = 5;
+  while (k * f.den < 10) k += 5;
+  if (static_cast<uint64_t>(f.num) * k > 0x7fffffffull) return false;
+  *view = f;
+  view->num = f.num * k;
+  view->den = f.den * k;
+  view->fold = k;
+  return true;
+}
+
+namespace {
+// Launch time: the filter as a plan made on a folded view sees it (the state's FilterSpec carries no table then: a cheap
+// copy), and the descriptors with their period counts on the folded den.  k_shift and base_shift need no change: output K
+// of a stream is phase (K num) mod den at window start (K num) div den whatever period length K is decomposed by.
+struct FoldedLaunch {
+  FilterSpec f;
+  DescPack pack;
+  FoldedLaunch(const FilterSpec &real, uint32_t fold, const StreamDesc *h_descs, const DescPack *src, uint32_t n_streams) : f(real) {
+    f.num *= fold;
+    f.den *= fold;
+    f.fold = fold;
+    if (src != nullptr)
+      pack = *src;
+    else
+      std::memcpy(pack.d, h_descs, sizeof(StreamDesc) * n_streams);
+    for (uint32_t s = 0; s < n_streams; s++)
+      pack.d[s].m_total = static_cast<uint32_t>((static_cast<uint64_t>(pack.d[s].k_shift) + pack.d[s].n_out + f.den - 1) / f.den);
+  }
+};
+}  // namespace
+
 PeriodPlan plan_period(const FilterSpec &f, uint32_t channels, size_t lds_budget, bool w16, bool a64, bool pp) {
   PeriodPlan t = plan_period_r(f, channels, lds_budget, pp ? default_r_pp(f) : default_r(f), w16, a64, pp);
   if (!t.usable && t.r != 10) t = plan_period_r(f, channels, lds_budget, 10, w16, a64, pp);
@@ -80,6 +113,7 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   t.r = r;
   t.w16 = w16;
   t.a64 = a64;
+  t.fold = f.fold;
   const size_t eb = w16 ? 2 : 4;  // bytes per LDS element
   // Phase pairs for mono (round 4): the two halves of a packed FMA are two phases of one sample instead of two
   // periods of one tap, so a tile is 64 periods instead of 128 -- half the window for the same lanes (wide windows:
@@ -379,6 +413,10 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &t, const fl
 bool period_launch_prefers_w16(const FilterSpec &f, const PeriodPlan &t, bool has_fine, const StreamDesc *h_descs,
                                uint32_t n_streams) {
   if (!t.float_ok) return true;  // (there is no float window to prefer)
+  if (t.fold != f.fold) {
+    const FoldedLaunch v(f, t.fold, h_descs, nullptr, n_streams);
+    return period_launch_prefers_w16(v.f, t, has_fine, v.pack.d, n_streams);
+  }
   const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
   const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;
   if (split_count(t, tiles, n_streams, 2 * device_compute_units()) == 1) return true;
@@ -411,6 +449,10 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
                               uint32_t n_streams) {
   static const int env_pp = SPEEXHIP_DIAG_ENV("SPEEXHIP_PP") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_PP")) : -1;
   if (env_pp >= 0) return env_pp != 0;
+  if (two.fold != f.fold) {
+    const FoldedLaunch v(f, two.fold, h_descs, nullptr, n_streams);
+    return period_launch_prefers_pp(v.f, two, pp, v.pack.d, n_streams);
+  }
   const uint32_t cus = device_compute_units();
   const uint32_t slots = 64 / two.cgroups * (two.ct == 1 ? 2 : 1);  // periods a full tile of the other plan holds
   const bool unfilled = 4 * two.lane_periods < 3 * slots;
@@ -458,6 +500,10 @@ bool period_launch_prefers_pp(const FilterSpec &f, const PeriodPlan &two, const 
 // Host only (speexhip_debug_launch_shape, tests): the shape launch_period_plan would give this launch.
 bool debug_period_shape(const FilterSpec &f, const PeriodPlan &t, uint32_t channels, const StreamDesc *h_descs, uint32_t n_streams,
                         bool float_io, uint32_t out[6]) {
+  if (t.fold != f.fold) {
+    const FoldedLaunch v(f, t.fold, h_descs, nullptr, n_streams);
+    return debug_period_shape(v.f, t, channels, v.pack.d, n_streams, float_io, out);
+  }
   PeriodShape sh{};
   if (launch_period_plan(f, t, nullptr, channels, h_descs, nullptr, n_streams, float_io, nullptr, &sh) != hipSuccess) return false;
   out[0] = sh.tiles;
@@ -478,6 +524,10 @@ hipError_t launch_period(const FilterSpec &f, const PeriodPlan &t, const float *
                          const float *d_rows_fine, uint32_t channels, const StreamDesc *h_descs,
                          const DescPack *pack, uint32_t n_streams, bool float_io,
                          hipStream_t stream, bool fixed_shape) {
+  if (t.fold != f.fold) {  // a plan made on a folded view of this filter (period_view)
+    const FoldedLaunch v(f, t.fold, h_descs, pack, n_streams);
+    return launch_period(v.f, t, d_rows, fine, d_rows_fine, channels, v.pack.d, &v.pack, n_streams, float_io, stream, fixed_shape);
+  }
   if (fine != nullptr && fine->usable && d_rows_fine != nullptr) {
     const uint32_t max_periods = periods_of_launch(f, h_descs, n_streams);
     const uint32_t tiles = (max_periods + t.lane_periods - 1) / t.lane_periods;

@@ -422,12 +422,22 @@ def test_planner_choices_for_the_named_configurations():
     assert cfg2["w16_lane_periods"] == 0 and cfg4["w16_lane_periods"] == 0
     # (round 5: three channels too -- 18 -> 38 of a tile's 42 periods)
     assert plan(48000, 11025, 7, 3)["w16_lane_periods"] == 38 and plan(48000, 11025, 7, 3)["lane_periods"] == 18
-    # n:1 shapes: one period per lane from 16:1 on; 11:1 and 7:6 have no fast kernel
+    # n:1 shapes: one period per lane from 16:1 on
     assert plan(192000, 8000, 7, 2)["r_or_p"] == 1 and plan(96000, 8000, 7, 2)["r_or_p"] == 2
     assert plan(48000, 8000, 7, 2)["r_or_p"] == 4 and plan(48000, 24000, 7, 2)["r_or_p"] == 8
-    assert plan(88000, 8000, 5, 1)["fast_path"] == 0 and plan(56000, 48000, 4, 2)["fast_path"] == 0
+    # round 6: 11:1, 7:6, 9:2, 16:3, 25:1 -- den <= 6 outside the slide kernel's shapes -- plan the period kernel on a
+    # folded view (110:10, 35:30, 45:10, 80:15, 250:10: whole groups of five phases); a filter no LDS holds stays exact
+    for (i, o, q, ch) in ((88000, 8000, 5, 1), (56000, 48000, 4, 2), (72000, 16000, 7, 2), (200000, 8000, 5, 2)):
+        got = plan(i, o, q, ch)
+        assert (got["fast_path"], got["r_or_p"]) == (2, 5), ((i, o, q, ch), got)
+    assert plan(64000, 12000, 7, 1)["fast_path"] == 2 and plan(192000, 1000, 10, 1)["fast_path"] == 0
+    assert speexhip.debug_plan64(7, 6, 10, 1)["fast_path"] == 5
     # a filter too long for even a two-wave workgroup falls back to the exact kernel
-    assert plan(192000, 8000, 10, 8)["fast_path"] in (0, 3)
+    # (24:1 of 6 144 taps x 8 channels fits no slide workgroup; since round 6 it runs the period kernel folded to 240:10, int16
+    #  calls over the int16 window -- 14 of a tile's 16 periods; 192:1 at quality 10 fits nothing)
+    p24 = plan(192000, 8000, 10, 8)
+    assert p24["fast_path"] == 2 and p24["w16_lane_periods"] >= 8
+    assert plan(192000, 1000, 10, 8)["fast_path"] == 0
     assert plan(192000, 1000, 10, 1)["fast_path"] == 0
 
 

@@ -424,11 +424,11 @@ def test_eight_channel_padded_window_and_odd_channel_counts():
 
 
 def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
-    """Ratios no fast kernel covers (11:1, 7:6, filters too long for LDS) must still be right:
-    FAST mode falls back to the bit-exact kernel (fast_path == 0), staged in LDS or streaming
-    straight from L2 when the filter does not fit."""
-    for (ch, i, o, q, frames) in [(1, 88000, 8000, 5, 30000), (2, 56000, 48000, 4, 4000),
-                                  (1, 192000, 1000, 10, 120000), (2, 96000, 1500, 3, 90000)]:
+    """Filters no fast kernel can hold (192:1 at quality 10: 49 152 taps, a window beyond the LDS) must still be right:
+    the fast modes fall back to the bit-exact kernel (fast_path == 0), staged in LDS or streaming straight from L2 when
+    the filter does not fit.  (Until round 6 this list also held 11:1, 7:6 and 64:1: they run the period kernel on a
+    folded view now -- test_small_denominator_ratios_run_the_period_kernel_on_a_folded_view.)"""
+    for (ch, i, o, q, frames) in [(1, 192000, 1000, 10, 120000), (2, 192000, 1000, 8, 90000)]:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
         assert r.info()["fast_path"] == 0, (ch, i, o, q)
@@ -439,6 +439,61 @@ def test_extreme_ratios_take_the_exact_kernel_even_in_fast_mode():
             assert used == wu and r.position() == ref.position()
             assert np.array_equal(got, want), "exact fallback differs for %s" % ((ch, i, o, q),)
         r.close()
+
+
+def test_small_denominator_ratios_run_the_period_kernel_on_a_folded_view():
+    """Round 6 (VERDICT r5 #7a).  Ratios with den <= 6 outside the slide kernel's shapes -- 7:6, 11:1, 9:2, 16:3, 25:1,
+    64:1, 7:2 -- ran the exact kernel (~5x slower).  A resampler's outputs repeat with period den, hence also with period
+    k * den: they run the period kernel as 35:30, 110:10, 45:10, 80:15 ... (FilterSpec::fold, period_view), the same taps
+    per output.  fast_path 2 (5 where the reference sums in fp64), every sample within +-1 LSB over several calls of ragged
+    sizes, counters, position and history equal; float entry point and a many-states launch too; EXACT mode unchanged."""
+    cases = [(1, 88000, 8000, 5), (2, 56000, 48000, 4), (2, 96000, 1500, 3), (2, 72000, 16000, 7), (1, 64000, 12000, 7),
+             (2, 200000, 8000, 5), (1, 56000, 48000, 10), (3, 88000, 8000, 6), (8, 56000, 48000, 5), (4, 72000, 16000, 9),
+             (2, 28000, 8000, 6), (6, 88000, 8000, 3), (1, 56000, 48000, 0),
+             # 24:1 of 6 144 taps x 8 channels: too long for a slide workgroup, folded to 240:10 over the int16 window (fp32 chain)
+             (8, 192000, 8000, 10)]
+    for (ch, i, o, q) in cases:
+        ref = orc.Oracle(ch, i, o, q)
+        r = speexhip.Resampler(ch, i, o, q)
+        info = r.info()
+        assert info["fast_path"] in (2, 5) and info["den_rate"] <= 6, ((ch, i, o, q), info["fast_path"], info["den_rate"])
+        assert (info["fast_path"] == 5) == (q >= 9 and ch in (1, 2, 4, 6, 8) and i != 192000), ((ch, i, o, q), info["fast_path"])
+        long_filter = q >= 8 and i > 2 * o
+        for call, frames in enumerate([50000, 3, 0, 1, 70001, 160]):
+            x = orc.tone_pcm(frames, ch, seed=call + q) if call % 2 else orc.lcg_pcm(frames * ch, 31 + call).reshape(frames, ch)
+            got, used = r.process(x, 1 << 20)
+            want, wu = ref.process(x, 1 << 20)
+            assert used == wu and r.position() == ref.position(), ((ch, i, o, q), call)
+            assert_close(got, want, "folded %s call %d" % ((ch, i, o, q), call), rate=0.017 if long_filter else MISMATCH_RATE)
+        h = r.history()
+        for c in range(ch):
+            assert np.array_equal(h[:, c], ref.history(c)), (ch, i, o, q)
+        r.close()
+    # float entry point; EXACT stays bit-identical; 40 states of one folded filter through one many-states call
+    for (ch, i, o, q) in [(2, 56000, 48000, 4), (1, 88000, 8000, 5)]:
+        x = orc.lcg_pcm(40000 * ch, 5).reshape(40000, ch)
+        xf = x.astype(np.float32) / np.float32(32768.0)
+        r, ref = speexhip.Resampler(ch, i, o, q), orc.Oracle(ch, i, o, q)
+        got, used = r.process_float(xf, 1 << 20)
+        want, wu = ref.process_float(xf, 1 << 20)
+        assert used == wu and np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 4e-6, (ch, i, o, q)
+        r.close()
+        e = speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT)
+        got, used = e.process(x, 1 << 20)
+        want, wu = orc.Oracle(ch, i, o, q).process(x, 1 << 20)
+        assert used == wu and np.array_equal(got, want), (ch, i, o, q)
+        e.close()
+        states = [speexhip.Resampler(ch, i, o, q) for _ in range(40)]
+        refs = [orc.Oracle(ch, i, o, q) for _ in range(40)]
+        for step, f in enumerate([9000, 161]):
+            chunks = [orc.lcg_pcm((f + s) * ch, 100 * step + s).reshape(f + s, ch) for s in range(40)]
+            outs, useds, codes = speexhip.process_many(states, chunks, [1 << 16] * 40)
+            for s in range(40):
+                want, wu = refs[s].process(chunks[s], 1 << 16)
+                assert codes[s] == 0 and useds[s] == wu and states[s].position() == refs[s].position(), (s, step)
+                assert_close(outs[s], want, "folded many %s state %d" % ((ch, i, o, q), s))
+        for st in states:
+            st.close()
 
 
 def test_n_to_one_decimation_takes_the_slide_kernel():
@@ -1585,11 +1640,10 @@ def test_fp64_accumulate_slide_kernel_on_every_shape():
             ref = orc.Oracle(ch, i, o, q)
             r = speexhip.Resampler(ch, i, o, q)
             info = r.info()
-            if (i, o) in ((56000, 16000), (72000, 16000)) and ch == 2:
-                assert info["fast_path"] == 0     # (no fp32 slide shape for channel pairs there: exact kernel)
-                r.close()
-                continue
-            assert info["fast_path"] == 4 and info["accumulate_bits"] == 64, (ch, i, o, q, info)
+            # (7:2 and 9:2 have no slide shape for channel pairs: the exact kernel until round 6, now the fp64-accumulate
+            #  PERIOD kernel on a folded view of the filter, 35:10 and 45:10 -- same checks)
+            folded = (i, o) in ((56000, 16000), (72000, 16000)) and ch == 2
+            assert info["fast_path"] == (5 if folded else 4) and info["accumulate_bits"] == 64, (ch, i, o, q, info)
             for call, frames in enumerate([1, 30000, 777, 50001]):
                 x = orc.lcg_pcm(frames * ch, 17 * call + ch + n).reshape(frames, ch)
                 cap = max(1, frames * o // i // 2) if call == 2 else 1 << 20  # one capacity-bound call
