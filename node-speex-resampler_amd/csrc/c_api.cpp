@@ -620,6 +620,6 @@ int speexhip_plan_filter_change(uint32_t old_filt_len, uint32_t new_filt_len, ui
   return SPEEXHIP_ERR_SUCCESS;
 }
 
-const char *speexhip_version(void) { return "speexhip 0.3.0 gfx950"; }
+const char *speexhip_version(void) { return "speexhip 0.4.0 gfx950"; }
 
 }  // extern "C"
