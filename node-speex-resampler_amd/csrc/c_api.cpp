@@ -282,7 +282,7 @@ int speexhip_debug_plan(uint32_t ratio_num, uint32_t ratio_den, int quality, uin
       out[5] = t.pad;
       if (t.r == 10) {
         const speexhip::PeriodPlan fine = speexhip::plan_period_r(pf, channels, speexhip::lds_budget(), 5);
-        out[6] = fine.usable && fine.lane_periods == t.lane_periods;
+        out[6] = fine.usable && fine.float_ok && fine.lane_periods == t.lane_periods;
       }
       const speexhip::PeriodPlan w16 = speexhip::plan_period_w16(pf, channels, speexhip::lds_budget(), t);
       out[7] = w16.usable ? w16.lane_periods : 0;

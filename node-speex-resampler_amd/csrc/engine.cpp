@@ -414,7 +414,10 @@ int build_tables(int device, const FilterSpec &g, uint32_t channels, hipStream_t
   if (t->period.usable && t->period.float_ok && t->period.r == 10) {
     static const bool no_fine = SPEEXHIP_DIAG_ENV("SPEEXHIP_NO_FINE") != nullptr;  // diagnostics: A/B
     t->fine = plan_period_r(pf, channels, kLdsBudget, 5);
-    if (no_fine || t->fine.lane_periods != t->period.lane_periods) t->fine.usable = false;
+    // (... and a float window of its own: an R = 5 plan that only stands for its int16 plan -- 100 channels of 320:147, one
+    //  period per tile either way -- has nothing to launch; found by the fuzzer the day the layouts without an ISA loop
+    //  got int16 plans, seed 611002591)
+    if (no_fine || !t->fine.float_ok || t->fine.lane_periods != t->period.lane_periods) t->fine.usable = false;
     if (t->fine.usable) {
       std::vector<float> rows;
       build_period_rows(pf, t->fine, &rows);
@@ -1687,6 +1690,7 @@ int warm_device(int device) {
   warm_unit_period_odd(s);
   warm_unit_period_frames(s);
   warm_unit_period64_w16(s);
+  warm_unit_period_w16g(s);
   warm_unit_slide_f32(s);
   warm_unit_slide64_f32(s);
   HIP_TRY(hipStreamSynchronize(s));

@@ -46,6 +46,7 @@ void warm_unit_period_pp(hipStream_t s);
 void warm_unit_period_odd(hipStream_t s);
 void warm_unit_period_frames(hipStream_t s);
 void warm_unit_period64_w16(hipStream_t s);
+void warm_unit_period_w16g(hipStream_t s);
 
 // compute units of the calling thread's current device (cached per device id)
 inline uint32_t device_compute_units() {

@@ -12,6 +12,8 @@ hipError_t dispatch_period64_w16(const PeriodPlan &t, const PeriodParams &p, con
 // the instances for frames of five and seven channels (kernels_period_odd.hip)
 hipError_t dispatch_period_frames(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                                   dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);  // kernels_period_frames.hip
+hipError_t dispatch_period_w16g(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack, dim3 grid, uint32_t threads,
+                                hipStream_t stream);  // kernels_period_w16g.hip
 hipError_t dispatch_period_odd(const PeriodPlan &t, const PeriodParams &p, const DescPack *pack,
                                dim3 grid, uint32_t threads, bool float_io, hipStream_t stream);
 // the phase-pair instances for mono (kernels_period_pp.hip)
@@ -279,7 +281,10 @@ PeriodPlan plan_period_r(const FilterSpec &f, uint32_t channels, size_t lds_budg
   // (frames of 10 / 12 / 16 channels -- 5, 6, 8 channel pairs -- have ISA loops of the fp32 chain since late in round 5:
   //  the int16 window, not the fp64 rows)
   const bool wide_frame = t.ct == 2 && (t.cgroups == 5 || t.cgroups == 6 || t.cgroups == 8) && !a64;
-  if ((w16 || a64) && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1) || odd_frame || wide_frame)) t.usable = false;
+  // (round 6: the int16 window on every other layout too, read by the C++ loop -- kernels_period_w16g.hip; the fp64 rows
+  //  stay with the ISA loops)
+  if (a64 && !t.pp && !((t.ct == 2 && t.cgroups <= 4) || (t.ct == 1 && t.cgroups == 1) || odd_frame || wide_frame)) t.usable = false;
+  if (w16 && !t.pp && t.pad != 0 && t.r != 10) t.usable = false;
   if (t.pp && t.pad != 0 && t.r != 10) t.usable = false;
   return t;
 }
@@ -797,6 +802,8 @@ hipError_t launch_period_plan(const FilterSpec &f, const PeriodPlan &plan, const
   if (t.pp) return dispatch_period_pp(t, p, pack, grid, threads, float_io, stream);   // kernels_period_pp.hip
   if (t.ct == 1 && (t.cgroups == 3 || t.cgroups == 5 || t.cgroups == 7)) return dispatch_period_odd(t, p, pack, grid, threads, float_io, stream);
   if (t.ct == 2 && (t.cgroups == 5 || t.cgroups == 6 || t.cgroups == 8)) return dispatch_period_frames(t, p, pack, grid, threads, float_io, stream);
+  // (round 6: the int16 window of the layouts without an ISA loop -- frames of 9, 11, 13-15, 17 ... channels, C++ loop)
+  if (t.w16 && !(t.cgroups == 1 || (t.ct == 2 && t.cgroups <= 4))) return dispatch_period_w16g(t, p, pack, grid, threads, stream);
   // (LRC: the kernel of the layout, or its tap-range-shares twin)
 #define SPEEXHIP_LRCW(RV, CTV, ONE, PADV, TV, CGV, W)                                                                                    \
   (p.ksplit > 1 ? launch_rc<RV, CTV, ONE, PADV, TV, CGV, W, true>(p, pack, grid, threads, t.window_bytes, stream)              \

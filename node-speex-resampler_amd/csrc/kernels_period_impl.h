@@ -164,10 +164,20 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   const uint32_t C = c.C;
   const uint32_t delta_g = p.delta[g];  // (g*R*num) div den, tabulated on the host
   // (delta_g < num: no padding boundary before the group's first sample)
-  const float *xp = xs + c.xlane + delta_g * C;
-  if constexpr (W16) {
+  // (E: the element type of the LDS window -- int16 samples as they came from HBM for W16, floats otherwise; positions count
+  //  elements either way)
+  using E = typename std::conditional<W16, int16_t, float>::type;
+  const E *xp = reinterpret_cast<const E *>(xs) + c.xlane + delta_g * C;
+#ifndef SPEEXHIP_CXX_FIR_LOOP
+  constexpr bool kIsa16 = W16 && CF != 0 && FirLoopAsm<R, CT, CF, PADDED, W16>::available;
+#else
+  constexpr bool kIsa16 = false;
+#endif
+  // Round 6: an int16 window on the layouts WITHOUT an ISA loop too (frames of 9, 11, 13-15, 17 ... channels: the C++ loop
+  // below converts each sample it reads) -- their wide-window decimators held half the periods per tile of their
+  // neighbours with ISA loops and ran at 0.10-0.16 of the vector peak beside 0.33-0.39 (profiles/r06_sweep_frames.txt).
+  if constexpr (kIsa16) {
     using Isa = FirLoopAsm<R, CT, CF, PADDED, true>;
-    static_assert(CF != 0 && Isa::available, "an int16 window needs the ISA loop of its layout");
     constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
     const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];
     const uint32_t head = R == 10 ? trips & 15u : 0u, tail = R == 10 ? (trips >> 4) & 15u : 0u;
@@ -187,7 +197,7 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   // its reference -- same taps, same samples, same order per accumulator -- and runs the other layouts
   // (odd channel counts >= 3, more than 8 channels).  -DSPEEXHIP_CXX_FIR_LOOP builds the A/B library.
   using Isa = FirLoopAsm<R, CT, CF, PADDED, false>;
-  if constexpr (CF != 0 && Isa::available) {
+  if constexpr (!W16 && CF != 0 && Isa::available) {
     constexpr uint32_t kStepsPerTrip = 2 * Isa::steps_per_bank;
     static_assert(kStepsPerTrip * R == 2 * bank_taps(R), "the ISA loop and the tap rows disagree on the trip");
     const uint32_t trips = skip_all ? 0u : p.delta[2 * p.groups + g];  // head | tail << 4 | total << 8
@@ -240,12 +250,15 @@ __device__ __forceinline__ void fir_group(const PeriodParams &p, const float *__
   static_assert(R == 10 || R == 5, "phases per wave");
   const float *__restrict__ trow = rows + static_cast<size_t>(g) * p.l4 * (2 * BANK);
   f32x2 ta[NP], tb[NP], xa[STEPS], xb[STEPS];
-  auto load_bank = [&](f32x2 (&t)[NP], f32x2 (&x)[STEPS], const float *tp, const float *sp) {
+  auto load_bank = [&](f32x2 (&t)[NP], f32x2 (&x)[STEPS], const float *tp, const E *sp) {
 #pragma unroll
     for (int j = 0; j < NP; j++) t[j] = *reinterpret_cast<const f32x2 *>(tp + 2 * j);
 #pragma unroll
     for (int u = 0; u < STEPS; u++) {
-      if (CT == 2) {
+      if constexpr (W16) {  // (one 4-byte read and two conversions for a channel pair; two 2-byte reads for a lane's two periods)
+        x[u].x = static_cast<float>(sp[u * C]);
+        x[u].y = static_cast<float>(CT == 2 ? sp[u * C + 1] : sp[u * C + p.half_offset]);
+      } else if (CT == 2) {
         x[u] = *reinterpret_cast<const f32x2 *>(sp + u * C);
       } else {
         // (mono: two steps of each period arrive as (a0, a1), (b0, b1) and hipcc re-pairs them with ~7 v_mov

@@ -416,7 +416,7 @@ def test_planner_choices_for_the_named_configurations():
     for i, o in ((44100, 8000), (88200, 48000), (88200, 16000), (176400, 8000)):
         assert plan(i, o, 7, 2)["r_or_p"] == 5, (i, o)
     # wide windows (round 3): int16 calls run over an int16 LDS window with twice the periods per tile; not where
-    # the float window already fills the waves, not for the layouts without an ISA loop (9 channels and more)
+    # the float window already fills the waves (round 6: the layouts without an ISA loop, 9 channels and more, have one too)
     assert plan(48000, 11025, 7, 2)["w16_lane_periods"] >= 2 * plan(48000, 11025, 7, 2)["lane_periods"]
     assert plan(44100, 16000, 7, 2)["w16_lane_periods"] == 64 and plan(48000, 11025, 7, 4)["w16_lane_periods"] == 28
     assert cfg2["w16_lane_periods"] == 0 and cfg4["w16_lane_periods"] == 0
@@ -659,8 +659,12 @@ def test_round5_plans_for_wide_frames_and_plans_that_stand_for_their_int16_windo
         t = plan(640, 147, 7, ch)
         assert (t["fast_path"], t["r_or_p"], t["lane_periods"], t["w16_lane_periods"]) == (2, 10, lp, lp16), (ch, t)
         assert plan(147, 160, 7, ch)["fast_path"] == 2 and plan(147, 160, 7, ch)["w16_lane_periods"] == 0, ch  # narrow: float window
-    # 9 channels (no ISA loop): no int16 window
-    assert plan(640, 147, 7, 9)["w16_lane_periods"] == 0
+    # 9 channels (no ISA loop): no int16 window until round 6; now the C++ loop reads one (kernels_period_w16g.hip):
+    # twice the periods per tile on wide windows, none where the float window already fills the waves
+    for ch in (9, 11, 13, 14, 15, 17, 20):
+        t = plan(640, 147, 7, ch)
+        assert t["fast_path"] == 2 and t["w16_lane_periods"] >= 2 * t["lane_periods"] - 1 > 0, (ch, t)
+        assert plan(147, 160, 7, ch)["w16_lane_periods"] == 0, ch
     # 8 channels of 2 232 taps at num = 1280: one period of the float window (a sixteenth of a tile), five of the int16 one
     t = plan(1280, 147, 10, 8)
     assert (t["fast_path"], t["lane_periods"], t["w16_lane_periods"]) == (2, 1, 5) and t["lds_bytes"] > 0, t

@@ -773,7 +773,10 @@ def test_window_layout_variants_of_the_period_kernel():
              # frames of 10 / 12 / 16 channels (5, 6, 8 channel pairs; kernels_period_frames.hip): unpadded, padded, groups of 5,
              # wide windows (int16 window under SPEEXHIP_W16_ALWAYS, test_int16_window_on_small_launches_too)
              (10, 44100, 48000, 7), (12, 48000, 44100, 5), (16, 44100, 48000, 4), (12, 44100, 8000, 6), (10, 48000, 11025, 7),
-             (16, 48000, 11025, 5), (12, 32000, 44100, 8), (16, 96000, 11025, 7), (12, 96000, 11025, 8)]
+             (16, 48000, 11025, 5), (12, 32000, 44100, 8), (16, 96000, 11025, 7), (12, 96000, 11025, 8),
+             # round 6: frames WITHOUT an ISA loop (C++ loop) -- their int16 window under SPEEXHIP_W16_ALWAYS too
+             (9, 48000, 11025, 7), (11, 44100, 16000, 6), (13, 48000, 11025, 5), (14, 96000, 11025, 4), (15, 44100, 8000, 7),
+             (17, 48000, 11025, 7), (20, 44100, 16000, 5), (18, 32000, 44100, 7), (9, 44100, 48000, 7)]
     for (ch, i, o, q) in cases:
         ref = orc.Oracle(ch, i, o, q)
         r = speexhip.Resampler(ch, i, o, q)
@@ -2408,3 +2411,42 @@ def test_block_acquire_hands_out_distinct_blocks_and_says_no_when_the_slabs_are_
     b.close()
     with pytest.raises(MemoryError):
         speexhip.PinnedBlock(1 << 40)
+
+
+def test_int16_window_on_the_layouts_without_an_isa_loop():
+    """Round 6 (VERDICT r5 #7c): frames of 9, 11, 13, 14, 15, 17, 20, 24 channels run the C++ FIR loop; their wide-window
+    decimators now get an int16 LDS window as well (kernels_period_w16g.hip: the loop converts each sample it reads), twice
+    the periods per tile.  Eight states x 100 000 frames through one many-states call -- a launch large enough for the
+    planner's own rule to take the int16 window (checked through the shape hook) -- two steps, then a float call that moves
+    the state to the float window for good: +-1 LSB, counters, positions and histories equal."""
+    from math import gcd
+    for (ch, i, o, q) in [(9, 48000, 11025, 7), (11, 48000, 11025, 6), (13, 48000, 11025, 5), (14, 48000, 11025, 7),
+                          (15, 96000, 11025, 4), (17, 48000, 11025, 7), (20, 48000, 11025, 6), (24, 44100, 16000, 5)]:
+        g = gcd(i, o)
+        shape = speexhip.debug_launch_shape(i // g, o // g, q, ch, 8, 100000)
+        assert shape["int16_window"] and shape["r"] in (5, 10), ((ch, i, o, q), shape)
+        states = [speexhip.Resampler(ch, i, o, q) for _ in range(8)]
+        refs = [orc.Oracle(ch, i, o, q) for _ in range(8)]
+        assert states[0].info()["fast_path"] == 2
+        for step, frames in enumerate([100000, 100000 + 7]):
+            chunks = [orc.lcg_pcm((frames + s) * ch, 50 * step + s).reshape(frames + s, ch) for s in range(8)]
+            outs, useds, codes = speexhip.process_many(states, chunks, [1 << 17] * 8)
+            for s in range(8):
+                want, wu = refs[s].process(chunks[s], 1 << 17)
+                assert codes[s] == 0 and useds[s] == wu and states[s].position() == refs[s].position(), ((ch, i, o, q), s, step)
+                assert_close(outs[s], want, "int16 window, C++ loop %s state %d step %d" % ((ch, i, o, q), s, step))
+        xf = orc.lcg_pcm(3000 * ch, 3).reshape(3000, ch).astype(np.float32) / np.float32(32768.0)
+        got, used = states[0].process_float(xf, 1 << 16)
+        want, wu = refs[0].process_float(xf, 1 << 16)
+        # (the float call's first outputs still see the int16-scale history: an LSB-sized absolute tolerance, as in the mixed tests)
+        assert used == wu and np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 0.05
+        x = orc.lcg_pcm(20000 * ch, 9).reshape(20000, ch)
+        got, used = states[0].process(x, 1 << 16)
+        want, wu = refs[0].process(x, 1 << 16)
+        assert used == wu
+        assert_close(got, want, "after a float call %s" % ((ch, i, o, q),))
+        for s in range(8):
+            h = states[s].history()
+            for c in range(ch):
+                assert np.array_equal(h[:, c], refs[s].history(c)), ((ch, i, o, q), s)
+            states[s].close()

@@ -382,12 +382,18 @@ def main():
     seed = (args.seed * 1000003) % (2 ** 32 - 10 ** 7)  # (trial seeds = seed + n must stay below numpy's 2^32)
     while time.time() - t0 < args.seconds:
         s = args.only if args.only is not None else seed + trials
-        if args.many:
-            err, what = many_trial(s, args.max_frames)
-        elif (args.batch or args.only is not None) and (s % 3 == 0) and (args.batch or args.only_batch):
-            err, what = batch_trial(s, args.max_frames)
-        else:
-            err, what = one_trial(s, args.max_frames if not args.many_channels else min(args.max_frames, 30000), args.many_channels)
+        try:
+            if args.many:
+                err, what = many_trial(s, args.max_frames)
+            elif (args.batch or args.only is not None) and (s % 3 == 0) and (args.batch or args.only_batch):
+                err, what = batch_trial(s, args.max_frames)
+            else:
+                err, what = one_trial(s, args.max_frames if not args.many_channels else min(args.max_frames, 30000), args.many_channels)
+        except RuntimeError as e:  # (an error code out of the library is a failure of the trial, with its seed)
+            err, what = "exception: %s" % e, "seed %d" % s
+            if args.only is not None:
+                import traceback
+                traceback.print_exc()
         trials += 1
         if err:
             fails += 1
