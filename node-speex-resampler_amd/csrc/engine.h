@@ -199,6 +199,7 @@ class Batch {
   PeriodPlan period_w16_;   // the same filter over an int16 LDS window (usable only where it pays)
   float *d_period_w16_rows_ = nullptr;
   bool float_seen_ = false;  // a float call has put samples into the histories that an int16 window cannot hold
+  void int16_call_done(const CallPlan *plans, uint32_t n);  // ... until int16 calls have replaced all of them (round 6)
   SlidePlan slide_;        // small-ratio fast path (kernels_slide.hip); neither usable -> exact
   float *d_slide_rows_ = nullptr;
   SlidePlan slide64_;      // ... with an fp64 accumulator: what FAST runs for the double kinds (quality 9, 10)

@@ -1459,7 +1459,8 @@ def test_control_calls_and_destruction_do_not_wait_for_other_states():
 def test_int16_window_plan_serves_int16_calls_until_a_float_call():
     """Round 3: ratios whose float LDS window cannot hold a full tile (48k->11.025k ...) run int16 calls over an
     int16 window.  That is only right while the histories hold PCM values: after a float call (non-integer
-    samples in the history) the stream goes back to the float window for good.  Int16 / float / int16 calls on
+    samples in the history) the stream goes back to the float window -- until int16 calls have replaced the whole history
+    (round 6; "for good" until then).  Int16 / float / int16 calls on
     one state against the oracle doing the same, FAST mode within +-1 LSB (float: relative), counters equal;
     and the window kind shows in nothing but speed: SPEEXHIP_NO_W16-style A/B is tools/gpu_ab.sh's job."""
     # (16 channels 96k -> 11.025k, late in round 5: not even one period of the float window fits the LDS -- the plan exists for its
@@ -1468,7 +1469,9 @@ def test_int16_window_plan_serves_int16_calls_until_a_float_call():
         assert speexhip.debug_plan(i, o, q, ch)["w16_lane_periods"] > 0
         r = speexhip.Resampler(ch, i, o, q)
         ref = orc.Oracle(ch, i, o, q)
-        for step, frames in enumerate([50000, 777, 40000, 3000, 60000]):
+        # (round 6: a SHORT int16 call behind the float calls leaves fractions in the history -- the float window still --, a
+        #  long one replaces them all, and the calls after it run over the int16 window again)
+        for step, frames in enumerate([50000, 777, 40000, 3000, 100, 60000, 50000, 20, 30000]):
             if step in (2, 3):      # float calls: samples with fractions
                 xf = (orc.lcg_pcm(frames * ch, 10 + step).astype(np.float32) * np.float32(0.37)).reshape(-1, ch)
                 got, used = r.process_float(xf, 1 << 20)
