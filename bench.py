@@ -26,8 +26,15 @@ Prints ONE JSON line on rank 0 (contract in the task description): value = whole
 Msamples/s, plus "roofline" (algorithmic HBM bytes per launch / launch time measured with HIP
 events on the launch stream, vs the 8 TB/s HBM peak), "parity" (first chunk of up to four
 streams checked against the CPU oracle) and, at N=1, "cpu_baseline" (the reference's own C
-timed on the host cores) and "end_to_end" (the host-buffer call a Node caller makes, PCIe
-included -- reported beside `value`, never as it).
+timed on the host cores) and the HOST-FED legs, reported beside `value`, never as it: "end_to_end"
+(the host-buffer call a Node caller makes, PCIe included: pageable input, and -- round 6 -- a chunk
+in a pinned block of the library, read in place), "end_to_end_streams" (32 states through one
+many-states call), each with a "pcie" block {achieved_in_GBs, achieved_out_GBs, peak, frac}
+against "pcie_peak", the link's own rate measured in the same run by plain pinned copies one way
+and both ways at once.  The host-fed legs and the probe run in a CHILD process without torch: the
+library then sits on /opt/rocm's HIP runtime, the one a Node or C caller of the drop-in loads
+(behind torch it shares torch's bundled runtime, under which pinned copies of opposite directions
+do not overlap -- profiles/r06_runtime_ab.txt).
 """
 import argparse
 import json

@@ -9,7 +9,10 @@
 # workload (parity block in each; cpu_baseline in the 1-stream ones)   -> r0N_bench_lines.jsonl
 # Results land in gpurun_out/prof_r0N/; copy the summaries into profiles/ by hand.
 N=${1:-06}
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_r$N; rm -rf $O; mkdir -p $O; cd $R
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_r$N; [ -z "$LINES_ONLY" ] && rm -rf $O; mkdir -p $O; cd $R
+# LINES_ONLY=1: skip the rocprofv3 passes (a second lease that only re-collects the bench lines and the host-side tools on
+# the traffic file of the first)
+if [ -z "$LINES_ONLY" ]; then
 cd /tmp && export TMPDIR=/tmp
 for CFG in cfg2 cfg3 cfg4 f3; do
   for S in 1 32; do
@@ -73,12 +76,14 @@ for cfg in ('cfg2', 'cfg3', 'cfg4', 'f3'):
         f = summary.get('pmc_FETCH_SIZE_%s_s%d' % (cfg, s), {}).get('FETCH_SIZE')
         w = summary.get('pmc_WRITE_SIZE_%s_s%d' % (cfg, s), {}).get('WRITE_SIZE')
         if f and w:
-            traffic['%s_s%d_fast_fixed' % (cfg, s)]  # (bench.py's default mode since round 6) = int(round(2 * f['avg_per_dispatch'] * 1024 + w['avg_per_dispatch'] * 1024))
+            traffic['%s_s%d_fast_fixed' % (cfg, s)] = int(round(2 * f['avg_per_dispatch'] * 1024 + w['avg_per_dispatch'] * 1024))
 json.dump(summary, open(O + '/r%s_pmc_summary.json' % N, 'w'), indent=1)
 json.dump(traffic, open(O + '/pmc_traffic.json', 'w'), indent=1)
 shutil.copy(O + '/pmc_traffic.json', R + '/profiles/pmc_traffic.json')   # bench.py reads it from here
 print(json.dumps(traffic, indent=1))
 PY
+fi  # LINES_ONLY
+cd $R
 # bench lines AFTER the PMC passes: every line carries the traffic of this very collection
 : > $O/r${N}_bench_lines.jsonl
 python bench.py >> $O/r${N}_bench_lines.jsonl 2> $O/bench_default.err
@@ -109,7 +114,7 @@ for CFG in cfg2 cfg3 cfg4; do
     python bench.py --config $CFG --mode fast --streams $S --steps 60 --no-cpu-baseline >> $O/r${N}_bench_lines.jsonl 2>/dev/null
   done
 done
-python tools/pinned_path_bench.py > $O/r${N}_pinned_path.json 2>/dev/null
+SPEEXHIP_PY_NO_TORCH=1 python tools/pinned_path_bench.py > $O/r${N}_pinned_path.json 2>/dev/null   # (the runtime a Node / C caller loads)
 python bench.py --total-streams 256 --steps 10 --warmup 2 > $O/r${N}_bench_total256.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_form.json 2>/dev/null
 python tools/call_stamps.py > $O/r${N}_call_stamps.txt 2>/dev/null
