@@ -1810,7 +1810,9 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     //  is a plain DMA -- so that the call can take the pipelined path, inputs arriving while results leave: read in place,
     //  all the reads come first and all the pageable copies out after them, 32 x 2^20 stereo frames 5.4 ms against 4.0,
     //  profiles/r06_bench_driver_form_v2.json)
-    if (it.pin_in != nullptr && it.pin_out == nullptr && it.out_bytes >= kDirectCopyBytes) it.pin_in = nullptr;
+    if (it.pin_in != nullptr && it.pin_out == nullptr && it.out_bytes >= kDirectCopyBytes &&
+        diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_PIN_IN_COPY"), 1) != 0)  // (A/B: 0 = read in place even then)
+      it.pin_in = nullptr;
     if (it.pin_in != nullptr) pinned_bytes += it.in_bytes, it.in_bytes = 0;
     if (it.pin_out != nullptr) pinned_bytes += it.out_bytes, it.out_bytes = 0;
     it.work = it.plan.produced != 0 || it.plan.magic_used + it.plan.consumed != 0;
@@ -2095,12 +2097,16 @@ int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in
   static const int env_lanes = SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_LANES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_LANES")) : -1;  // A/B: 1 = never split
   for (auto &kv : by_device) {
     uint64_t bytes = 0;
-    for (uint32_t i : kv.second) {  // (inputs in the library's pinned blocks are read in place: nothing to stage, no second lane)
+    for (uint32_t i : kv.second) {
+      // (inputs in the library's pinned blocks do not count: read in place they need no thread, and copied from pinned
+      //  memory -- the rule of many_on_device for pinned chunks beside large pageable results -- the copy is a plain DMA that
+      //  does not keep its thread busy.  32 x 2^20 frames, pinned chunks, pageable results, one box: one lane 4.02 ms, two
+      //  4.54; read in place 5.3-5.4 either way -- tools/ab.sh over SPEEXHIP_MANY_LANES / SPEEXHIP_PIN_IN_COPY)
       const uint64_t b = static_cast<uint64_t>(in_len[i]) * st[i]->channels_ * (float_io ? 4 : 2);
       if (!pool::block_owns(in[i], b)) bytes += b;
     }
     // (from 128 MB of input: 32 x 2^20 stereo frames 4.11 -> 4.00 ms, 64 states 7.90 -> 7.14; at 67 MB nothing, 2.26 / 2.44)
-    const bool split = env_lanes != 1 && kv.second.size() >= 8 && bytes >= (static_cast<uint64_t>(128) << 20);
+    const bool split = env_lanes != 1 && kv.second.size() >= 8 && (env_lanes == 2 || bytes >= (static_cast<uint64_t>(128) << 20));  // (A/B: 2 = always)
     if (!split) {
       units.push_back(Unit{kv.first, 0, kv.second});
     } else {
