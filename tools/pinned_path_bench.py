@@ -27,7 +27,8 @@ def timed(fn, n, warm=3):
 
 
 cfgs = {"cfg2": (2, 44100, 48000, 7), "cfg3": (1, 24000, 48000, 10), "cfg4": (8, 48000, 44100, 5)}
-only = sys.argv[1:] or list(cfgs)
+one_line = '--one-line' in sys.argv  # for tools/ab.sh, which reads a command's last line
+only = [a for a in sys.argv[1:] if not a.startswith('--')] or list(cfgs)
 for name in only:
     ch, fi, fo, q = cfgs[name]
     for frames in (16384, 1 << 20):
@@ -120,4 +121,4 @@ for frames in (16384, 1 << 20):
         st.close()
     for b in bis + bos:
         b.close()
-print(json.dumps(out, indent=1))
+print(json.dumps(out) if one_line else json.dumps(out, indent=1))
