@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# (SPEEXHIP_LIB_PATH: same-box A/B of two builds of the library, tools/gpu_ab.sh; never set in tests)
+# (SPEEXHIP_LIB_PATH: same-box A/B of two builds of the library, tools/ab.sh and tools/lease.sh lib-ab)
 LIB_PATH = os.environ.get("SPEEXHIP_LIB_PATH") or os.path.join(PKG_DIR, "libspeexhip.so")
 
 MODE_FAST, MODE_EXACT, MODE_FAST_F32, MODE_FAST_FIXED = 0, 1, 2, 3

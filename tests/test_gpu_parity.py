@@ -1462,7 +1462,7 @@ def test_int16_window_plan_serves_int16_calls_until_a_float_call():
     samples in the history) the stream goes back to the float window -- until int16 calls have replaced the whole history
     (round 6; "for good" until then).  Int16 / float / int16 calls on
     one state against the oracle doing the same, FAST mode within +-1 LSB (float: relative), counters equal;
-    and the window kind shows in nothing but speed: SPEEXHIP_NO_W16-style A/B is tools/gpu_ab.sh's job."""
+    and the window kind shows in nothing but speed: SPEEXHIP_NO_W16-style A/B is tools/ab.sh's job."""
     # (16 channels 96k -> 11.025k, late in round 5: not even one period of the float window fits the LDS -- the plan exists for its
     #  int16 plan alone, float calls and every call after one run the exact kernel)
     for (ch, i, o, q) in [(2, 48000, 11025, 7), (4, 48000, 11025, 5), (2, 44100, 16000, 7), (16, 96000, 11025, 7)]:
