@@ -1770,6 +1770,46 @@ int grow_stage(int device, char **buf, size_t *cap_now, size_t want, bool pinned
   return SPEEXHIP_ERR_SUCCESS;
 }
 inline size_t align64(size_t v) { return (v + 63) & ~static_cast<size_t>(63); }
+
+// The stage's copy stream: a stream of its own that carries host -> device copies and NOTHING else, made and primed here.
+// Why (late in round 6; profiles/r06_engine_log.txt, r06_pinned_in_leg.txt): the runtime picks a copy engine per stream --
+// for a copy in, the lowest engine free at the moment it asks; for a copy out, the engine ROCr recommends for that
+// direction (0x2 on this box) -- and then KEEPS it for that stream whatever the direction of the stream's later copies.
+// The pool's streams are shared with every state's own calls, which copy both ways: a copy stream that had last carried
+// a state's results kept engine 0x2 for the inputs of the next many-states call, the 32 queued copies in of a call over
+// pinned chunks went ahead of every copy out on that one engine, and the call took 6.0-6.3 ms instead of 4.0 (pageable
+// chunks: 5.5 instead of 3.8) -- or not, depending on which calls the process had made before.  A stream that only ever
+// copies in asks once, here, one stage at a time and with its copy waited for, so that the lowest engine is free when
+// the next stage asks: every stage's inputs travel on engine 0x1, the results on 0x2 / 0x4.
+int prime_copy_stream(int device, ManyStage &ms) {
+  static std::mutex one_at_a_time;
+  std::lock_guard<std::mutex> lock(one_at_a_time);
+  if (ms.copy_stream != nullptr) return SPEEXHIP_ERR_SUCCESS;
+  DeviceScope scope(device);
+  HIP_TRY(scope.error());
+  hipStream_t s = nullptr;
+  HIP_TRY(pool::stream_own(device, &s));
+  const size_t bytes = 64 * 1024;  // (above the 16 KiB the runtime copies with a kernel: a copy ENGINE must be asked for)
+  void *h = nullptr, *d = nullptr;
+  hipEvent_t e = nullptr;
+  int rc = SPEEXHIP_ERR_SUCCESS;
+  if (hip_failed(pool::pinned_get(&h, bytes), "hipHostMalloc") || hip_failed(pool::device_get(device, &d, bytes), "hipMalloc") ||
+      hip_failed(pool::event_get(device, &e), "hipEventCreate") ||
+      hip_failed(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync (priming)") ||
+      hip_failed(hipEventRecord(e, s), "hipEventRecord") ||
+      // (the EVENT is waited for, not the stream: the stream is never synchronised, the engine it was given stays its own)
+      hip_failed(hipEventSynchronize(e), "hipEventSynchronize"))
+    rc = SPEEXHIP_ERR_DEVICE;
+  if (e != nullptr) pool::event_put(device, e);
+  if (d != nullptr) pool::device_put(device, d);
+  if (h != nullptr) pool::pinned_put(h);
+  if (rc != SPEEXHIP_ERR_SUCCESS) {
+    (void)hipStreamDestroy(s);
+    return rc;
+  }
+  ms.copy_stream = s;
+  return SPEEXHIP_ERR_SUCCESS;
+}
 }  // namespace
 
 // The fused states of ONE device: idx = their positions in the caller's arrays.
@@ -1939,8 +1979,8 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     // inputs), while a second thread waits for the events, runs the launches on the stage's stream and copies each
     // launch's results out behind it: results leave while the next inputs arrive.
     if (ms.copy_stream == nullptr) {
-      for (int tries = 0; tries < 4 && (ms.copy_stream == nullptr || ms.copy_stream == ms.stream); tries++)
-        HIP_TRY(pool::stream_get(device, &ms.copy_stream));
+      const int prc = prime_copy_stream(device, ms);  // (process_host_many has done this for every large unit, one after the other)
+      if (prc != SPEEXHIP_ERR_SUCCESS) return prc;
     }
     while (ms.events.size() < launches.size()) {
       hipEvent_t e = nullptr;
@@ -2113,6 +2153,17 @@ int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in
       const size_t half = kv.second.size() / 2;
       units.push_back(Unit{kv.first, 0, std::vector<uint32_t>(kv.second.begin(), kv.second.begin() + half)});
       units.push_back(Unit{kv.first, 1, std::vector<uint32_t>(kv.second.begin() + half, kv.second.end())});
+    }
+  }
+  // (the copy streams of the units that will take the pipelined path: made and primed one after the other, before any
+  //  unit copies anything -- prime_copy_stream)
+  for (const Unit &u : units) {
+    uint64_t bytes = 0;
+    for (uint32_t i : u.idx) bytes += static_cast<uint64_t>(in_len[i]) * st[i]->channels_ * (float_io ? 4 : 2);
+    if (bytes >= (static_cast<uint64_t>(32) << 20)) {
+      ManyStage &ms = many_stage(u.device, u.lane);
+      std::lock_guard<std::mutex> lock(ms.mu);  // (the order many_on_device takes them in: the stage, then the priming)
+      (void)prime_copy_stream(u.device, ms);   // (a failure shows again, with its code, in the unit's own call)
     }
   }
   std::vector<int> dev_rc(units.size(), SPEEXHIP_ERR_SUCCESS);

@@ -324,6 +324,12 @@ hipError_t stream_get(int device, hipStream_t *out) {
 
 void stream_put(int, hipStream_t) {}  // shared: nothing to give back
 
+// A stream of the caller's own (not one of the shared ones; never given back): the many-states stages' copy streams
+hipError_t stream_own(int, hipStream_t *out) {
+  MissTimer timer("hipStreamCreate (a stage's copy stream)", 0);
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 // Warm-up (engine.cpp, warm_device): all of a device's shared streams made ahead of the first state -- the first
 // stream of a process costs 20-160 ms (the runtime sets up its hardware queues), each further one ~8 ms
 // (profiles/r05_first_call_trace.txt); made here, off the caller's path, a state's creation never meets that.

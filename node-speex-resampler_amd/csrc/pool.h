@@ -33,6 +33,8 @@ void pinned_put(void *ptr);
 // on it must be waited for by the call that queued it.
 hipError_t stream_get(int device, hipStream_t *s);
 void stream_put(int device, hipStream_t s);
+// ... and a stream that is NOT shared (made now, on the calling thread's current device = `device`; kept by the caller)
+hipError_t stream_own(int device, hipStream_t *s);
 hipError_t streams_prewarm(int device);  // make the device's shared streams now (warm-up)
 // A timing-disabled event of `device` (lent, returned with event_put).
 hipError_t event_get(int device, hipEvent_t *e);

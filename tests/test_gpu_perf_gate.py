@@ -47,3 +47,28 @@ def test_no_workload_is_slower_than_its_ceiling():
             late.append(report[-1])
     print("box: %.3f GHz under load (slowest workgroup %.3f), ceilings x %.3f\n" % (ghz, ghz_min, slack) + "\n".join(report))
     assert not late, "slower than the ceiling of profiles/perf_floor.json (box at %.3f GHz):\n%s" % (ghz, "\n".join(late))
+
+
+@pytest.mark.skipif(os.environ.get("SPEEXHIP_PERF_GATE") == "0", reason="SPEEXHIP_PERF_GATE=0")
+def test_many_states_call_keeps_its_rate_after_separate_calls():
+    """Late in round 6 (profiles/r06_pinned_in_leg.txt, r06_engine_log.txt): the runtime keeps, per stream, the copy engine
+    it last gave it; the many-states call's copy stream was one of the pool's shared streams, and once the states' own
+    calls had carried results on it, the inputs of the next large many-states call travelled on the results' engine --
+    32 x 2^20 stereo frames 3.8 -> 5.5 ms from pageable chunks, 4.0 -> 6.1 from pinned ones.  The stages now copy in on
+    streams of their own (prime_copy_stream).  Here: the call before and after 32 separate calls, and over pinned chunks,
+    in a child process without torch (behind torch's bundled runtime the two directions never overlap: nothing to lose)."""
+    import re
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEEXHIP_PY_NO_TORCH="1", SPEEXHIP_TAKE_MAX_MB="1024")
+    env.pop("SPEEXHIP_LIB_PATH", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "many_pinned_probe.py"), "--calls", "6",
+                        "many", "apart", "many", "pinned_in"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-800:]
+    line = p.stdout.strip().splitlines()[-1]
+    ms = [(m.group(1), float(m.group(2))) for m in re.finditer(r"(\w+) ([0-9.]+) \(min", line)]
+    assert [n for n, _ in ms] == ["many", "apart", "many", "pinned_in"], line
+    first, _, again, pinned = (v for _, v in ms)
+    print(line)
+    assert again <= 1.2 * first, "the many-states call after separate calls: %s" % line
+    assert pinned <= 1.25 * first, "the many-states call over pinned chunks after separate calls: %s" % line
