@@ -1853,6 +1853,10 @@ int Batch::many_on_device(int device, int lane, const std::vector<uint32_t> &idx
     if (it.pin_in != nullptr && it.pin_out == nullptr && it.out_bytes >= kDirectCopyBytes &&
         diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_PIN_IN_COPY"), 1) != 0)  // (A/B: 0 = read in place even then)
       it.pin_in = nullptr;
+    // (experiment, diagnostics: large chunks AND results in pinned memory by the copy engines as well, pipelined)
+    if (it.pin_in != nullptr && it.pin_out != nullptr && it.in_bytes >= kDirectCopyBytes && it.out_bytes >= kDirectCopyBytes &&
+        diag_int(SPEEXHIP_DIAG_ENV("SPEEXHIP_PIN_BOTH_COPY"), 0) != 0)
+      it.pin_in = nullptr, it.pin_out = nullptr;
     if (it.pin_in != nullptr) pinned_bytes += it.in_bytes, it.in_bytes = 0;
     if (it.pin_out != nullptr) pinned_bytes += it.out_bytes, it.out_bytes = 0;
     it.work = it.plan.produced != 0 || it.plan.magic_used + it.plan.consumed != 0;
@@ -2136,16 +2140,25 @@ int Batch::process_host_many(uint32_t n, Batch *const *st, const void *const *in
   std::vector<Unit> units;
   static const int env_lanes = SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_LANES") ? std::atoi(SPEEXHIP_DIAG_ENV("SPEEXHIP_MANY_LANES")) : -1;  // A/B: 1 = never split
   for (auto &kv : by_device) {
-    uint64_t bytes = 0;
+    // What a lane is for: the runtime's PAGEABLE copies keep the thread that issues them busy, so the bytes that count are
+    // the pageable ones of the busier direction.  Buffers in the library's pinned blocks do not count (a range check; read or
+    // written in place -- or, chunks beside large pageable results, copied by a plain DMA that keeps no thread).
+    // 32 x 2^20 stereo frames, one box (profiles/r06_pin_both_copy.txt, r06_pinned_in_leg.txt): pageable both ways one lane
+    // 4.11, two 3.80 ms; pinned chunks + pageable results (146 MB out) 4.04 -> 3.83; both pinned 3.61 / 3.65 (nothing to
+    // split).  (Until the stages had copy streams of their own -- prime_copy_stream -- the second case measured 4.02 / 4.54:
+    // that was the copy engines' lottery, not the lanes.)
+    uint64_t bytes_in = 0, bytes_out = 0;
     for (uint32_t i : kv.second) {
-      // (inputs in the library's pinned blocks do not count: read in place they need no thread, and copied from pinned
-      //  memory -- the rule of many_on_device for pinned chunks beside large pageable results -- the copy is a plain DMA that
-      //  does not keep its thread busy.  32 x 2^20 frames, pinned chunks, pageable results, one box: one lane 4.02 ms, two
-      //  4.54; read in place 5.3-5.4 either way -- tools/ab.sh over SPEEXHIP_MANY_LANES / SPEEXHIP_PIN_IN_COPY)
-      const uint64_t b = static_cast<uint64_t>(in_len[i]) * st[i]->channels_ * (float_io ? 4 : 2);
-      if (!pool::block_owns(in[i], b)) bytes += b;
+      const uint64_t es = float_io ? 4 : 2;
+      const uint64_t b = static_cast<uint64_t>(in_len[i]) * st[i]->channels_ * es;
+      if (in[i] != nullptr && !pool::block_owns(in[i], b)) bytes_in += b;
+      // (results: about den / num of the input's frames, capped by the caller's capacity)
+      const uint64_t frames_out = std::min<uint64_t>(out_len[i], static_cast<uint64_t>(in_len[i]) * st[i]->filter_.den / std::max<uint32_t>(st[i]->filter_.num, 1) + 1);
+      const uint64_t o = frames_out * st[i]->channels_ * es;
+      if (out[i] != nullptr && !pool::block_owns(out[i], o)) bytes_out += o;
     }
-    // (from 128 MB of input: 32 x 2^20 stereo frames 4.11 -> 4.00 ms, 64 states 7.90 -> 7.14; at 67 MB nothing, 2.26 / 2.44)
+    const uint64_t bytes = std::max(bytes_in, bytes_out);
+    // (from 128 MB: 32 x 2^20 stereo frames 4.11 -> 4.00 ms, 64 states 7.90 -> 7.14; at 67 MB nothing, 2.26 / 2.44)
     const bool split = env_lanes != 1 && kv.second.size() >= 8 && (env_lanes == 2 || bytes >= (static_cast<uint64_t>(128) << 20));  // (A/B: 2 = always)
     if (!split) {
       units.push_back(Unit{kv.first, 0, kv.second});
