@@ -2173,8 +2173,8 @@ def test_fast_fixed_mode_bytes_do_not_depend_on_chunking_or_batch_size(ch, i, o,
 def test_large_many_states_call_runs_pipelined_and_matches():
     """Round 5: a many-states call of >= 32 MB of large buffers runs in pieces -- the calling thread copies launch
     after launch's inputs on one stream, a second thread launches behind each event and copies that launch's results out
-    while the next inputs arrive (PCIe both ways at once).  12 stereo states x 2^20 frames (50 MB in), two consecutive
-    calls: EXACT bytes equal the oracle's for three states and the separate single-state calls' for all; counters,
+    while the next inputs arrive (PCIe both ways at once).  12 stereo states x 2^20 frames (50 MB in), three consecutive
+    calls (the third over chunks in pinned blocks): EXACT bytes equal the oracle's for three states and the separate single-state calls' for all; counters,
     positions, histories equal.  SPEEXHIP_MANY_PIPELINE=0 (a child process) is the same call in one piece."""
     import sys
     ch, i, o, q, S, frames = 2, 44100, 48000, 7, 12, 1 << 20
@@ -2182,9 +2182,17 @@ def test_large_many_states_call_runs_pipelined_and_matches():
     many = [speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT) for _ in range(S)]
     apart = [speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT) for _ in range(S)]
     refs = {s: orc.Oracle(ch, i, o, q) for s in (0, 5, 11)}
-    for call in range(2):
+    blocks = []
+    for call in range(3):
         chunks = [orc.lcg_pcm(frames * ch, 100 * call + s).reshape(frames, ch) for s in range(S)]
-        outs, used, codes = speexhip.process_many(many, chunks, [cap] * S)
+        fed = chunks
+        if call == 2:
+            # (late in round 6: the chunks in pinned blocks, the results pageable -- copied in by plain DMAs on the stage's
+            #  own copy stream, same pieces)
+            pinned = [_pinned_copy(x) for x in chunks]
+            blocks += [b for b, _ in pinned]
+            fed = [v for _, v in pinned]
+        outs, used, codes = speexhip.process_many(many, fed, [cap] * S)
         assert codes == [0] * S
         for s in range(S):
             want, wu = apart[s].process(chunks[s], cap)
@@ -2197,6 +2205,8 @@ def test_large_many_states_call_runs_pipelined_and_matches():
         assert np.array_equal(many[s].history(), apart[s].history())
     for r in many + apart:
         r.close()
+    for b in blocks:
+        b.close()
     if os.environ.get("SPEEXHIP_MANY_PIPELINE") is None:
         env = diag_env(SPEEXHIP_MANY_PIPELINE="0")
         res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
