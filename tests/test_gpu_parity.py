@@ -2221,7 +2221,8 @@ def test_many_states_calls_from_several_threads_at_once():
     import threading
     ch, i, o, q = 2, 44100, 48000, 7
     sets = [[speexhip.Resampler(ch, i, o, q, mode=speexhip.MODE_EXACT) for _ in range(9)] for _ in range(3)]
-    steps = [2000, 160, 70000, 5, 16384, 160, 300000, 1000]
+    # (2^20 frames x 9 states = 38 MB: the pipelined form, with its own copy stream primed while the other threads copy)
+    steps = [2000, 160, 70000, 5, 16384, 160, 300000, 1000, 1 << 20, 480]
     got = [[[] for _ in s] for s in sets]
     errors = []
 
