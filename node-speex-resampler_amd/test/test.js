@@ -190,6 +190,20 @@ async function goldenBatchTest() {
     ran++;
   }
   assert(ran >= 3, 'goldenBatchTest ran too few cases');
+  // a chunk that starts anywhere inside a pinned block (Buffer.subarray of an allocChunk block): read where it lies, at
+  // whatever alignment, with the bytes of the same chunk in an ordinary Buffer
+  {
+    const n = 2 * 2 * 30000;
+    const src = Buffer.alloc(n);
+    for (let k = 0; k < n; k += 2) src.writeInt16LE(((k * 2654435761) >>> 17) % 60000 - 30000, k);
+    const want = new SpeexResampler(2, 44100, 48000, 7).processChunk(src);
+    for (const off of [2, 6, 10, 64]) {
+      const block = SpeexResampler.allocChunk(n + 128);
+      src.copy(block, off);
+      const got = new SpeexResampler(2, 44100, 48000, 7).processChunk(block.subarray(off, off + n));
+      assert(Buffer.compare(got, want) === 0, `pinned chunk at byte offset ${off}: bytes differ`);
+    }
+  }
   const st = require('../speex_hip_napi.node').stats();
   if (process.env.SPEEXHIP_NAPI_COPY !== '1') assert(st.pinnedChunks > 0, 'allocChunk never returned a pinned chunk');
   console.log(`golden cases through SpeexResamplerBatch / the coalescer / pinned chunks / Transform{pinned}: ${ran} (pinned chunks handed out: ${st.pinnedChunks})`);

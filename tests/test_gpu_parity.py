@@ -2327,6 +2327,70 @@ def test_pinned_input_and_output_blocks_are_used_in_place(ch, i, o, q, frames):
             blk_out.close()
 
 
+@pytest.mark.parametrize("ch,i,o,q,frames", [(1, 44100, 48000, 7, 200000), (2, 44100, 48000, 7, 300000), (1, 24000, 48000, 5, 100000),
+                                              (1, 24000, 48000, 10, 100000), (8, 48000, 44100, 5, 60000), (3, 44100, 16000, 6, 50000),
+                                              (2, 44100, 48300, 3, 30000), (1, 48000, 11025, 7, 200000), (2, 16000, 48000, 7, 2000)])
+def test_pinned_chunks_at_any_sample_offset_inside_a_block(ch, i, o, q, frames):
+    """Late in round 6.  Read in place, a pinned chunk reaches the kernels at whatever address the caller has -- a
+    Buffer.subarray of an allocChunk block starts anywhere -- where a pageable chunk always arrived through the library's own
+    64-byte-aligned staging.  Chunks and results 2, 6 and 10 bytes into their blocks (int16) and 4 / 12 bytes (float),
+    every kernel family: the bytes of the aligned call (EXACT: the oracle's)."""
+    cap = frames * o // i + 64
+    for mode in (speexhip.MODE_EXACT, speexhip.MODE_FAST):
+        for off_in, off_out in ((1, 0), (3, 5), (0, 1), (5, 3)):
+            ref = orc.Oracle(ch, i, o, q)
+            r = speexhip.Resampler(ch, i, o, q, mode=mode)
+            aligned = speexhip.Resampler(ch, i, o, q, mode=mode)
+            blk_in, blk_out = speexhip.PinnedBlock((frames * ch + 8) * 2), speexhip.PinnedBlock((cap * ch + 8) * 2)
+            vin = blk_in.array(np.int16, (frames * ch + 8,))[off_in: off_in + frames * ch].reshape(frames, ch)
+            vout = blk_out.array(np.int16, (cap * ch + 8,))[off_out: off_out + cap * ch].reshape(cap, ch)
+            assert vin.ctypes.data % 4 == (2 * off_in) % 4 and vout.ctypes.data % 4 == (2 * off_out) % 4
+            for call in range(2):
+                x = orc.lcg_pcm(frames * ch, 1300 + call).reshape(frames, ch)
+                want, wu = ref.process(x, cap)
+                base, _ = aligned.process(np.ascontiguousarray(x), cap)
+                vin[...] = x
+                vout[...] = -7
+                used, made = r.process_into(vin, vout)
+                got = vout[:made].copy()
+                assert (vout[made:] == -7).all() and used == wu and made == want.shape[0] and r.position() == ref.position()
+                assert np.array_equal(got, base), ("offsets", off_in, off_out, mode, call, int(np.abs(got.astype(int) - base).max()))
+                if mode == speexhip.MODE_EXACT:
+                    assert np.array_equal(got, want)
+                # ... and through the copying entry with only the chunk pinned
+                if call == 1:
+                    again = speexhip.Resampler(ch, i, o, q, mode=mode)
+                    x0 = orc.lcg_pcm(frames * ch, 1300).reshape(frames, ch)
+                    vin[...] = x0
+                    g0, _ = again.process(vin, cap)
+                    a0 = speexhip.Resampler(ch, i, o, q, mode=mode)
+                    b0, _ = a0.process(np.ascontiguousarray(x0), cap)
+                    assert np.array_equal(g0, b0), ("in+copy", off_in, mode)
+                    again.close()
+                    a0.close()
+            r.close()
+            aligned.close()
+            blk_in.close()
+            blk_out.close()
+    if o != 48300:
+        rf, af = speexhip.Resampler(ch, i, o, q), speexhip.Resampler(ch, i, o, q)
+        n = min(frames, 50000)
+        capf = n * o // i + 64
+        bi, bo = speexhip.PinnedBlock((n * ch + 8) * 4), speexhip.PinnedBlock((capf * ch + 8) * 4)
+        for off_in, off_out in ((1, 3), (3, 1)):
+            vin = bi.array(np.float32, (n * ch + 8,))[off_in: off_in + n * ch].reshape(n, ch)
+            vout = bo.array(np.float32, (capf * ch + 8,))[off_out: off_out + capf * ch].reshape(capf, ch)
+            x = (orc.lcg_pcm(n * ch, 77 + off_in).astype(np.float32) / 32768.0).reshape(n, ch)
+            vin[...] = x
+            used, made = rf.process_into(vin, vout, float_io=True)
+            base, _ = af.process_float(np.ascontiguousarray(x), capf)
+            assert made == base.shape[0] and np.array_equal(vout[:made], base), ("float offsets", off_in, off_out)
+        rf.close()
+        af.close()
+        bi.close()
+        bo.close()
+
+
 def test_memory_the_caller_pinned_itself_is_recognised_and_float_calls_too():
     """hipHostMalloc'ed memory that is not the library's (a torch pinned tensor) takes the same in-place path from
     256 KB (pinned_view asks the runtime about both ends of the buffer); below that it is an ordinary buffer.  Float
