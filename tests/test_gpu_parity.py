@@ -2391,6 +2391,36 @@ def test_pinned_chunks_at_any_sample_offset_inside_a_block(ch, i, o, q, frames):
         bo.close()
 
 
+def test_a_pinned_result_that_overlaps_its_pinned_chunk_takes_the_chunk_in_first():
+    """On pageable buffers a result that overlaps its chunk works as it does in no resampler that streams -- the chunk is
+    copied to the device whole before a sample is written -- and callers may have come to rely on it (a decimator run "in
+    place").  In pinned memory the kernel would read what it is overwriting; the library sees the overlap and takes the
+    chunk in first, there too: same bytes as with separate buffers, single call and many-states call."""
+    import ctypes as C
+    ch, i, o, q, frames = 2, 48000, 24000, 5, 200000
+    cap = frames * o // i + 64
+    x = orc.lcg_pcm(frames * ch, 4242).reshape(frames, ch)
+    base, _ = speexhip.Resampler(ch, i, o, q).process(np.ascontiguousarray(x), cap)
+    for shift in (0, 64, 1000):   # result at the chunk's own address / a little into it
+        blk = speexhip.PinnedBlock((frames * ch + shift + 64) * 2)
+        whole = blk.array(np.int16, (frames * ch + shift + 64,))
+        vin = whole[: frames * ch].reshape(frames, ch)
+        vout = whole[shift: shift + cap * ch].reshape(cap, ch)
+        vin[...] = x
+        r = speexhip.Resampler(ch, i, o, q)
+        used, made = r.process_into(vin, vout)
+        assert used == frames and made == base.shape[0] and np.array_equal(vout[:made], base), ("single", shift)
+        r.close()
+        vin[...] = x
+        r = speexhip.Resampler(ch, i, o, q)
+        hs, ins, outs = (C.c_void_p * 1)(r._h), (C.c_void_p * 1)(vin.ctypes.data), (C.c_void_p * 1)(vout.ctypes.data)
+        il, ol, codes = (C.c_uint32 * 1)(frames), (C.c_uint32 * 1)(cap), (C.c_int * 1)()
+        assert speexhip.lib().speexhip_resampler_process_many_int(1, hs, ins, il, outs, ol, codes) == 0 and codes[0] == 0
+        assert il[0] == frames and ol[0] == base.shape[0] and np.array_equal(vout[: ol[0]], base), ("many", shift)
+        r.close()
+        blk.close()
+
+
 def test_memory_the_caller_pinned_itself_is_recognised_and_float_calls_too():
     """hipHostMalloc'ed memory that is not the library's (a torch pinned tensor) takes the same in-place path from
     256 KB (pinned_view asks the runtime about both ends of the buffer); below that it is an ordinary buffer.  Float
