@@ -20,6 +20,10 @@ namespace {
 // Size classes: 4 KiB, then powers of two with a half step in between (4, 6, 8, 12, 16 ... KiB): a
 // request is served with at most 1.5x its size.  Requests above kMaxPooled bypass the pool.
 const size_t kMinClass = 4096;
+// Pinned host memory the kernels of ANY device of the process may read and write where it lies (round 6: chunks and result
+// blocks are used in place, and a state may live on a GPU other than the one that was current when the slab was made):
+// portable = allocated for every context, mapped = in the devices' address space.
+const unsigned int kPinnedFlags = hipHostMallocPortable | hipHostMallocMapped;
 const size_t kMaxPooled = static_cast<size_t>(256) << 20;
 
 struct Shelf {
@@ -148,7 +152,7 @@ bool block_get(void **ptr, size_t bytes) {
   void *p = nullptr;
   {
     MissTimer timer("hipHostMalloc (slab of result blocks)", size);
-    if (hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, size, kPinnedFlags) != hipSuccess) {
       (void)hipGetLastError();
       ss.refused_for = kRetryCalls;
       return false;
@@ -268,7 +272,7 @@ hipError_t pinned_get(void **ptr, size_t bytes) {
     }
   }
   MissTimer timer("hipHostMalloc", cls);
-  const hipError_t e = hipHostMalloc(ptr, cls, hipHostMallocDefault);
+  const hipError_t e = hipHostMalloc(ptr, cls, kPinnedFlags);
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> lock(s.mu);
   s.live[*ptr] = pooled ? cls : 0;
